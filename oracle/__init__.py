@@ -1,0 +1,152 @@
+"""CPU oracle for the SoftRas hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package.  ``jrender_amd`` never does.
+
+Two interchangeable back-ends behind one NumPy interface:
+
+* ``kind="port"`` — ``oracle/softras_oracle.c``: our plain-C restatement of the
+  reference arithmetic (every function cites SRK/SRW file:line).
+* ``kind="reference"`` — ``oracle/_ref/libsoftras_ref.so``: the reference's own
+  kernel source compiled for the host by ``oracle/build_ref.py`` (only
+  buildable where ``/root/reference`` is mounted; the built ``.so`` travels).
+
+Argument handling mirrors the reference wrapper (SRW:10-42): ``dist_eps`` is
+mapped to ``log(1/dist_eps - 1)`` (SRW:25), the enum strings to the integer
+ids of SRW:39-42, every scalar is passed to the kernels as ``float``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_LIB = os.path.join(HERE, "libsoftras_oracle.so")
+REF_LIB = os.path.join(HERE, "_ref", "libsoftras_ref.so")
+
+DIST = {"hard": 0, "barycentric": 1, "euclidean": 2}          # SRW:39
+RGB = {"hard": 0, "softmax": 1, "none": 2}                    # SRW:40
+ALPHA = {"hard": 0, "sum": 1, "prod": 2}                      # SRW:41
+TEX = {"surface": 0, "vertex": 1}                             # SRW:42
+
+DEFAULTS = dict(image_size=256, near=1, far=100, fill_back=True, eps=1e-3, sigma_val=1e-5,
+                dist_func="euclidean", dist_eps=1e-4, gamma_val=1e-4, aggr_func_rgb="softmax",
+                aggr_func_alpha="prod", texture_type="surface", max_faces_per_pixel_for_grad=16)
+
+
+def make_port(force=False):
+    src = os.path.join(HERE, "softras_oracle.c")
+    if (not force and os.path.exists(PORT_LIB)
+            and os.path.getmtime(PORT_LIB) >= os.path.getmtime(src)):
+        return PORT_LIB
+    tmp = PORT_LIB + ".tmp%d" % os.getpid()
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                           "-fopenmp", "-fPIC", "-shared", src, "-o", tmp, "-lm"])
+    os.replace(tmp, PORT_LIB)
+    return PORT_LIB
+
+
+def make_ref(force=False):
+    import importlib
+    return importlib.import_module(__name__ + ".build_ref").build(force=force)
+
+
+def have_ref():
+    return os.path.exists(REF_LIB) or make_ref() is not None
+
+
+def _scalars(kw):
+    p = dict(DEFAULTS)
+    unknown = set(kw) - set(p) - {"background_color"}
+    if unknown:
+        raise TypeError("unknown parameters: %s" % sorted(unknown))
+    p.update(kw)
+    f32 = lambda v: C.c_float(float(np.float32(v)))
+    dist_eps_log = np.log(1.0 / p["dist_eps"] - 1.0)             # SRW:25
+    return p, dict(near=f32(p["near"]), far=f32(p["far"]), eps=f32(p["eps"]),
+                   sigma=f32(p["sigma_val"]), dist=DIST[p["dist_func"]],
+                   dist_eps=f32(dist_eps_log), gamma=f32(p["gamma_val"]),
+                   rgb=RGB[p["aggr_func_rgb"]], alpha=ALPHA[p["aggr_func_alpha"]],
+                   tex=TEX[p["texture_type"]], ds=int(bool(p["fill_back"])))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Oracle:
+    """forward()/backward() on NumPy arrays; layouts are the reference's."""
+
+    def __init__(self, kind="port", nthreads=0):
+        self.kind = kind
+        self.nthreads = int(nthreads)
+        if kind == "port":
+            self.lib = C.CDLL(make_port())
+            self.lib.orc_ub_events.restype = C.c_long
+        elif kind == "reference":
+            path = make_ref()
+            if path is None or not os.path.exists(path):
+                raise FileNotFoundError("oracle/_ref not built and /root/reference not mounted")
+            self.lib = C.CDLL(path)
+        else:
+            raise ValueError(kind)
+
+    def num_procs(self):
+        return (self.lib.orc_num_procs if self.kind == "port" else self.lib.ref_num_procs)()
+
+    def ub_events(self):
+        return int(self.lib.orc_ub_events()) if self.kind == "port" else 0
+
+    def forward(self, face_vertices, textures, **kw):
+        p, s = _scalars(kw)
+        fv = np.ascontiguousarray(face_vertices, np.float32)
+        B, NF = fv.shape[:2]
+        fv = fv.reshape(B, NF, 9)
+        tex = np.ascontiguousarray(textures, np.float32).reshape(B, NF, -1, 3)
+        T, IS, K = tex.shape[2], int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+        info = np.empty((B, NF, 27), np.float32)
+        aggr = np.empty((B, 2, IS, IS), np.float32)
+        rgba = np.empty((B, 4, IS, IS), np.float32)
+        ids = np.empty((B, K, IS, IS), np.int32)
+        common = (B, NF, T, IS, K, s["near"], s["far"], s["eps"], s["sigma"], s["dist"],
+                  s["dist_eps"], s["gamma"], s["rgb"], s["alpha"], s["tex"], s["ds"])
+        if self.kind == "port":
+            bg = kw.get("background_color")
+            bgp = None if bg is None else _fp(np.ascontiguousarray(bg, np.float32))
+            self.lib.orc_ub_reset()
+            rc = self.lib.orc_softras_forward(_fp(fv), _fp(tex), _fp(info), _fp(aggr), _fp(rgba),
+                                              _ip(ids), *common, bgp, self.nthreads)
+        else:
+            rc = self.lib.ref_softras_forward(_fp(fv), _fp(tex), _fp(info), _fp(aggr), _fp(rgba),
+                                              _ip(ids), *common, self.nthreads)
+        if rc:
+            raise RuntimeError("oracle forward failed rc=%d" % rc)
+        return dict(face_vertices=fv, textures=tex, soft_colors=rgba, faces_info=info,
+                    aggrs_info=aggr, faces_id_buffer=ids, params=p)
+
+    def backward(self, saved, grad_soft_colors, nthreads=1):
+        p, s = _scalars({k: v for k, v in saved["params"].items()})
+        fv, tex = saved["face_vertices"], saved["textures"]
+        B, NF, T = fv.shape[0], fv.shape[1], tex.shape[2]
+        IS, K = int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+        g = np.ascontiguousarray(grad_soft_colors, np.float32).reshape(B, 4, IS, IS)
+        gf = np.empty((B, NF, 9), np.float32)
+        gt = np.empty((B, NF, T, 3), np.float32)
+        common = (B, NF, T, IS, K, s["near"], s["far"], s["eps"], s["sigma"], s["dist"],
+                  s["dist_eps"], s["gamma"], s["rgb"], s["alpha"], s["tex"], s["ds"], int(nthreads))
+        ids = saved["faces_id_buffer"]
+        if self.kind == "port":
+            fn = self.lib.orc_softras_backward
+        else:
+            fn = self.lib.ref_softras_backward
+            ids = np.ascontiguousarray(ids.transpose(0, 2, 3, 1))            # SRW:108
+        rc = fn(_fp(fv), _fp(tex), _fp(saved["soft_colors"]), _fp(saved["faces_info"]),
+                _fp(saved["aggrs_info"]), _ip(ids), _fp(g), _fp(gf), _fp(gt), *common)
+        if rc:
+            raise RuntimeError("oracle backward failed rc=%d" % rc)
+        return gf.reshape(B, NF, 3, 3), gt

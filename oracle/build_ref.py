@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY — builds oracle/_ref/libsoftras_ref.so.
+
+Compiles the *reference's own* SoftRas kernel arithmetic for the host CPU,
+from the sources where they lie under /root/reference (nothing is copied into
+the repository; the extracted strings go to the git-ignored oracle/_ref/).
+
+Recipe:
+  1. put a stub ``jittor`` package on sys.path whose ``code(...)`` records its
+     keyword arguments instead of JIT-compiling CUDA;
+  2. import jrender/renderer/dr/softras/cuda/soft_rasterize.py by file path and
+     call forward_soft_rasterize / backward_soft_rasterize with dummy Vars —
+     this yields the ``cuda_header`` strings (the kernels, SRK:12-458 and
+     SRK:975-1362);
+  3. write them to oracle/_ref/srk_{fwd,bwd}.inc and compile
+     oracle/ref_driver.cpp (our launch glue) against oracle/ref_shim/ with
+     ``g++ -O2 -ffp-contract=off -fno-fast-math -fopenmp``.
+
+One textual patch is applied, and recorded here because it defines the oracle:
+``backward_sample_texture`` (SRK:1154-1174) returns an UNINITIALISED local for
+every texel that is not the sampled one (undefined behaviour inherited from
+official SoftRas; the evident intent is 0).  We initialise that local to 0.
+
+The result only exists where /root/reference exists (the build container);
+the .so then travels to the GPU box with the repo snapshot.
+"""
+import importlib.util
+import os
+import subprocess
+import sys
+import tempfile
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_ROOT = os.environ.get("JRENDER_REFERENCE", "/root/reference")
+SRK = os.path.join(REF_ROOT, "jrender/renderer/dr/softras/cuda/soft_rasterize.py")
+OUT_DIR = os.path.join(HERE, "_ref")
+LIB = os.path.join(OUT_DIR, "libsoftras_ref.so")
+
+CXXFLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+            "-fPIC", "-shared", "-fpermissive", "-w"]
+
+
+class _Var:
+    """Dummy jittor.Var: only .shape / .dtype are touched by the op wrappers."""
+
+    def __init__(self, shape, dtype="float32"):
+        self.shape, self.dtype = tuple(shape), dtype
+
+
+def _extract():
+    captured = []
+    stub = types.ModuleType("jittor")
+
+    def code(shapes, dtypes, inputs, **kw):
+        captured.append(kw)
+        return [_Var(s, d) for s, d in zip(shapes, dtypes)]
+
+    stub.code = code
+    saved = sys.modules.get("jittor")
+    sys.modules["jittor"] = stub
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_srk", SRK)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        B, NF, T, IS, K = 1, 1, 1, 4, 16
+        fv, tex = _Var((B, NF, 9)), _Var((B, NF, T, 3))
+        info, aggr = _Var((B, NF, 27)), _Var((B, 2, IS, IS))
+        rgba, ids = _Var((B, 4, IS, IS)), _Var((B, K, IS, IS), "int32")
+        scal = (IS, 1, 100, 1e-3, 1e-5, 2, 9.21, 1e-4, 1, 2, 0, 1)
+        mod.forward_soft_rasterize(fv, tex, info, aggr, rgba, ids, *scal)
+        mod.backward_soft_rasterize(fv, tex, rgba, info, aggr, ids, fv, tex, rgba, *scal)
+    finally:
+        if saved is None:
+            del sys.modules["jittor"]
+        else:
+            sys.modules["jittor"] = saved
+    fwd, bwd = captured[0]["cuda_header"], captured[1]["cuda_header"]
+    needle = "scalar_t grad_texture_k;"
+    if bwd.count(needle) != 1:
+        raise RuntimeError("reference backward_sample_texture changed; re-check the UB patch")
+    bwd = bwd.replace(needle, "scalar_t grad_texture_k = 0;")
+    return fwd, bwd
+
+
+def build(force=False):
+    """Build (or reuse) oracle/_ref/libsoftras_ref.so.  Returns its path, or
+    None when the reference tree is not mounted (e.g. on the GPU box)."""
+    if not os.path.exists(SRK):
+        return LIB if os.path.exists(LIB) else None
+    deps = [SRK, os.path.join(HERE, "ref_driver.cpp"), os.path.join(HERE, "ref_shim/cuda_runtime.h"),
+            os.path.abspath(__file__)]
+    if (not force and os.path.exists(LIB)
+            and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps)):
+        return LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    fwd, bwd = _extract()
+    with open(os.path.join(OUT_DIR, "srk_fwd.inc"), "w") as f:
+        f.write(fwd)
+    with open(os.path.join(OUT_DIR, "srk_bwd.inc"), "w") as f:
+        f.write(bwd)
+    tmp = tempfile.mktemp(suffix=".so", dir=OUT_DIR)
+    cmd = ["g++", *CXXFLAGS, "-I", HERE, "-I", os.path.join(HERE, "ref_shim"),
+           os.path.join(HERE, "ref_driver.cpp"), "-o", tmp]
+    subprocess.check_call(cmd, cwd=HERE)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

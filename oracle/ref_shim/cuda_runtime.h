@@ -1,0 +1,61 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle/_ref build).  Not part of the product.
+ *
+ * Minimal CUDA -> host shim: lets the reference's own SoftRas kernel source
+ * (jrender/renderer/dr/softras/cuda/soft_rasterize.py, the `cuda_header`
+ * strings at SRK:12-458 and SRK:975-1362) compile with g++ so that the
+ * reference arithmetic can run on the CPU.  Nothing from the reference is
+ * copied here: this file only supplies the names CUDA would supply.
+ *
+ * Semantics reproduced on purpose:
+ *   - CUDA's min/max overload set: (float,float)->float with fminf/fmaxf
+ *     NaN behaviour, mixed (float,double)/(double,float)->double,
+ *     (double,double)->double, (int,int)->int.
+ *   - exp/sqrt on float resolve to expf/sqrtf (std:: overloads).
+ *   - atomicAdd(float*) : `omp atomic` so the backward can be run in
+ *     parallel for the timing baseline; serial runs are deterministic.
+ */
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <math.h>
+
+#define __global__
+#define __device__
+#define __host__
+#define __restrict__
+#define __forceinline__ inline
+
+struct uint3_shim { unsigned x, y, z; };
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern thread_local uint3_shim blockIdx, threadIdx;
+extern thread_local dim3 blockDim, gridDim;
+
+typedef float float32;
+
+using std::exp;
+using std::sqrt;
+using std::isnan;
+
+static inline float  min(float a, float b)   { return fminf(a, b); }
+static inline float  max(float a, float b)   { return fmaxf(a, b); }
+static inline double min(double a, double b) { return fmin(a, b); }
+static inline double max(double a, double b) { return fmax(a, b); }
+static inline double min(float a, double b)  { return fmin((double)a, b); }
+static inline double max(float a, double b)  { return fmax((double)a, b); }
+static inline double min(double a, float b)  { return fmin(a, (double)b); }
+static inline double max(double a, float b)  { return fmax(a, (double)b); }
+static inline int    min(int a, int b)       { return a < b ? a : b; }
+static inline int    max(int a, int b)       { return a > b ? a : b; }
+
+static inline float atomicAdd(float* addr, float v) {
+    float old;
+#pragma omp atomic capture
+    { old = *addr; *addr += v; }
+    return old;
+}
