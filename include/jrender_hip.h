@@ -1,0 +1,125 @@
+/*
+ * jrender_hip.h — C ABI of the MI355X-native SoftRas hot path (libjrender_hip.so).
+ *
+ * Drop-in boundary for jrender's `soft_rasterize` operator.  The reference binds
+ * its kernels through Jittor's JIT operator `jt.code(out_shapes, out_dtypes,
+ * inputs, cuda_header, cuda_src)`:
+ *   forward  op: jrender/renderer/dr/softras/cuda/soft_rasterize.py:3-521
+ *                inputs {faces, textures} -> outputs {faces_info, aggrs_info,
+ *                soft_colors, faces_id_buffer}
+ *   backward op: jrender/renderer/dr/softras/cuda/soft_rasterize.py:966-1416
+ *                inputs {faces, textures, soft_colors, faces_info, aggrs_info,
+ *                grad_soft_colors, faces_id_buffer} -> {grad_faces, grad_textures}
+ * called from SoftRasterizeFunction.execute / .grad
+ * (jrender/renderer/dr/softras/soft_rasterize.py:34-103, :105-133).
+ * The entry points below are what an FFI for those two ops binds instead
+ * (ctypes stub: INTEGRATION.md).  Plain pointers and sizes only; every array
+ * pointer is a DEVICE pointer on the context's GPU unless marked "host".
+ *
+ * Conventions
+ *   - all functions return 0 on success, non-zero on failure; jr_last_error()
+ *     returns a thread-local message for the last failure.  (The reference only
+ *     printf's launch errors, SRK:487-489.)
+ *   - work is enqueued on the context's HIP stream; results are complete after
+ *     jr_synchronize() or any blocking copy.
+ *   - tensor layouts and dtypes are exactly the reference's (row-major, fp32 /
+ *     int32), EXCEPT that the backward takes faces_id_buffer in the forward's own
+ *     [B,K,IS,IS] layout: the reference's extra transpose to [B,IS,IS,K]
+ *     (soft_rasterize.py:108) is pure re-indexing and is skipped.
+ *   - scalars are passed as float exactly like the literals the reference
+ *     interpolates into its launches (SRK:485-516); `dist_eps` is the already
+ *     transformed value log(1/dist_eps - 1) of soft_rasterize.py:25.
+ */
+#ifndef JRENDER_HIP_H
+#define JRENDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jr_ctx jr_ctx; /* one per (process, GPU): device id, stream, scratch arena */
+
+/* enum ids = the reference's maps, soft_rasterize.py:39-42 */
+enum { JR_DIST_HARD = 0, JR_DIST_BARYCENTRIC = 1, JR_DIST_EUCLIDEAN = 2 };
+enum { JR_RGB_HARD = 0, JR_RGB_SOFTMAX = 1, JR_RGB_NONE = 2 };
+enum { JR_ALPHA_HARD = 0, JR_ALPHA_SUM = 1, JR_ALPHA_PROD = 2 };
+enum { JR_TEX_SURFACE = 0, JR_TEX_VERTEX = 1 };
+
+#define JR_MAX_FACES_PER_PIXEL 64 /* reference: kMaxPointsPerPixel, SRK:16 (unchecked there) */
+
+/* ---- runtime / memory (replaces what the Jittor runtime provided) ---------- */
+const char* jr_last_error(void);
+const char* jr_version(void);
+int jr_device_count(int* count);
+int jr_ctx_create(int device, jr_ctx** out);
+int jr_ctx_destroy(jr_ctx* ctx);
+int jr_ctx_device(const jr_ctx* ctx);
+void* jr_ctx_stream(const jr_ctx* ctx); /* hipStream_t */
+int jr_malloc(jr_ctx* ctx, size_t bytes, void** dptr);
+int jr_free(jr_ctx* ctx, void* dptr);
+int jr_memcpy_h2d(jr_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* blocking */
+int jr_memcpy_d2h(jr_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* blocking */
+int jr_memcpy_d2d(jr_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);  /* async   */
+int jr_memset(jr_ctx* ctx, void* dptr, int byte_value, size_t bytes);              /* async   */
+int jr_synchronize(jr_ctx* ctx);
+/* HIP events on the context's stream (benchmark timing) */
+int jr_event_create(jr_ctx* ctx, void** event);
+int jr_event_destroy(jr_ctx* ctx, void* event);
+int jr_event_record(jr_ctx* ctx, void* event);
+int jr_event_elapsed_ms(jr_ctx* ctx, void* start, void* stop, float* ms); /* syncs on stop */
+
+/* ---- SoftRas forward: replaces forward_soft_rasterize (SRK:3-521) ---------------
+ * in : face_vertices [B,NF,9] f32 (NDC x,y ; camera z per vertex), textures [B,NF,T,3] f32
+ * out: faces_info [B,NF,27] f32, aggrs_info [B,2,IS,IS] f32, soft_colors [B,4,IS,IS] f32,
+ *      faces_id_buffer [B,K,IS,IS] i32 (-1 = empty slot).  Outputs need no pre-initialisation.
+ * background_rgb: host pointer to 3 floats, or NULL = the reference's behaviour (background
+ *      colour ignored, i.e. 0; soft_rasterize.py:68-74 vs SRK:469).
+ * K = max_faces_per_pixel_for_grad, 1..JR_MAX_FACES_PER_PIXEL.  IS <= 4096.
+ */
+int jr_softras_forward(jr_ctx* ctx, const float* face_vertices, const float* textures,
+                       float* faces_info, float* aggrs_info, float* soft_colors,
+                       int32_t* faces_id_buffer, int B, int NF, int T, int IS, int K,
+                       float near_, float far_, float eps, float sigma_val, int func_id_dist,
+                       float dist_eps, float gamma_val, int func_id_rgb, int func_id_alpha,
+                       int texture_sample_type, int double_side, const float* background_rgb);
+
+/* ---- SoftRas backward: replaces backward_soft_rasterize (SRK:966-1416) ----------
+ * in : the forward's inputs and outputs + grad_soft_colors [B,4,IS,IS] f32
+ * out: grad_faces [B,NF,9] f32, grad_textures [B,NF,T,3] f32 (zeroed here, like SRK:1374-1375)
+ */
+int jr_softras_backward(jr_ctx* ctx, const float* face_vertices, const float* textures,
+                        const float* soft_colors, const float* faces_info,
+                        const float* aggrs_info, const int32_t* faces_id_buffer,
+                        const float* grad_soft_colors, float* grad_faces, float* grad_textures,
+                        int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
+                        float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                        int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                        int double_side);
+
+/* ---- adjacent steps the reference ran as Jittor tensor ops -----------------------
+ * face_vertices gather  vertices[B,NV,3] x faces[NF,3] (shared) -> [B,NF,9]
+ *   (jrender/structures/utils/faces_vertices.py:4-19) and its scatter-add backward
+ *   (was Jittor autograd).
+ * 2x2 mean pool for anti_aliasing (nn.pool(images, 2, "mean", stride=2),
+ *   jrender/renderer/dr/softras/rasterizer.py:54-55) and its backward.
+ */
+int jr_face_vertices_forward(jr_ctx* ctx, const float* vertices, const int32_t* faces,
+                             float* face_vertices, int B, int NV, int NF);
+int jr_face_vertices_backward(jr_ctx* ctx, const float* grad_face_vertices, const int32_t* faces,
+                              float* grad_vertices, int B, int NV, int NF);
+int jr_avgpool2x2_forward(jr_ctx* ctx, const float* in, float* out, int planes, int H, int W);
+int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, int planes, int H,
+                           int W);
+
+/* ---- introspection for tests / benchmarks ---------------------------------------- */
+/* statistics of the last forward on this context: [0]=tile-face pairs, [1]=non-empty tiles,
+ * [2]=max faces in a tile, [3]=tiles per image */
+int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JRENDER_HIP_H */

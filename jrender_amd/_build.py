@@ -1,0 +1,53 @@
+"""Builds jrender_amd/csrc/libjrender_hip.so in-tree with hipcc for gfx950.
+
+``python -m jrender_amd._build [--force]``.  The flags matter for parity:
+``-ffp-contract=off`` (no FMA contraction) and no fast-math, because the per-pixel
+face-index buffer must match the reference bit for bit.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libjrender_hip.so")
+SOURCES = ["jr_api.cpp", "binning.hip", "softras_forward.hip", "softras_backward.hip", "aux_kernels.hip"]
+HEADERS = ["jr_kernels.h", "softras_device.h", "../../include/jrender_hip.h"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+         "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([HIPCC, *FLAGS, "-x", "hip", "-c", src, "-o", obj])
+    if jobs:
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=CSRC)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or _stale(LIB, objs):
+        tmp = LIB + ".tmp%d" % os.getpid()
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp], cwd=CSRC)
+        os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

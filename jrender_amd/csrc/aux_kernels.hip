@@ -1,0 +1,88 @@
+// Small kernels adjacent to the SoftRas op which the reference ran as Jittor tensor ops.
+//   face_vertices gather  : jrender/structures/utils/faces_vertices.py:4-19
+//   its backward          : scatter-add (was Jittor autograd)
+//   2x2 mean pool (+bwd)  : nn.pool(images, 2, "mean", stride=2), softras/rasterizer.py:54-55
+// All are HBM-bound elementwise/gather passes: one coalesced read, one coalesced write.
+#include "jr_kernels.h"
+
+namespace jr {
+
+__global__ __launch_bounds__(256) void k_face_vertices_fwd(const float* __restrict__ v,
+                                                           const int32_t* __restrict__ faces,
+                                                           float* __restrict__ fv, int B, int NV, int NF) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (b, face, corner)
+    const long total = (long)B * NF * 3;
+    if (i >= total) return;
+    const long b = i / ((long)NF * 3);
+    const long fc = i - b * NF * 3;
+    const int vi = faces[fc];
+    const float* src = v + (b * NV + vi) * 3;
+    float* dst = fv + i * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+__global__ __launch_bounds__(256) void k_face_vertices_bwd(const float* __restrict__ gfv,
+                                                           const int32_t* __restrict__ faces,
+                                                           float* __restrict__ gv, int B, int NV, int NF) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * NF * 3;
+    if (i >= total) return;
+    const long b = i / ((long)NF * 3);
+    const long fc = i - b * NF * 3;
+    const int vi = faces[fc];
+    float* dst = gv + (b * NV + vi) * 3;
+    const float* src = gfv + i * 3;
+    atomicAdd(dst + 0, src[0]); atomicAdd(dst + 1, src[1]); atomicAdd(dst + 2, src[2]);
+}
+
+__global__ __launch_bounds__(256) void k_avgpool_fwd(const float* __restrict__ in, float* __restrict__ out,
+                                                     long total, int Ho, int Wo) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % Wo);
+    const long r = i / Wo;
+    const int y = (int)(r % Ho);
+    const long pl = r / Ho;
+    const float* s = in + (pl * (2 * Ho) + 2 * y) * (long)(2 * Wo) + 2 * x;
+    const float2 a = *reinterpret_cast<const float2*>(s);
+    const float2 b = *reinterpret_cast<const float2*>(s + 2 * Wo);
+    out[i] = (((a.x + a.y) + b.x) + b.y) / 4;
+}
+
+__global__ __launch_bounds__(256) void k_avgpool_bwd(const float* __restrict__ gout, float* __restrict__ gin,
+                                                     long total, int Ho, int Wo) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % Wo);
+    const long r = i / Wo;
+    const int y = (int)(r % Ho);
+    const long pl = r / Ho;
+    const float g = gout[i] / 4;
+    float* d = gin + (pl * (2 * Ho) + 2 * y) * (long)(2 * Wo) + 2 * x;
+    *reinterpret_cast<float2*>(d) = make_float2(g, g);
+    *reinterpret_cast<float2*>(d + 2 * Wo) = make_float2(g, g);
+}
+
+void launch_face_vertices_forward(hipStream_t st, const float* v, const int32_t* faces, float* fv, int B,
+                                  int NV, int NF) {
+    const long total = (long)B * NF * 3;
+    k_face_vertices_fwd<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(v, faces, fv, B, NV, NF);
+}
+void launch_face_vertices_backward(hipStream_t st, const float* gfv, const int32_t* faces, float* gv, int B,
+                                   int NV, int NF) {
+    hipMemsetAsync(gv, 0, sizeof(float) * (size_t)B * NV * 3, st);
+    const long total = (long)B * NF * 3;
+    k_face_vertices_bwd<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(gfv, faces, gv, B, NV, NF);
+}
+void launch_avgpool2x2_forward(hipStream_t st, const float* in, float* out, int planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)planes * Ho * Wo;
+    k_avgpool_fwd<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(in, out, total, Ho, Wo);
+}
+void launch_avgpool2x2_backward(hipStream_t st, const float* gout, float* gin, int planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)planes * Ho * Wo;
+    k_avgpool_bwd<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(gout, gin, total, Ho, Wo);
+}
+
+}  // namespace jr

@@ -1,0 +1,336 @@
+// C ABI of libjrender_hip.so — see include/jrender_hip.h for the contract and the reference
+// interfaces (file:line) each entry point replaces.  Host-side only: argument validation, the
+// per-context scratch arena for the tile lists, kernel launches on the context stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/jrender_hip.h"
+#include "jr_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define JR_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+}  // namespace
+
+struct jr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    jr::BinWorkspace ws;
+    unsigned long long* h_counters = nullptr;   // pinned, 4 entries
+    // identity of the tile lists currently held in ws (reused by the backward)
+    const void* bins_faces = nullptr;
+    int bins_B = 0, bins_NF = 0, bins_IS = 0;
+    float bins_rad = 0.f;
+    bool bins_valid = false;
+    int64_t stats[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+template <typename T>
+int grow(T*& ptr, size_t& cap, size_t need, double slack) {
+    if (need <= cap && ptr) return 0;
+    if (ptr) JR_HIP(hipFree(ptr));
+    ptr = nullptr;
+    const size_t ncap = (size_t)(need * slack) + 1024;
+    JR_HIP(hipMalloc((void**)&ptr, sizeof(T) * ncap));
+    cap = ncap;
+    return 0;
+}
+
+int validate(int B, int NF, int T, int IS, int K, int dist, int rgb, int alpha, int tex) {
+    if (B < 1 || NF < 1 || T < 1 || IS < 1) return fail("B, NF, T, image_size must be >= 1 (got %d %d %d %d)", B, NF, T, IS);
+    if (IS > 256 * jr::TILE) return fail("image_size %d exceeds the supported maximum %d", IS, 256 * jr::TILE);
+    if (K < 1 || K > JR_MAX_FACES_PER_PIXEL)
+        return fail("max_faces_per_pixel_for_grad must be in [1,%d] (got %d)", JR_MAX_FACES_PER_PIXEL, K);
+    if (dist < 0 || dist > 2) return fail("func_id_dist must be 0 (hard), 1 (barycentric) or 2 (euclidean)");
+    if (rgb < 0 || rgb > 2) return fail("func_id_rgb must be 0 (hard), 1 (softmax) or 2 (none)");
+    if (alpha < 0 || alpha > 2) return fail("func_id_alpha must be 0 (hard), 1 (sum) or 2 (prod)");
+    if (tex < 0 || tex > 1) return fail("texture_sample_type must be 0 (surface) or 1 (vertex)");
+    if (tex == 1 && T < 3) return fail("texture_type 'vertex' needs 3 colours per face (T=%d)", T);
+    if ((long)NF >= (1L << 24) && rgb == 0)
+        return fail("aggr_func_rgb='hard' stores the face index as float: NF must be < 2^24");
+    return 0;
+}
+
+jr::RasterParams make_params(int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
+                             float sigma, int dist, float dist_eps, float gamma, int rgb, int alpha,
+                             int tex, int double_side, const float* bg) {
+    jr::RasterParams p;
+    p.B = B; p.NF = NF; p.T = T; p.R = (int)std::sqrt((double)T); p.IS = IS; p.K = K;      // SRK:475
+    p.near_ = near_; p.far_ = far_; p.eps = eps; p.sigma = sigma; p.dist_eps = dist_eps; p.gamma = gamma;
+    p.thr = dist_eps * sigma;                                                              // SRK:289 (float multiply)
+    p.rad = sqrtf(p.thr);                                                                  // SRK:316
+    p.dist = dist; p.rgb = rgb; p.alpha = alpha; p.tex = tex; p.double_side = double_side ? 1 : 0;
+    for (int k = 0; k < 3; k++) p.bg[k] = bg ? bg[k] : 0.f;
+    p.tiles_x = (IS + jr::TILE - 1) / jr::TILE;
+    p.tiles_y = p.tiles_x;
+    return p;
+}
+
+// Build (or rebuild) the per-tile ascending face lists for this geometry.
+int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, float* faces_info) {
+    const size_t nfaces = (size_t)p.B * p.NF, ntiles = (size_t)p.B * p.tiles_x * p.tiles_y;
+    jr::BinWorkspace& ws = ctx->ws;
+    if (grow(ws.face_rect, ws.faces_cap, nfaces, 1.0)) return 1;
+    if (ntiles > ws.tiles_cap || !ws.tile_count) {
+        size_t c0 = ws.tiles_cap, c1 = ws.tiles_cap, c2 = ws.tiles_cap;
+        if (grow(ws.tile_count, c0, ntiles, 1.0)) return 1;
+        if (grow(ws.tile_base, c1, ntiles, 1.0)) return 1;
+        if (grow(ws.tile_cursor, c2, ntiles, 1.0)) return 1;
+        ws.tiles_cap = c0;
+    }
+    jr::launch_binning(ctx->stream, p, faces, faces_info, ws);
+    JR_HIP(hipMemcpyAsync(ctx->h_counters, ws.counters, sizeof(unsigned long long) * 4,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t pairs = (size_t)ctx->h_counters[0];
+    ctx->stats[0] = (int64_t)pairs;
+    ctx->stats[1] = (int64_t)ctx->h_counters[1];
+    ctx->stats[2] = (int64_t)ctx->h_counters[2];
+    ctx->stats[3] = (int64_t)p.tiles_x * p.tiles_y;
+    if (pairs > ws.pool_cap || !ws.pool) {
+        size_t c0 = ws.pool_cap, c1 = ws.pool_cap;
+        if (grow(ws.pool, c0, pairs, 1.25)) return 1;
+        if (grow(ws.pool_scratch, c1, pairs, 1.25)) return 1;
+        ws.pool_cap = c0;
+    }
+    jr::launch_bin_fill_sort(ctx->stream, p, ws);
+    JR_HIP(hipGetLastError());
+    ctx->bins_faces = faces; ctx->bins_B = p.B; ctx->bins_NF = p.NF; ctx->bins_IS = p.IS;
+    ctx->bins_rad = p.rad; ctx->bins_valid = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* jr_last_error(void) { return g_err; }
+const char* jr_version(void) { return "jrender_hip 0.1 (gfx950)"; }
+
+int jr_device_count(int* count) {
+    JR_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+
+int jr_ctx_create(int device, jr_ctx** out) {
+    if (!out) return fail("jr_ctx_create: out is NULL");
+    int n = 0;
+    JR_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail("jr_ctx_create: device %d out of range (%d visible)", device, n);
+    JR_HIP(hipSetDevice(device));
+    jr_ctx* c = new (std::nothrow) jr_ctx();
+    if (!c) return fail("out of host memory");
+    c->device = device;
+    JR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    JR_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * 4, hipHostMallocDefault));
+    JR_HIP(hipMalloc((void**)&c->ws.counters, sizeof(unsigned long long) * 4));
+    *out = c;
+    return 0;
+}
+
+int jr_ctx_destroy(jr_ctx* ctx) {
+    if (!ctx) return 0;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    jr::BinWorkspace& ws = ctx->ws;
+    hipFree(ws.face_rect); hipFree(ws.tile_count); hipFree(ws.tile_base); hipFree(ws.tile_cursor);
+    hipFree(ws.counters); hipFree(ws.pool); hipFree(ws.pool_scratch);
+    hipHostFree(ctx->h_counters);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int jr_ctx_device(const jr_ctx* ctx) { return ctx ? ctx->device : -1; }
+void* jr_ctx_stream(const jr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int jr_malloc(jr_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return fail("jr_malloc: NULL argument");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return 0;
+}
+int jr_free(jr_ctx* ctx, void* dptr) {
+    if (!ctx) return fail("jr_free: NULL context");
+    JR_HIP(hipSetDevice(ctx->device));
+    if (ctx->bins_faces == dptr) ctx->bins_valid = false;
+    JR_HIP(hipFree(dptr));
+    return 0;
+}
+int jr_memcpy_h2d(jr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return fail("NULL context");
+    JR_HIP(hipSetDevice(ctx->device));
+    if (ctx->bins_faces == dst) ctx->bins_valid = false;
+    JR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int jr_memcpy_d2h(jr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return fail("NULL context");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int jr_memcpy_d2d(jr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return fail("NULL context");
+    JR_HIP(hipSetDevice(ctx->device));
+    if (ctx->bins_faces == dst) ctx->bins_valid = false;
+    JR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+int jr_memset(jr_ctx* ctx, void* dptr, int value, size_t bytes) {
+    if (!ctx) return fail("NULL context");
+    JR_HIP(hipSetDevice(ctx->device));
+    if (ctx->bins_faces == dptr) ctx->bins_valid = false;
+    JR_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return 0;
+}
+int jr_synchronize(jr_ctx* ctx) {
+    if (!ctx) return fail("NULL context");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_event_create(jr_ctx* ctx, void** event) {
+    if (!ctx || !event) return fail("NULL argument");
+    JR_HIP(hipSetDevice(ctx->device));
+    hipEvent_t e;
+    JR_HIP(hipEventCreate(&e));
+    *event = (void*)e;
+    return 0;
+}
+int jr_event_destroy(jr_ctx* ctx, void* event) {
+    if (!ctx) return fail("NULL context");
+    JR_HIP(hipEventDestroy((hipEvent_t)event));
+    return 0;
+}
+int jr_event_record(jr_ctx* ctx, void* event) {
+    if (!ctx) return fail("NULL context");
+    JR_HIP(hipEventRecord((hipEvent_t)event, ctx->stream));
+    return 0;
+}
+int jr_event_elapsed_ms(jr_ctx* ctx, void* start, void* stop, float* ms) {
+    if (!ctx || !ms) return fail("NULL argument");
+    JR_HIP(hipEventSynchronize((hipEvent_t)stop));
+    JR_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+int jr_softras_forward(jr_ctx* ctx, const float* face_vertices, const float* textures,
+                       float* faces_info, float* aggrs_info, float* soft_colors,
+                       int32_t* faces_id_buffer, int B, int NF, int T, int IS, int K,
+                       float near_, float far_, float eps, float sigma_val, int func_id_dist,
+                       float dist_eps, float gamma_val, int func_id_rgb, int func_id_alpha,
+                       int texture_sample_type, int double_side, const float* background_rgb) {
+    if (!ctx) return fail("jr_softras_forward: NULL context");
+    if (!face_vertices || !textures || !faces_info || !aggrs_info || !soft_colors || !faces_id_buffer)
+        return fail("jr_softras_forward: NULL tensor pointer");
+    if (validate(B, NF, T, IS, K, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type)) return 1;
+    JR_HIP(hipSetDevice(ctx->device));
+    const jr::RasterParams p = make_params(B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
+                                           dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                                           texture_sample_type, double_side, background_rgb);
+    if (build_bins(ctx, p, face_vertices, faces_info)) return 1;
+    jr::launch_softras_forward(ctx->stream, p, face_vertices, textures, faces_info, ctx->ws, aggrs_info,
+                               soft_colors, faces_id_buffer);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_softras_backward(jr_ctx* ctx, const float* face_vertices, const float* textures,
+                        const float* soft_colors, const float* faces_info,
+                        const float* aggrs_info, const int32_t* faces_id_buffer,
+                        const float* grad_soft_colors, float* grad_faces, float* grad_textures,
+                        int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
+                        float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                        int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                        int double_side) {
+    if (!ctx) return fail("jr_softras_backward: NULL context");
+    if (!face_vertices || !textures || !soft_colors || !faces_info || !aggrs_info || !faces_id_buffer ||
+        !grad_soft_colors || !grad_faces || !grad_textures)
+        return fail("jr_softras_backward: NULL tensor pointer");
+    if (validate(B, NF, T, IS, K, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type)) return 1;
+    JR_HIP(hipSetDevice(ctx->device));
+    const jr::RasterParams p = make_params(B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
+                                           dist_eps, gamma_val, func_id_rgb, func_id_alpha,
+                                           texture_sample_type, double_side, nullptr);
+    // Tile lists of the matching forward are reused; anything else rebuilds them (no faces_info write).
+    const bool reuse = ctx->bins_valid && ctx->bins_faces == face_vertices && ctx->bins_B == B &&
+                       ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad;
+    if (!reuse && build_bins(ctx, p, face_vertices, nullptr)) return 1;
+    jr::launch_softras_backward(ctx->stream, p, face_vertices, textures, soft_colors, faces_info,
+                                aggrs_info, faces_id_buffer, grad_soft_colors, ctx->ws, grad_faces,
+                                grad_textures);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_face_vertices_forward(jr_ctx* ctx, const float* vertices, const int32_t* faces,
+                             float* face_vertices, int B, int NV, int NF) {
+    if (!ctx || !vertices || !faces || !face_vertices) return fail("jr_face_vertices_forward: NULL argument");
+    if (B < 1 || NV < 1 || NF < 1) return fail("jr_face_vertices_forward: bad sizes");
+    JR_HIP(hipSetDevice(ctx->device));
+    if (ctx->bins_faces == face_vertices) ctx->bins_valid = false;
+    jr::launch_face_vertices_forward(ctx->stream, vertices, faces, face_vertices, B, NV, NF);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_face_vertices_backward(jr_ctx* ctx, const float* grad_face_vertices, const int32_t* faces,
+                              float* grad_vertices, int B, int NV, int NF) {
+    if (!ctx || !grad_face_vertices || !faces || !grad_vertices) return fail("jr_face_vertices_backward: NULL argument");
+    if (B < 1 || NV < 1 || NF < 1) return fail("jr_face_vertices_backward: bad sizes");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_face_vertices_backward(ctx->stream, grad_face_vertices, faces, grad_vertices, B, NV, NF);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_avgpool2x2_forward(jr_ctx* ctx, const float* in, float* out, int planes, int H, int W) {
+    if (!ctx || !in || !out) return fail("jr_avgpool2x2_forward: NULL argument");
+    if (planes < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail("jr_avgpool2x2: H and W must be even");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_avgpool2x2_forward(ctx->stream, in, out, planes, H, W);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, int planes, int H, int W) {
+    if (!ctx || !grad_out || !grad_in) return fail("jr_avgpool2x2_backward: NULL argument");
+    if (planes < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail("jr_avgpool2x2: H and W must be even");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_avgpool2x2_backward(ctx->stream, grad_out, grad_in, planes, H, W);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]) {
+    if (!ctx || !stats) return fail("NULL argument");
+    memcpy(stats, ctx->stats, sizeof(ctx->stats));
+    return 0;
+}
+
+}  // extern "C"

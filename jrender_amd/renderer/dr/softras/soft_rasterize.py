@@ -1,0 +1,136 @@
+"""SoftRas operator — host-side mirror of jrender/renderer/dr/softras/soft_rasterize.py.
+
+``SoftRasterizeFunction`` keeps the reference's constructor arguments, defaults and
+the ``execute`` / ``grad`` protocol of ``jittor.Function`` (SRW:9-133); the two
+``jt.code`` JIT ops it called (SRK:3, SRK:966) are replaced by
+``jr_softras_forward`` / ``jr_softras_backward`` of libjrender_hip.so.  Inputs may be
+NumPy arrays (copied to the GPU) or ``DeviceArray``s; outputs are ``DeviceArray``s
+(``.numpy()`` like a ``jt.Var``).
+
+Differences that are deliberate and documented:
+  * ``bin_size`` / ``max_elems_per_bin`` are accepted and ignored: the reference's
+    coarse-to-fine path (C2F) is an optimisation with nondeterministic face order;
+    here screen tiling is always on and deterministic, results equal ``bin_size=0``.
+  * ``background_color`` is ignored exactly like the reference (SRW:68-74 builds a
+    pre-filled tensor but never passes it to the kernel; the kernel's memset makes
+    the background 0, SRK:469).  ``honor_background=True`` opts into the evident intent.
+  * the transposition of ``faces_id_buffer`` before the backward (SRW:108) is skipped
+    (pure re-indexing; the kernels read the [B,K,IS,IS] layout directly).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .... import _ffi
+
+__all__ = ["SoftRasterizeFunction", "soft_rasterize"]
+
+FUNC_DIST = {'hard': 0, 'barycentric': 1, 'euclidean': 2}       # SRW:39
+FUNC_RGB = {'hard': 0, 'softmax': 1, 'none': 2}                 # SRW:40
+FUNC_ALPHA = {'hard': 0, 'sum': 1, 'prod': 2}                   # SRW:41
+FUNC_SAMPLE = {'surface': 0, 'vertex': 1}                       # SRW:42
+
+
+def _f32(v):
+    return C.c_float(float(np.float32(v)))
+
+
+class SoftRasterizeFunction:
+    def __init__(self, image_size=256, background_color=[0, 0, 0], near=1, far=100,
+                 fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
+                 gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod',
+                 texture_type='surface', bin_size=0, max_elems_per_bin=0,
+                 max_faces_per_pixel_for_grad=16, honor_background=False, ctx=None):
+        self.image_size = image_size
+        self.background_color = background_color
+        self.near = near
+        self.far = far
+        self.eps = eps
+        self.sigma_val = sigma_val
+        self.gamma_val = gamma_val
+        self.dist_func = dist_func
+        self.dist_eps = np.log(1. / dist_eps - 1.)                  # SRW:25
+        self.aggr_func_rgb = aggr_func_rgb
+        self.aggr_func_alpha = aggr_func_alpha
+        self.fill_back = fill_back
+        self.aggr_texture_type = texture_type
+        self.bin_size = bin_size
+        self.max_elems_per_bin = max_elems_per_bin
+        self.max_faces_id = max_faces_per_pixel_for_grad
+        self.honor_background = honor_background
+        self.ctx = ctx
+        self.save_vars = None
+
+    def _scalars(self):
+        return (int(self.batch_size), int(self.num_faces), int(self.texture_size), int(self.image_size),
+                int(self.max_faces_id), _f32(self.near), _f32(self.far), _f32(self.eps),
+                _f32(self.sigma_val), self.func_dist_type, _f32(self.dist_eps), _f32(self.gamma_val),
+                self.func_rgb_type, self.func_alpha_type, self.texture_type, int(bool(self.fill_back)))
+
+    def execute(self, face_vertices, textures):
+        # face_vertices: [nb, nf, 3, 3] (or [nb, nf, 9]);  textures: [nb, nf, T, 3]
+        try:
+            self.func_dist_type = FUNC_DIST[self.dist_func]
+            self.func_rgb_type = FUNC_RGB[self.aggr_func_rgb]
+            self.func_alpha_type = FUNC_ALPHA[self.aggr_func_alpha]
+            self.texture_type = FUNC_SAMPLE[self.aggr_texture_type]
+        except KeyError as e:                                       # the reference raises KeyError here too
+            raise KeyError(e.args[0])
+        ctx = self.ctx or _ffi.Context.default()
+        lib = _ffi.load()
+        # the reference clones its inputs so that the saved tensors cannot change before grad() (SRW:59-60)
+        fv_in = face_vertices if isinstance(face_vertices, _ffi.DeviceArray) else None
+        tex_in = textures if isinstance(textures, _ffi.DeviceArray) else None
+        fv = fv_in.clone() if fv_in is not None else ctx.array(np.asarray(face_vertices, np.float32))
+        tex = tex_in.clone() if tex_in is not None else ctx.array(np.asarray(textures, np.float32))
+        if fv.dtype != np.float32 or tex.dtype != np.float32:
+            raise TypeError("face_vertices and textures must be float32")
+        self.batch_size, self.num_faces = fv.shape[:2]
+        if fv.size != self.batch_size * self.num_faces * 9:
+            raise ValueError("face_vertices must be [B, NF, 3, 3], got %s" % (fv.shape,))
+        self.texture_size = tex.size // (self.batch_size * self.num_faces * 3)
+        if tex.size != self.batch_size * self.num_faces * self.texture_size * 3 or self.texture_size < 1:
+            raise ValueError("textures must be [B, NF, T, 3], got %s" % (tex.shape,))
+        B, NF, IS, K = self.batch_size, self.num_faces, int(self.image_size), int(self.max_faces_id)
+        faces_info = ctx.empty((B, NF, 27), np.float32)             # [inv*9, sym*9, obt*3, 0*6]  SRW:64
+        aggrs_info = ctx.empty((B, 2, IS, IS), np.float32)
+        soft_colors = ctx.empty((B, 4, IS, IS), np.float32)
+        faces_id_buffer = ctx.empty((B, K, IS, IS), np.int32)
+        bg = None
+        if self.honor_background:
+            bg = (C.c_float * 3)(*[float(np.float32(c)) for c in self.background_color])
+        _ffi._check(lib.jr_softras_forward(ctx.handle, fv.ptr, tex.ptr, faces_info.ptr, aggrs_info.ptr,
+                                           soft_colors.ptr, faces_id_buffer.ptr, *self._scalars(), bg))
+        self._ctx = ctx
+        self.save_vars = fv, tex, soft_colors, faces_info, aggrs_info, faces_id_buffer   # SRW:101
+        return soft_colors
+
+    __call__ = execute
+
+    def grad(self, grad_soft_colors):
+        if self.save_vars is None:
+            raise RuntimeError("grad() called before execute()")
+        fv, tex, soft_colors, faces_info, aggrs_info, faces_id_buffer = self.save_vars
+        ctx = self._ctx
+        g = grad_soft_colors if isinstance(grad_soft_colors, _ffi.DeviceArray) else \
+            ctx.array(np.asarray(grad_soft_colors, np.float32))
+        if g.size != soft_colors.size:
+            raise ValueError("grad_soft_colors must be %s, got %s" % (soft_colors.shape, g.shape))
+        grad_faces = ctx.empty(fv.shape, np.float32)
+        grad_textures = ctx.empty(tex.shape, np.float32)
+        _ffi._check(_ffi.load().jr_softras_backward(
+            ctx.handle, fv.ptr, tex.ptr, soft_colors.ptr, faces_info.ptr, aggrs_info.ptr,
+            faces_id_buffer.ptr, g.ptr, grad_faces.ptr, grad_textures.ptr, *self._scalars()))
+        return grad_faces, grad_textures
+
+
+def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1,
+                   far=100, fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean',
+                   dist_eps=1e-4, gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod',
+                   texture_type='surface', bin_size=0, max_elems_per_bin=0,
+                   max_faces_per_pixel_for_grad=16):
+    """SRW:136-148."""
+    return SoftRasterizeFunction(image_size, background_color, near, far, fill_back, eps, sigma_val,
+                                 dist_func, dist_eps, gamma_val, aggr_func_rgb, aggr_func_alpha,
+                                 texture_type, bin_size, max_elems_per_bin,
+                                 max_faces_per_pixel_for_grad)(face_vertices, textures)
