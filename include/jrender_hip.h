@@ -59,7 +59,8 @@ int jr_ctx_destroy(jr_ctx* ctx);
 int jr_ctx_device(const jr_ctx* ctx);
 void* jr_ctx_stream(const jr_ctx* ctx); /* hipStream_t */
 int jr_malloc(jr_ctx* ctx, size_t bytes, void** dptr);
-int jr_free(jr_ctx* ctx, void* dptr);
+int jr_free(jr_ctx* ctx, void* dptr);   /* returns the block to the context's cache (stream-ordered reuse) */
+int jr_ctx_trim(jr_ctx* ctx);           /* hipFree everything cached by jr_free */
 int jr_memcpy_h2d(jr_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* blocking */
 int jr_memcpy_d2h(jr_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* blocking */
 int jr_memcpy_d2d(jr_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);  /* async   */
@@ -113,6 +114,15 @@ int jr_face_vertices_backward(jr_ctx* ctx, const float* grad_face_vertices, cons
 int jr_avgpool2x2_forward(jr_ctx* ctx, const float* in, float* out, int planes, int H, int W);
 int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, int planes, int H,
                            int W);
+
+/* ---- per-phase GPU timing with HIP events on the context stream (benchmarks) ---------
+ * After jr_profile_enable(ctx, 1) every forward/backward brackets its phases with event pairs;
+ * jr_profile_collect synchronises, returns the summed milliseconds and the number of brackets
+ * per phase since the previous collect, and resets. */
+enum { JR_PHASE_BIN_COUNT = 0, JR_PHASE_BIN_FILL_SORT = 1, JR_PHASE_FWD_RASTER = 2,
+       JR_PHASE_BWD_RASTER = 3, JR_NUM_PHASES = 4 };
+int jr_profile_enable(jr_ctx* ctx, int on);
+int jr_profile_collect(jr_ctx* ctx, double ms[JR_NUM_PHASES], int64_t launches[JR_NUM_PHASES]);
 
 /* ---- introspection for tests / benchmarks ---------------------------------------- */
 /* statistics of the last forward on this context: [0]=tile-face pairs, [1]=non-empty tiles,

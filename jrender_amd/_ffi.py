@@ -33,6 +33,7 @@ SIGNATURES = {
     "jr_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "jr_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "jr_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "jr_ctx_trim": (C.c_int, [C.c_void_p]),
     "jr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jr_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jr_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -48,6 +49,8 @@ SIGNATURES = {
     "jr_face_vertices_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3),
     "jr_avgpool2x2_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_avgpool2x2_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
+    "jr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "jr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "jr_softras_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
@@ -205,6 +208,10 @@ class Context:
         arr = np.ascontiguousarray(arr, dtype)
         return self.empty(arr.shape, arr.dtype).copy_from_host(arr)
 
+    def trim(self):
+        """Return the allocator cache to the driver."""
+        _check(load().jr_ctx_trim(self.handle))
+
     def synchronize(self):
         _check(load().jr_synchronize(self.handle))
 
@@ -221,6 +228,18 @@ class Context:
         ms = C.c_float(0)
         _check(load().jr_event_elapsed_ms(self.handle, start, stop, C.byref(ms)))
         return ms.value
+
+    PHASES = ("bin_count", "bin_fill_sort", "fwd_raster", "bwd_raster")
+
+    def profile_enable(self, on=True):
+        _check(load().jr_profile_enable(self.handle, int(bool(on))))
+
+    def profile_collect(self):
+        """-> {phase: (total_ms, brackets)} since the previous collect (synchronises)."""
+        ms = (C.c_double * 4)()
+        n = (C.c_int64 * 4)()
+        _check(load().jr_profile_collect(self.handle, ms, n))
+        return {name: (ms[i], n[i]) for i, name in enumerate(self.PHASES)}
 
     def last_stats(self):
         s = (C.c_int64 * 4)()

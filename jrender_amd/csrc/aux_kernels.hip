@@ -70,7 +70,7 @@ void launch_face_vertices_forward(hipStream_t st, const float* v, const int32_t*
 }
 void launch_face_vertices_backward(hipStream_t st, const float* gfv, const int32_t* faces, float* gv, int B,
                                    int NV, int NF) {
-    hipMemsetAsync(gv, 0, sizeof(float) * (size_t)B * NV * 3, st);
+    (void)hipMemsetAsync(gv, 0, sizeof(float) * (size_t)B * NV * 3, st);
     const long total = (long)B * NF * 3;
     k_face_vertices_bwd<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(gfv, faces, gv, B, NV, NF);
 }

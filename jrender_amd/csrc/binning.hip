@@ -162,8 +162,8 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, f
                     BinWorkspace& ws) {
     const int nfaces = p.B * p.NF;
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
-    hipMemsetAsync(ws.tile_count, 0, sizeof(int) * (size_t)ntiles, st);
-    hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * 4, st);
+    (void)hipMemsetAsync(ws.tile_count, 0, sizeof(int) * (size_t)ntiles, st);
+    (void)hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * 4, st);
     k_face_setup<<<(nfaces + 255) / 256, 256, 0, st>>>(p, faces, faces_info, ws.face_rect, ws.tile_count);
     k_tile_alloc<<<(ntiles + 255) / 256, 256, 0, st>>>(ntiles, ws.tile_count, ws.tile_base, ws.tile_cursor,
                                                        ws.counters);

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <unordered_map>
+#include <vector>
 
 #include "../../include/jrender_hip.h"
 #include "jr_kernels.h"
@@ -44,7 +46,43 @@ struct jr_ctx {
     float bins_rad = 0.f;
     bool bins_valid = false;
     int64_t stats[4] = {0, 0, 0, 0};
+    // optional per-phase HIP-event timing (jr_profile_*): pairs of events bracketing each phase
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_events;     // pool, reused after every collect
+    std::vector<int> prof_phase;             // phase id of pair i (events 2i, 2i+1)
+    size_t prof_used = 0;                    // events handed out since the last collect
+    // Stream-ordered caching allocator behind jr_malloc/jr_free: hipMalloc/hipFree of the
+    // 100+ MB image tensors cost milliseconds and synchronise the device, so freed blocks are
+    // kept per size class and handed out again.  Safe because every consumer of this context
+    // runs on ctx->stream: a block reused by a later call is only touched after all earlier
+    // work that used it.  jr_ctx_trim() returns the cache to the driver.
+    std::unordered_map<size_t, std::vector<void*>> cache;   // rounded size -> free blocks
+    std::unordered_map<void*, size_t> live;                 // block -> rounded size
+    size_t cached_bytes = 0;
 };
+
+namespace {
+struct ProfScope {
+    jr_ctx* c;
+    hipEvent_t stop = nullptr;
+    ProfScope(jr_ctx* ctx, int phase) : c(ctx) {
+        if (!c->prof_on) return;
+        while (c->prof_events.size() < c->prof_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            c->prof_events.push_back(e);
+        }
+        hipEvent_t start = c->prof_events[c->prof_used];
+        stop = c->prof_events[c->prof_used + 1];
+        c->prof_used += 2;
+        c->prof_phase.push_back(phase);
+        (void)hipEventRecord(start, c->stream);
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, c->stream);
+    }
+};
+}  // namespace
 
 namespace {
 
@@ -101,7 +139,10 @@ int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, float
         if (grow(ws.tile_cursor, c2, ntiles, 1.0)) return 1;
         ws.tiles_cap = c0;
     }
-    jr::launch_binning(ctx->stream, p, faces, faces_info, ws);
+    {
+        ProfScope ps(ctx, JR_PHASE_BIN_COUNT);
+        jr::launch_binning(ctx->stream, p, faces, faces_info, ws);
+    }
     JR_HIP(hipMemcpyAsync(ctx->h_counters, ws.counters, sizeof(unsigned long long) * 4,
                           hipMemcpyDeviceToHost, ctx->stream));
     JR_HIP(hipStreamSynchronize(ctx->stream));
@@ -116,7 +157,10 @@ int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, float
         if (grow(ws.pool_scratch, c1, pairs, 1.25)) return 1;
         ws.pool_cap = c0;
     }
-    jr::launch_bin_fill_sort(ctx->stream, p, ws);
+    {
+        ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
+        jr::launch_bin_fill_sort(ctx->stream, p, ws);
+    }
     JR_HIP(hipGetLastError());
     ctx->bins_faces = faces; ctx->bins_B = p.B; ctx->bins_NF = p.NF; ctx->bins_IS = p.IS;
     ctx->bins_rad = p.rad; ctx->bins_valid = true;
@@ -153,13 +197,17 @@ int jr_ctx_create(int device, jr_ctx** out) {
 
 int jr_ctx_destroy(jr_ctx* ctx) {
     if (!ctx) return 0;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->cache)
+        for (void* p : kv.second) (void)hipFree(p);
+    for (auto& kv : ctx->live) (void)hipFree(kv.first);
     jr::BinWorkspace& ws = ctx->ws;
-    hipFree(ws.face_rect); hipFree(ws.tile_count); hipFree(ws.tile_base); hipFree(ws.tile_cursor);
-    hipFree(ws.counters); hipFree(ws.pool); hipFree(ws.pool_scratch);
-    hipHostFree(ctx->h_counters);
-    hipStreamDestroy(ctx->stream);
+    (void)hipFree(ws.face_rect); (void)hipFree(ws.tile_count); (void)hipFree(ws.tile_base); (void)hipFree(ws.tile_cursor);
+    (void)hipFree(ws.counters); (void)hipFree(ws.pool); (void)hipFree(ws.pool_scratch);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    (void)hipHostFree(ctx->h_counters);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
 }
@@ -170,14 +218,43 @@ void* jr_ctx_stream(const jr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullp
 int jr_malloc(jr_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return fail("jr_malloc: NULL argument");
     JR_HIP(hipSetDevice(ctx->device));
-    JR_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    const size_t sz = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+    auto it = ctx->cache.find(sz);
+    if (it != ctx->cache.end() && !it->second.empty()) {
+        *dptr = it->second.back();
+        it->second.pop_back();
+        ctx->cached_bytes -= sz;
+    } else {
+        hipError_t e = hipMalloc(dptr, sz);
+        if (e != hipSuccess && ctx->cached_bytes) {      // out of memory: drop the cache and retry
+            (void)hipGetLastError();
+            if (jr_ctx_trim(ctx)) return 1;
+            e = hipMalloc(dptr, sz);
+        }
+        if (e != hipSuccess) return fail("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
+    }
+    ctx->live[*dptr] = sz;
     return 0;
 }
 int jr_free(jr_ctx* ctx, void* dptr) {
     if (!ctx) return fail("jr_free: NULL context");
-    JR_HIP(hipSetDevice(ctx->device));
+    if (!dptr) return 0;
     if (ctx->bins_faces == dptr) ctx->bins_valid = false;
-    JR_HIP(hipFree(dptr));
+    auto it = ctx->live.find(dptr);
+    if (it == ctx->live.end()) return fail("jr_free: pointer %p was not allocated by this context", dptr);
+    ctx->cache[it->second].push_back(dptr);
+    ctx->cached_bytes += it->second;
+    ctx->live.erase(it);
+    return 0;
+}
+int jr_ctx_trim(jr_ctx* ctx) {
+    if (!ctx) return fail("NULL context");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->cache)
+        for (void* p : kv.second) JR_HIP(hipFree(p));
+    ctx->cache.clear();
+    ctx->cached_bytes = 0;
     return 0;
 }
 int jr_memcpy_h2d(jr_ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -257,8 +334,11 @@ int jr_softras_forward(jr_ctx* ctx, const float* face_vertices, const float* tex
                                            dist_eps, gamma_val, func_id_rgb, func_id_alpha,
                                            texture_sample_type, double_side, background_rgb);
     if (build_bins(ctx, p, face_vertices, faces_info)) return 1;
-    jr::launch_softras_forward(ctx->stream, p, face_vertices, textures, faces_info, ctx->ws, aggrs_info,
-                               soft_colors, faces_id_buffer);
+    {
+        ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
+        jr::launch_softras_forward(ctx->stream, p, face_vertices, textures, faces_info, ctx->ws, aggrs_info,
+                                   soft_colors, faces_id_buffer);
+    }
     JR_HIP(hipGetLastError());
     return 0;
 }
@@ -284,9 +364,12 @@ int jr_softras_backward(jr_ctx* ctx, const float* face_vertices, const float* te
     const bool reuse = ctx->bins_valid && ctx->bins_faces == face_vertices && ctx->bins_B == B &&
                        ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad;
     if (!reuse && build_bins(ctx, p, face_vertices, nullptr)) return 1;
-    jr::launch_softras_backward(ctx->stream, p, face_vertices, textures, soft_colors, faces_info,
-                                aggrs_info, faces_id_buffer, grad_soft_colors, ctx->ws, grad_faces,
-                                grad_textures);
+    {
+        ProfScope ps(ctx, JR_PHASE_BWD_RASTER);
+        jr::launch_softras_backward(ctx->stream, p, face_vertices, textures, soft_colors, faces_info,
+                                    aggrs_info, faces_id_buffer, grad_soft_colors, ctx->ws, grad_faces,
+                                    grad_textures);
+    }
     JR_HIP(hipGetLastError());
     return 0;
 }
@@ -324,6 +407,28 @@ int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, i
     JR_HIP(hipSetDevice(ctx->device));
     jr::launch_avgpool2x2_backward(ctx->stream, grad_out, grad_in, planes, H, W);
     JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_profile_enable(jr_ctx* ctx, int on) {
+    if (!ctx) return fail("NULL context");
+    ctx->prof_on = on != 0;
+    return 0;
+}
+
+int jr_profile_collect(jr_ctx* ctx, double ms[JR_NUM_PHASES], int64_t launches[JR_NUM_PHASES]) {
+    if (!ctx || !ms || !launches) return fail("NULL argument");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < JR_NUM_PHASES; i++) { ms[i] = 0.0; launches[i] = 0; }
+    for (size_t i = 0; i < ctx->prof_phase.size(); i++) {
+        float t = 0.f;
+        JR_HIP(hipEventElapsedTime(&t, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+        ms[ctx->prof_phase[i]] += t;
+        launches[ctx->prof_phase[i]] += 1;
+    }
+    ctx->prof_phase.clear();
+    ctx->prof_used = 0;
     return 0;
 }
 

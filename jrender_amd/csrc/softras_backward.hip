@@ -290,8 +290,8 @@ void launch_softras_backward(hipStream_t st, const RasterParams& p, const float*
                              const float* aggrs, const int32_t* ids, const float* grad_rgba,
                              const BinWorkspace& ws, float* grad_faces, float* grad_textures) {
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
-    hipMemsetAsync(grad_faces, 0, sizeof(float) * (size_t)p.B * p.NF * 9, st);          // SRK:1374
-    hipMemsetAsync(grad_textures, 0, sizeof(float) * (size_t)p.B * p.NF * p.T * 3, st); // SRK:1375
+    (void)hipMemsetAsync(grad_faces, 0, sizeof(float) * (size_t)p.B * p.NF * 9, st);          // SRK:1374
+    (void)hipMemsetAsync(grad_textures, 0, sizeof(float) * (size_t)p.B * p.NF * p.T * 3, st); // SRK:1375
 #define JR_BWD(D, R) \
     launch_k<D, R>(st, p, ntiles, faces, textures, infos, ws, rgba, aggrs, ids, grad_rgba, grad_faces, grad_textures)
     const int rgb = p.rgb == 0 ? 0 : (p.rgb == 1 ? 1 : 2);

@@ -150,3 +150,57 @@ class Oracle:
         if rc:
             raise RuntimeError("oracle backward failed rc=%d" % rc)
         return gf.reshape(B, NF, 3, 3), gt
+
+    # ---- pixel-subset variants (port only): full-size parity checks in seconds ----
+    def forward_subset(self, face_vertices, textures, pixels, **kw):
+        """Oracle outputs for the listed global pixel indices (b*IS*IS + row*IS + col) only.
+        -> dict(rgba [n,4], aggr [n,2], ids [n,K], faces_info [B,NF,27])."""
+        if self.kind != "port":
+            raise ValueError("subset evaluation exists for kind='port' only")
+        p, s = _scalars(kw)
+        fv = np.ascontiguousarray(face_vertices, np.float32)
+        B, NF = fv.shape[:2]
+        fv = fv.reshape(B, NF, 9)
+        tex = np.ascontiguousarray(textures, np.float32).reshape(B, NF, -1, 3)
+        T, IS, K = tex.shape[2], int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+        pix = np.ascontiguousarray(pixels, np.int64)
+        n = pix.size
+        info = np.empty((B, NF, 27), np.float32)
+        self.lib.orc_faces_info(_fp(fv), _fp(info), C.c_long(B * NF))
+        rgba = np.empty((n, 4), np.float32)
+        aggr = np.empty((n, 2), np.float32)
+        ids = np.empty((n, K), np.int32)
+        bg = kw.get("background_color")
+        bgp = None if bg is None else _fp(np.ascontiguousarray(bg, np.float32))
+        self.lib.orc_ub_reset()
+        rc = self.lib.orc_softras_forward_subset(
+            _fp(fv), _fp(tex), _fp(info), pix.ctypes.data_as(C.POINTER(C.c_int64)), C.c_long(n),
+            _fp(rgba), _fp(aggr), _ip(ids), B, NF, T, IS, K, s["near"], s["far"], s["eps"], s["sigma"],
+            s["dist"], s["dist_eps"], s["gamma"], s["rgb"], s["alpha"], s["tex"], s["ds"], bgp,
+            self.nthreads)
+        if rc:
+            raise RuntimeError("oracle forward_subset failed rc=%d" % rc)
+        return dict(rgba=rgba, aggr=aggr, ids=ids, faces_info=info, params=p)
+
+    def backward_subset(self, saved, grad_soft_colors, pixels):
+        """Backward over the listed pixels only (== full backward when the gradient is zero elsewhere).
+        ``saved`` holds full-layout arrays (e.g. downloaded from the GPU forward)."""
+        if self.kind != "port":
+            raise ValueError("subset evaluation exists for kind='port' only")
+        p, s = _scalars({k: v for k, v in saved["params"].items()})
+        fv, tex = saved["face_vertices"], saved["textures"]
+        B, NF, T = fv.shape[0], fv.shape[1], tex.shape[2]
+        IS, K = int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+        g = np.ascontiguousarray(grad_soft_colors, np.float32).reshape(B, 4, IS, IS)
+        pix = np.ascontiguousarray(pixels, np.int64)
+        gf = np.empty((B, NF, 9), np.float32)
+        gt = np.empty((B, NF, T, 3), np.float32)
+        rc = self.lib.orc_softras_backward_subset(
+            _fp(np.ascontiguousarray(fv, np.float32)), _fp(np.ascontiguousarray(tex, np.float32)),
+            _fp(saved["soft_colors"]), _fp(saved["faces_info"]), _fp(saved["aggrs_info"]),
+            _ip(saved["faces_id_buffer"]), _fp(g), pix.ctypes.data_as(C.POINTER(C.c_int64)),
+            C.c_long(pix.size), _fp(gf), _fp(gt), B, NF, T, IS, K, s["near"], s["far"], s["eps"],
+            s["sigma"], s["dist"], s["dist_eps"], s["gamma"], s["rgb"], s["alpha"], s["tex"], s["ds"])
+        if rc:
+            raise RuntimeError("oracle backward_subset failed rc=%d" % rc)
+        return gf.reshape(B, NF, 3, 3), gt

@@ -474,6 +474,65 @@ int orc_softras_backward(const float* faces, const float* textures, const float*
     return 0;
 }
 
+/*
+ * Pixel-subset variants (test infrastructure for full-size parity checks where the whole
+ * O(pixels x faces) image would take minutes on a CPU): the SAME per-pixel functions, run only
+ * for the listed pixels.  pix[i] = global pixel index b*IS*IS + row*IS + col.  faces_info must be
+ * precomputed (orc_faces_info).  Outputs are packed per listed pixel: rgba[n][4], aggr[n][2],
+ * ids[n][K].
+ */
+int orc_faces_info(const float* faces, float* faces_info, long nfaces) {
+    memset(faces_info, 0, sizeof(float) * (size_t)nfaces * 27);
+    for (long i = 0; i < nfaces; i++) orc_face_setup(faces + i * 9, faces_info + i * 27);
+    return 0;
+}
+
+int orc_softras_forward_subset(const float* faces, const float* textures, const float* faces_info,
+                               const int64_t* pix, long npix, float* rgba, float* aggr, int32_t* ids,
+                               int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
+                               float sigma, int dist, float dist_eps, float gamma, int rgb, int alpha,
+                               int tex_type, int double_side, const float* bg, int nthreads) {
+    if (K < 1 || K > 64) return 1;
+    orc_params p;
+    fill_params(&p, B, NF, T, IS, K, near_, far_, eps, sigma, dist, dist_eps, gamma, rgb, alpha,
+                tex_type, double_side, bg);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    const long pp = (long)IS * IS;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < npix; i++) {
+        int32_t tmp[64];
+        forward_pixel(&p, faces, textures, faces_info, (int)(pix[i] / pp), (int)(pix[i] % pp),
+                      rgba + i * 4, aggr + i * 2, tmp);
+        for (int k = 0; k < K; k++) ids[i * K + k] = tmp[k];
+    }
+    return 0;
+}
+
+/* Backward restricted to the listed pixels: equals the full backward when grad_soft_colors is
+ * zero everywhere else.  Full-layout inputs, as orc_softras_backward. */
+int orc_softras_backward_subset(const float* faces, const float* textures, const float* soft_colors,
+                                const float* faces_info, const float* aggrs_info,
+                                const int32_t* faces_id_buffer, const float* grad_soft_colors,
+                                const int64_t* pix, long npix, float* grad_faces, float* grad_textures,
+                                int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
+                                float sigma, int dist, float dist_eps, float gamma, int rgb, int alpha,
+                                int tex_type, int double_side) {
+    if (K < 1 || K > 64) return 1;
+    orc_params p;
+    fill_params(&p, B, NF, T, IS, K, near_, far_, eps, sigma, dist, dist_eps, gamma, rgb, alpha,
+                tex_type, double_side, NULL);
+    memset(grad_faces, 0, sizeof(float) * (size_t)B * NF * 9);
+    memset(grad_textures, 0, sizeof(float) * (size_t)B * NF * T * 3);
+    const long pp = (long)IS * IS;
+    for (long i = 0; i < npix; i++)
+        backward_pixel(&p, faces, textures, soft_colors, faces_info, aggrs_info, faces_id_buffer,
+                       grad_soft_colors, grad_faces, grad_textures, (int)(pix[i] / pp),
+                       (int)(pix[i] % pp), 0);
+    return 0;
+}
+
 int orc_num_procs(void) {
 #ifdef _OPENMP
     return omp_get_num_procs();
