@@ -1,0 +1,248 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical
+seeded inputs, and against the golden vectors generated from the reference's own kernels.
+
+Bars (north_star): per-pixel face-index buffer and faces_info BIT-EXACT; RGBA / aggregates
+within 1e-4 relative fp32 (absolute floor 1e-6 for alpha's 1 - prod(1-D) cancellation);
+gradients within 1e-4 of the largest gradient magnitude (float atomics reorder the sums, so a
+pure element-wise relative bound is ill-defined where contributions cancel) and, element-wise,
+within 1e-4 relative with a 1e-3*max floor.
+"""
+import glob
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import Oracle
+from jrender_amd import _ffi, synthetic as syn
+from jrender_amd.renderer.dr.softras import SoftRasterizeFunction, SoftRasterizer
+from tests.util import RGBA_ATOL, bits_equal, grad_err, grad_err_elementwise, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GRAD_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return _ffi.Context.default()
+
+
+@pytest.fixture(scope="module")
+def port():
+    return Oracle("port", nthreads=0)
+
+
+def check_against(ref, fn, g, ref_grads):
+    fv, tex, rgba, info, aggr, ids = [x.numpy() for x in fn.save_vars]
+    assert bits_equal(info, ref["faces_info"]), "faces_info not bit-exact"
+    assert bits_equal(ids, ref["faces_id_buffer"]), \
+        "face-index buffer differs in %d pixels" % int((ids != ref["faces_id_buffer"]).any(1).sum())
+    assert rel_err(rgba, ref["soft_colors"], RGBA_ATOL) <= 1.0
+    assert rel_err(aggr, ref["aggrs_info"], RGBA_ATOL) <= 1.0
+    gf, gt = fn.grad(g)
+    gf, gt = gf.numpy().reshape(ref_grads[0].shape), gt.numpy()
+    for a, b, name in ((gf, ref_grads[0], "grad_faces"), (gt, ref_grads[1], "grad_textures")):
+        if np.nanmax(np.abs(b)) == 0:
+            assert np.nanmax(np.abs(a)) == 0, name
+            continue
+        assert grad_err(a, b) <= GRAD_TOL, (name, grad_err(a, b))
+        assert grad_err_elementwise(a, b) <= GRAD_TOL * 10, (name, grad_err_elementwise(a, b))
+
+
+def run_case(ctx, port, fv, tex, seed=0, **kw):
+    ref = port.forward(fv, tex, **kw)
+    if port.ub_events():
+        pytest.skip("input hits the reference's undefined-behaviour corner (SRK:107-121)")
+    fn = SoftRasterizeFunction(ctx=ctx, **kw)
+    fn(fv, tex)
+    g = np.random.default_rng(seed).uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
+    check_against(ref, fn, g, port.backward(ref, g))
+    return ref, fn
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_vectors(ctx, path):
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    fn = SoftRasterizeFunction(ctx=ctx, **kw)
+    fn(z["face_vertices"], z["textures"])
+    ref = {k: z[k] for k in ("faces_info", "aggrs_info", "soft_colors", "faces_id_buffer")}
+    check_against(ref, fn, z["grad_soft_colors"], (z["grad_faces"].reshape(z["face_vertices"].shape[0], -1, 3, 3),
+                                                   z["grad_textures"]))
+
+
+def test_default_sphere(ctx, port):
+    run_case(ctx, port, *syn.sphere_views(280, 2), image_size=64)
+
+
+def test_default_sphere_3300_256(ctx, port):
+    run_case(ctx, port, *syn.sphere_views(3300, 2), image_size=256)
+
+
+def test_soup_ragged_image_size(ctx, port):
+    # image side not a multiple of the 16-pixel tile; faces partly outside the screen
+    fv, tex = syn.triangle_soup(800, 2, seed=4, scale=2.5)
+    fv[..., :2] *= 1.3
+    run_case(ctx, port, fv, tex, image_size=75)
+
+
+@pytest.mark.parametrize("dist,rgb,alpha", list(itertools.product(
+    ["hard", "barycentric", "euclidean"], ["hard", "softmax"], ["hard", "sum", "prod"])))
+def test_all_modes_surface(ctx, port, dist, rgb, alpha):
+    fv, tex = syn.triangle_soup(400, 1, seed=6, texels=4, scale=2.0)
+    run_case(ctx, port, fv, tex, image_size=48, dist_func=dist, aggr_func_rgb=rgb, aggr_func_alpha=alpha,
+             sigma_val=1e-4)
+
+
+@pytest.mark.parametrize("rgb,fill_back", [("hard", True), ("softmax", True), ("softmax", False), ("hard", False)])
+def test_vertex_textures(ctx, port, rgb, fill_back):
+    fv, tex = syn.sphere_views(280, 1, texels=3)
+    run_case(ctx, port, fv, tex, image_size=56, texture_type="vertex", aggr_func_rgb=rgb, fill_back=fill_back)
+
+
+@pytest.mark.parametrize("K", [1, 2, 7, 16, 17, 40, 64])
+def test_k_values(ctx, port, K):
+    fv, tex = syn.triangle_soup(600, 1, seed=8, scale=4.0)
+    run_case(ctx, port, fv, tex, image_size=40, max_faces_per_pixel_for_grad=K, sigma_val=1e-4)
+
+
+def test_near_far_cull(ctx, port):
+    run_case(ctx, port, *syn.sphere_views(280, 1), image_size=48, near=2.2, far=3.0, gamma_val=1e-2)
+
+
+def test_texture_resolution_25(ctx, port):
+    fv, tex = syn.sphere_views(280, 1, texels=25)
+    run_case(ctx, port, fv, tex, image_size=64)
+
+
+def test_empty_scene(ctx, port):
+    fv, tex = syn.triangle_soup(64, 2, seed=1)
+    fv = fv + np.array([5.0, 5.0, 0.0], np.float32)
+    ref, fn = run_case(ctx, port, fv, tex, image_size=33)
+    assert (fn.save_vars[5].numpy() == -1).all()
+
+
+def test_huge_tile_segment_uses_rank_sort(ctx, port):
+    # > 4096 faces inside ONE 16x16 tile: exercises the out-of-LDS sort path of the binning
+    rng = np.random.default_rng(3)
+    n = 4500
+    c = rng.uniform(-0.05, 0.05, (n, 1, 2))
+    xy = c + rng.uniform(-0.02, 0.02, (n, 3, 2))
+    z = rng.uniform(2, 4, (n, 3, 1))
+    fv = np.concatenate([xy, z], -1).astype(np.float32)[None] * np.array([0.2, 0.2, 1], np.float32) \
+        + np.array([0.1, 0.1, 0], np.float32)
+    tex = rng.uniform(0, 1, (1, n, 1, 3)).astype(np.float32)
+    ref, fn = run_case(ctx, port, fv, tex, image_size=32, sigma_val=1e-6)
+    assert ctx.last_stats()["max_faces_in_tile"] > 4096
+
+
+def test_degenerate_faces_do_not_break_parity(ctx, port):
+    # zero-area and sliver triangles: the det clamp path (SRK:213) must match bit for bit
+    fv, tex = syn.triangle_soup(200, 1, seed=9, scale=2.0)
+    fv[0, 0, 1] = fv[0, 0, 0]                      # two identical vertices
+    fv[0, 1, 2] = (fv[0, 1, 0] + fv[0, 1, 1]) / 2  # collinear
+    fv[0, 2] = fv[0, 2, 0:1]                       # a point
+    ref = port.forward(fv, tex, image_size=40)
+    fn = SoftRasterizeFunction(ctx=ctx, image_size=40)
+    fn(fv, tex)
+    assert bits_equal(fn.save_vars[3].numpy(), ref["faces_info"])
+    if port.ub_events() == 0:
+        assert bits_equal(fn.save_vars[5].numpy(), ref["faces_id_buffer"])
+
+
+def test_background_honoured_when_asked(ctx, port):
+    fv, tex = syn.sphere_views(280, 1)
+    bg = [0.2, 0.5, 0.9]
+    ref = port.forward(fv, tex, image_size=40, background_color=bg)
+    fn = SoftRasterizeFunction(image_size=40, background_color=bg, honor_background=True, ctx=ctx)
+    rgba = fn(fv, tex).numpy()
+    assert rel_err(rgba, ref["soft_colors"], RGBA_ATOL) <= 1.0
+    assert abs(rgba[0, 2, 0, 0] - 0.9) < 1e-6
+    # default: the reference ignores background_color (SRW:68-74 / SRK:469)
+    fn0 = SoftRasterizeFunction(image_size=40, background_color=bg, ctx=ctx)
+    assert fn0(fv, tex).numpy()[0, :3, 0, 0].tolist() == [0.0, 0.0, 0.0]
+
+
+def test_determinism_and_batch_independence(ctx):
+    fv, tex = syn.sphere_views(3300, 4)
+    fn = SoftRasterizeFunction(image_size=128, ctx=ctx)
+    a = fn(fv, tex).numpy()
+    ids_a = fn.save_vars[5].numpy()
+    b = fn(fv, tex).numpy()
+    assert bits_equal(a, b) and bits_equal(ids_a, fn.save_vars[5].numpy())
+    one = SoftRasterizeFunction(image_size=128, ctx=ctx)
+    c = one(fv[2:3], tex[2:3]).numpy()
+    assert bits_equal(c[0], a[2]) and bits_equal(one.save_vars[5].numpy()[0], ids_a[2])
+
+
+def test_device_array_inputs_and_clone_semantics(ctx):
+    fv, tex = syn.sphere_views(280, 1)
+    dfv, dtex = ctx.array(fv), ctx.array(tex)
+    fn = SoftRasterizeFunction(image_size=32, ctx=ctx)
+    a = fn(dfv, dtex).numpy()
+    dfv.copy_from_host(np.zeros_like(fv))          # caller mutates its buffer after the forward ...
+    g = np.ones_like(a)
+    gf1 = fn.grad(g)[0].numpy()                    # ... the saved clone (SRW:59-60) is unaffected
+    fn2 = SoftRasterizeFunction(image_size=32, ctx=ctx)
+    fn2(fv, tex)
+    gf2 = fn2.grad(g)[0].numpy()
+    assert grad_err(gf1, gf2) <= 1e-5
+
+
+def test_validation_errors(ctx):
+    fv, tex = syn.sphere_views(280, 1)
+    with pytest.raises(RuntimeError, match="max_faces_per_pixel"):
+        SoftRasterizeFunction(image_size=32, max_faces_per_pixel_for_grad=65, ctx=ctx)(fv, tex)
+    with pytest.raises(RuntimeError, match="image_size"):
+        SoftRasterizeFunction(image_size=5000, ctx=ctx)(fv, tex)
+    with pytest.raises(ValueError):
+        SoftRasterizer(dist_func="manhattan")
+    with pytest.raises(ValueError):
+        SoftRasterizer(aggr_func_rgb="none")
+
+
+def test_anti_aliasing_pool_and_modes(ctx, port):
+    class M:
+        pass
+    fv, tex = syn.sphere_views(280, 2)
+    m = M()
+    m.face_vertices, m.face_textures = fv, tex
+    r = SoftRasterizer(image_size=32, anti_aliasing=True, fill_back=True)
+    sil, rgb = r(m)
+    ref = port.forward(fv, tex, image_size=64)["soft_colors"]
+    pooled = ref.reshape(2, 4, 32, 2, 32, 2).mean((3, 5))
+    assert np.allclose(sil.numpy(), pooled[:, 3], rtol=1e-4, atol=1e-6)
+    assert np.allclose(rgb.numpy(), pooled[:, :3], rtol=1e-4, atol=1e-6)
+    assert r(m, 'silhouettes').shape == (2, 32, 32) and r(m, 'rgb').shape == (2, 3, 32, 32)
+    # backward through select + pool == oracle backward with the up-sampled gradient
+    gs = np.random.default_rng(2).uniform(-1, 1, (2, 32, 32)).astype(np.float32)
+    r(m, 'silhouettes')
+    gf, gt = r.backward(grad_silhouettes=gs)
+    full = np.zeros((2, 4, 64, 64), np.float32)
+    full[:, 3] = np.repeat(np.repeat(gs, 2, 1), 2, 2) / 4
+    o = port.forward(fv, tex, image_size=64)
+    gfo, gto = port.backward(o, full)
+    assert grad_err(gf.numpy().reshape(gfo.shape), gfo) <= GRAD_TOL
+
+
+def test_face_vertices_gather_scatter(ctx):
+    rng = np.random.default_rng(0)
+    B, NV, NF = 3, 50, 120
+    v = rng.normal(size=(B, NV, 3)).astype(np.float32)
+    f = rng.integers(0, NV, (NF, 3)).astype(np.int32)
+    dv, df = ctx.array(v), ctx.array(f)
+    out = ctx.empty((B, NF, 3, 3))
+    lib = _ffi.load()
+    _ffi._check(lib.jr_face_vertices_forward(ctx.handle, dv.ptr, df.ptr, out.ptr, B, NV, NF))
+    assert bits_equal(out.numpy(), v[:, f])
+    g = rng.normal(size=(B, NF, 3, 3)).astype(np.float32)
+    dg, gv = ctx.array(g), ctx.empty((B, NV, 3))
+    _ffi._check(lib.jr_face_vertices_backward(ctx.handle, dg.ptr, df.ptr, gv.ptr, B, NV, NF))
+    ref = np.zeros((B, NV, 3), np.float64)
+    for b in range(B):
+        np.add.at(ref[b], f.reshape(-1), g[b].reshape(-1, 3))
+    assert np.allclose(gv.numpy(), ref, rtol=1e-5, atol=1e-5)
