@@ -125,8 +125,8 @@ int jr_profile_enable(jr_ctx* ctx, int on);
 int jr_profile_collect(jr_ctx* ctx, double ms[JR_NUM_PHASES], int64_t launches[JR_NUM_PHASES]);
 
 /* ---- introspection for tests / benchmarks ---------------------------------------- */
-/* statistics of the last forward on this context: [0]=tile-face pairs, [1]=non-empty tiles,
- * [2]=max faces in a tile, [3]=tiles per image */
+/* statistics of the last forward on this context: [0]=bin-face pairs, [1]=non-empty 32x32 bins,
+ * [2]=max faces in a bin, [3]=bins per image */
 int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]);
 
 #ifdef __cplusplus

@@ -244,7 +244,7 @@ class Context:
     def last_stats(self):
         s = (C.c_int64 * 4)()
         _check(load().jr_softras_last_stats(self.handle, s))
-        return dict(tile_face_pairs=s[0], nonempty_tiles=s[1], max_faces_in_tile=s[2], tiles_per_image=s[3])
+        return dict(bin_face_pairs=s[0], nonempty_bins=s[1], max_faces_in_bin=s[2], bins_per_image=s[3])
 
     def close(self):
         if self.handle:

@@ -1,18 +1,21 @@
-// Screen-tile binning for the SoftRas kernels (gfx950).
+// Screen binning for the SoftRas kernels (gfx950).
 //
-// The reference visits ALL faces for every pixel (SRK:311) — O(pixels x faces).  Here every
-// 16x16-pixel tile gets the list of faces whose border box (triangle bbox grown by the cull
-// radius, SRK:28-34, :316) can touch it, in ASCENDING face order, because the per-pixel
-// aggregation (alpha product, online softmax, K-nearest buffer: SRK:350-419) is order dependent
-// and the face-index buffer must match the reference bit for bit.
+// The reference visits ALL faces for every pixel (SRK:311) — O(pixels x faces).  Here the screen
+// is cut into 32x32-pixel bins of 4x4 wavefront tiles (8x8 pixels each).  Every bin gets the list
+// of faces whose border box (triangle bbox grown by the cull radius, SRK:28-34, :316) can touch
+// it, in ASCENDING face order — the per-pixel aggregation (alpha product, online softmax,
+// K-nearest buffer: SRK:350-419) is order dependent and the face-index buffer must match the
+// reference bit for bit.  Each list entry carries a 16-bit mask of the bin's tiles the face can
+// touch, so a wavefront discards most of its bin's list with one bit test per face.
 //
-// Pipeline (all on the context stream, no host round trip except one 16-byte read of the totals):
-//   k_face_setup  : per face -> faces_info (SRK:176-236) + conservative tile rectangle + per-tile counts
-//   k_tile_alloc  : per tile -> segment base in the pair pool (atomic bump; placement is irrelevant)
-//   k_tile_fill   : per face -> append its id to each touched tile's segment (unordered)
-//   k_tile_sort   : per tile -> sort the segment ascending (LDS bitonic; rank sort for huge segments)
+// Pipeline (all on the context stream; one 32-byte read-back of the totals sizes the pool):
+//   k_face_setup : per face -> faces_info (SRK:176-236), packed FaceGeo record, conservative pixel
+//                  rectangle, per-bin counts
+//   k_bin_alloc  : per bin  -> segment base in the pool (atomic bump; placement is irrelevant)
+//   k_bin_fill   : per face -> append (id, tile mask) to each touched bin's segment (unordered)
+//   k_bin_sort   : per bin  -> sort the segment ascending by id (LDS bitonic; rank sort if huge)
 // The rectangle is only a conservative superset: the exact per-pixel border test of the
-// reference is re-applied in the raster kernels, so results do not depend on the binning.
+// reference is re-applied in the raster kernels, so results never depend on the binning.
 #include "jr_kernels.h"
 
 namespace jr {
@@ -36,98 +39,105 @@ __device__ inline void pixel_range(float vlo, float vhi, int is, int& lo, int& h
 
 __global__ __launch_bounds__(256) void k_face_setup(RasterParams p, const float* __restrict__ faces,
                                                     float* __restrict__ faces_info,
-                                                    uint32_t* __restrict__ face_rect,
-                                                    int* __restrict__ tile_count) {
+                                                    FaceGeo* __restrict__ geo,
+                                                    ushort4* __restrict__ face_rect,
+                                                    int* __restrict__ bin_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.B * p.NF) return;
     const float* f = faces + (size_t)i * 9;
     float info[27];
     face_setup(f, info);
-    if (faces_info) {   // nullptr when the backward only rebuilds the tile lists
+    if (faces_info) {   // nullptr when the backward only rebuilds the lists
         float* out = faces_info + (size_t)i * 27;
 #pragma unroll
         for (int k = 0; k < 27; k++) out[k] = info[k];
     }
+    FaceGeo g;
+    build_face_geo(g, f, info, p.rad);
+    geo[i] = g;
 
-    const float xhi = fmaxf(fmaxf(f[0], f[3]), f[6]) + p.rad;
-    const float xlo = fminf(fminf(f[0], f[3]), f[6]) - p.rad;
-    const float yhi = fmaxf(fmaxf(f[1], f[4]), f[7]) + p.rad;
-    const float ylo = fminf(fminf(f[1], f[4]), f[7]) - p.rad;
     int px0, px1, py0, py1;
-    pixel_range(xlo, xhi, p.IS, px0, px1);
-    pixel_range(ylo, yhi, p.IS, py0, py1);   // in "yi" space (yi = IS-1-row)
-    uint32_t rect = 0xffffffffu;             // empty
+    pixel_range(g.xlo, g.xhi, p.IS, px0, px1);
+    pixel_range(g.ylo, g.yhi, p.IS, py0, py1);   // in "yi" space (yi = IS-1-row)
+    ushort4 rect = make_ushort4(1, 0, 1, 0);     // empty: x0 > x1
     if (px0 <= px1 && py0 <= py1) {
         const int row0 = p.IS - 1 - py1, row1 = p.IS - 1 - py0;
-        const int tx0 = px0 / TILE, tx1 = px1 / TILE, ty0 = row0 / TILE, ty1 = row1 / TILE;
-        rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+        rect = make_ushort4((unsigned short)px0, (unsigned short)px1, (unsigned short)row0,
+                            (unsigned short)row1);
         const int b = i / p.NF;
-        int* tc = tile_count + (size_t)b * p.tiles_x * p.tiles_y;
-        for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&tc[ty * p.tiles_x + tx], 1);
+        int* bc = bin_count + (size_t)b * p.bins_x * p.bins_y;
+        for (int by = row0 / BIN; by <= row1 / BIN; by++)
+            for (int bx = px0 / BIN; bx <= px1 / BIN; bx++) atomicAdd(&bc[by * p.bins_x + bx], 1);
     }
     face_rect[i] = rect;
 }
 
-// counters: [0] = total pairs (bump pointer), [1] = non-empty tiles, [2] = max tile count
-__global__ __launch_bounds__(256) void k_tile_alloc(int ntiles_total, const int* __restrict__ tile_count,
-                                                    int* __restrict__ tile_base,
-                                                    int* __restrict__ tile_cursor,
-                                                    unsigned long long* __restrict__ counters) {
+// counters: [0] = total pairs (bump pointer), [1] = non-empty bins, [2] = max bin count
+__global__ __launch_bounds__(256) void k_bin_alloc(int nbins_total, const int* __restrict__ bin_count,
+                                                   int* __restrict__ bin_base,
+                                                   int* __restrict__ bin_cursor,
+                                                   unsigned long long* __restrict__ counters) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles_total) return;
-    const int n = tile_count[t];
+    if (t >= nbins_total) return;
+    const int n = bin_count[t];
     int base = 0;
     if (n > 0) {
         base = (int)atomicAdd(&counters[0], (unsigned long long)n);
         atomicAdd(&counters[1], 1ull);
         atomicMax(&counters[2], (unsigned long long)n);
     }
-    tile_base[t] = base;
-    tile_cursor[t] = 0;
+    bin_base[t] = base;
+    bin_cursor[t] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_tile_fill(RasterParams p, const uint32_t* __restrict__ face_rect,
-                                                   const int* __restrict__ tile_base,
-                                                   int* __restrict__ tile_cursor,
-                                                   int* __restrict__ pool) {
+__global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4* __restrict__ face_rect,
+                                                  const int* __restrict__ bin_base,
+                                                  int* __restrict__ bin_cursor,
+                                                  unsigned long long* __restrict__ pool) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.B * p.NF) return;
-    const uint32_t rect = face_rect[i];
-    if (rect == 0xffffffffu) return;
-    const int tx0 = rect & 255, ty0 = (rect >> 8) & 255, tx1 = (rect >> 16) & 255, ty1 = rect >> 24;
+    const ushort4 r = face_rect[i];
+    if (r.x > r.y) return;
     const int b = i / p.NF, fn = i - b * p.NF;
-    const size_t tb = (size_t)b * p.tiles_x * p.tiles_y;
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) {
-            const size_t t = tb + ty * p.tiles_x + tx;
-            const int pos = atomicAdd(&tile_cursor[t], 1);
-            pool[tile_base[t] + pos] = fn;
+    const size_t bb = (size_t)b * p.bins_x * p.bins_y;
+    const int tx0 = r.x / TILE, tx1 = r.y / TILE, ty0 = r.z / TILE, ty1 = r.w / TILE;
+    for (int by = r.z / BIN; by <= r.w / BIN; by++)
+        for (int bx = r.x / BIN; bx <= r.y / BIN; bx++) {
+            // mask of the bin's 4x4 tiles overlapped by the face rectangle (bit = ty*4 + tx)
+            const int sx0 = max(tx0 - bx * SUBS, 0), sx1 = min(tx1 - bx * SUBS, SUBS - 1);
+            const int sy0 = max(ty0 - by * SUBS, 0), sy1 = min(ty1 - by * SUBS, SUBS - 1);
+            const unsigned rowbits = ((1u << (sx1 + 1)) - 1u) & ~((1u << sx0) - 1u);
+            unsigned mask = 0;
+            for (int sy = sy0; sy <= sy1; sy++) mask |= rowbits << (sy * SUBS);
+            const size_t t = bb + by * p.bins_x + bx;
+            const int pos = atomicAdd(&bin_cursor[t], 1);
+            pool[bin_base[t] + pos] = ((unsigned long long)(unsigned)fn << 32) | mask;
         }
 }
 
-constexpr int SORT_LDS = 4096;   // ints sortable in LDS by one workgroup
+constexpr int SORT_LDS = 4096;   // 64-bit entries sortable in LDS by one workgroup (32 KB)
 
-// One workgroup per tile.  Ascending sort of the tile's face ids (unique keys).
-__global__ __launch_bounds__(256) void k_tile_sort(const int* __restrict__ tile_count,
-                                                   const int* __restrict__ tile_base,
-                                                   int* __restrict__ pool, int* __restrict__ scratch) {
-    __shared__ int s[SORT_LDS];
+// One workgroup per bin.  Ascending sort of the bin's entries by face id (unique keys).
+__global__ __launch_bounds__(256) void k_bin_sort(const int* __restrict__ bin_count,
+                                                  const int* __restrict__ bin_base,
+                                                  unsigned long long* __restrict__ pool,
+                                                  unsigned long long* __restrict__ scratch) {
+    __shared__ unsigned long long s[SORT_LDS];
     const int t = blockIdx.x;
-    const int n = tile_count[t];
+    const int n = bin_count[t];
     if (n <= 1) return;
-    int* seg = pool + tile_base[t];
+    unsigned long long* seg = pool + bin_base[t];
     if (n <= SORT_LDS) {
         int m = 2;
         while (m < n) m <<= 1;
-        for (int i = threadIdx.x; i < m; i += blockDim.x) s[i] = i < n ? seg[i] : 0x7fffffff;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) s[i] = i < n ? seg[i] : ~0ull;
         __syncthreads();
         for (int k = 2; k <= m; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int i = threadIdx.x; i < m; i += blockDim.x) {
                     const int l = i ^ j;
                     if (l > i) {
-                        const int a = s[i], b = s[l];
+                        const unsigned long long a = s[i], b = s[l];
                         const bool up = (i & k) == 0;
                         if ((a > b) == up) { s[i] = b; s[l] = a; }
                     }
@@ -136,14 +146,14 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int* __restrict__ tile_
             }
         for (int i = threadIdx.x; i < n; i += blockDim.x) seg[i] = s[i];
     } else {
-        // Huge segment (many faces inside one tile): rank sort through the scratch copy, staged
-        // through LDS in blocks.  O(n^2/256) per tile — correctness path for degenerate inputs.
-        int* src = scratch + tile_base[t];
+        // Huge segment (a whole mesh inside one bin): rank sort through the scratch copy, staged
+        // through LDS in blocks.  O(n^2/256) per bin — correctness path for degenerate inputs.
+        unsigned long long* src = scratch + bin_base[t];
         for (int i = threadIdx.x; i < n; i += blockDim.x) src[i] = seg[i];
         __syncthreads();
         for (int i0 = 0; i0 < n; i0 += blockDim.x) {
             const int i = i0 + threadIdx.x;
-            const int key = i < n ? src[i] : 0;
+            const unsigned long long key = i < n ? src[i] : 0;
             int rank = 0;
             for (int c0 = 0; c0 < n; c0 += SORT_LDS) {
                 const int cn = min(SORT_LDS, n - c0);
@@ -161,19 +171,18 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int* __restrict__ tile_
 void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, float* faces_info,
                     BinWorkspace& ws) {
     const int nfaces = p.B * p.NF;
-    const int ntiles = p.B * p.tiles_x * p.tiles_y;
-    (void)hipMemsetAsync(ws.tile_count, 0, sizeof(int) * (size_t)ntiles, st);
+    const int nbins = p.B * p.bins_x * p.bins_y;
+    (void)hipMemsetAsync(ws.bin_count, 0, sizeof(int) * (size_t)nbins, st);
     (void)hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * 4, st);
-    k_face_setup<<<(nfaces + 255) / 256, 256, 0, st>>>(p, faces, faces_info, ws.face_rect, ws.tile_count);
-    k_tile_alloc<<<(ntiles + 255) / 256, 256, 0, st>>>(ntiles, ws.tile_count, ws.tile_base, ws.tile_cursor,
-                                                       ws.counters);
+    k_face_setup<<<(nfaces + 255) / 256, 256, 0, st>>>(p, faces, faces_info, ws.geo, ws.face_rect, ws.bin_count);
+    k_bin_alloc<<<(nbins + 255) / 256, 256, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.counters);
 }
 
 void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws) {
     const int nfaces = p.B * p.NF;
-    const int ntiles = p.B * p.tiles_x * p.tiles_y;
-    k_tile_fill<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.tile_base, ws.tile_cursor, ws.pool);
-    k_tile_sort<<<ntiles, 256, 0, st>>>(ws.tile_count, ws.tile_base, ws.pool, ws.pool_scratch);
+    const int nbins = p.B * p.bins_x * p.bins_y;
+    k_bin_fill<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.bin_base, ws.bin_cursor, ws.pool);
+    k_bin_sort<<<nbins, 256, 0, st>>>(ws.bin_count, ws.bin_base, ws.pool, ws.pool_scratch);
 }
 
 }  // namespace jr

@@ -1,6 +1,6 @@
 // C ABI of libjrender_hip.so — see include/jrender_hip.h for the contract and the reference
 // interfaces (file:line) each entry point replaces.  Host-side only: argument validation, the
-// per-context scratch arena for the tile lists, kernel launches on the context stream.
+// per-context scratch arena for the bin lists, kernel launches on the context stream.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -40,7 +40,7 @@ struct jr_ctx {
     hipStream_t stream = nullptr;
     jr::BinWorkspace ws;
     unsigned long long* h_counters = nullptr;   // pinned, 4 entries
-    // identity of the tile lists currently held in ws (reused by the backward)
+    // identity of the bin lists currently held in ws (reused by the backward)
     const void* bins_faces = nullptr;
     int bins_B = 0, bins_NF = 0, bins_IS = 0;
     float bins_rad = 0.f;
@@ -99,7 +99,7 @@ int grow(T*& ptr, size_t& cap, size_t need, double slack) {
 
 int validate(int B, int NF, int T, int IS, int K, int dist, int rgb, int alpha, int tex) {
     if (B < 1 || NF < 1 || T < 1 || IS < 1) return fail("B, NF, T, image_size must be >= 1 (got %d %d %d %d)", B, NF, T, IS);
-    if (IS > 256 * jr::TILE) return fail("image_size %d exceeds the supported maximum %d", IS, 256 * jr::TILE);
+    if (IS > jr::MAX_IMAGE) return fail("image_size %d exceeds the supported maximum %d", IS, jr::MAX_IMAGE);
     if (K < 1 || K > JR_MAX_FACES_PER_PIXEL)
         return fail("max_faces_per_pixel_for_grad must be in [1,%d] (got %d)", JR_MAX_FACES_PER_PIXEL, K);
     if (dist < 0 || dist > 2) return fail("func_id_dist must be 0 (hard), 1 (barycentric) or 2 (euclidean)");
@@ -122,22 +122,27 @@ jr::RasterParams make_params(int B, int NF, int T, int IS, int K, float near_, f
     p.rad = sqrtf(p.thr);                                                                  // SRK:316
     p.dist = dist; p.rgb = rgb; p.alpha = alpha; p.tex = tex; p.double_side = double_side ? 1 : 0;
     for (int k = 0; k < 3; k++) p.bg[k] = bg ? bg[k] : 0.f;
-    p.tiles_x = (IS + jr::TILE - 1) / jr::TILE;
-    p.tiles_y = p.tiles_x;
+    p.bins_x = (IS + jr::BIN - 1) / jr::BIN;
+    p.bins_y = p.bins_x;
     return p;
 }
 
-// Build (or rebuild) the per-tile ascending face lists for this geometry.
+// Build (or rebuild) the per-bin ascending face lists for this geometry.
 int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, float* faces_info) {
-    const size_t nfaces = (size_t)p.B * p.NF, ntiles = (size_t)p.B * p.tiles_x * p.tiles_y;
+    const size_t nfaces = (size_t)p.B * p.NF, nbins = (size_t)p.B * p.bins_x * p.bins_y;
     jr::BinWorkspace& ws = ctx->ws;
-    if (grow(ws.face_rect, ws.faces_cap, nfaces, 1.0)) return 1;
-    if (ntiles > ws.tiles_cap || !ws.tile_count) {
-        size_t c0 = ws.tiles_cap, c1 = ws.tiles_cap, c2 = ws.tiles_cap;
-        if (grow(ws.tile_count, c0, ntiles, 1.0)) return 1;
-        if (grow(ws.tile_base, c1, ntiles, 1.0)) return 1;
-        if (grow(ws.tile_cursor, c2, ntiles, 1.0)) return 1;
-        ws.tiles_cap = c0;
+    if (nfaces > ws.faces_cap || !ws.geo) {
+        size_t c0 = ws.faces_cap, c1 = ws.faces_cap;
+        if (grow(ws.geo, c0, nfaces, 1.0)) return 1;
+        if (grow(ws.face_rect, c1, nfaces, 1.0)) return 1;
+        ws.faces_cap = c0;
+    }
+    if (nbins > ws.bins_cap || !ws.bin_count) {
+        size_t c0 = ws.bins_cap, c1 = ws.bins_cap, c2 = ws.bins_cap;
+        if (grow(ws.bin_count, c0, nbins, 1.0)) return 1;
+        if (grow(ws.bin_base, c1, nbins, 1.0)) return 1;
+        if (grow(ws.bin_cursor, c2, nbins, 1.0)) return 1;
+        ws.bins_cap = c0;
     }
     {
         ProfScope ps(ctx, JR_PHASE_BIN_COUNT);
@@ -150,7 +155,7 @@ int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, float
     ctx->stats[0] = (int64_t)pairs;
     ctx->stats[1] = (int64_t)ctx->h_counters[1];
     ctx->stats[2] = (int64_t)ctx->h_counters[2];
-    ctx->stats[3] = (int64_t)p.tiles_x * p.tiles_y;
+    ctx->stats[3] = (int64_t)p.bins_x * p.bins_y;
     if (pairs > ws.pool_cap || !ws.pool) {
         size_t c0 = ws.pool_cap, c1 = ws.pool_cap;
         if (grow(ws.pool, c0, pairs, 1.25)) return 1;
@@ -203,7 +208,7 @@ int jr_ctx_destroy(jr_ctx* ctx) {
         for (void* p : kv.second) (void)hipFree(p);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     jr::BinWorkspace& ws = ctx->ws;
-    (void)hipFree(ws.face_rect); (void)hipFree(ws.tile_count); (void)hipFree(ws.tile_base); (void)hipFree(ws.tile_cursor);
+    (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor);
     (void)hipFree(ws.counters); (void)hipFree(ws.pool); (void)hipFree(ws.pool_scratch);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipHostFree(ctx->h_counters);
@@ -336,7 +341,7 @@ int jr_softras_forward(jr_ctx* ctx, const float* face_vertices, const float* tex
     if (build_bins(ctx, p, face_vertices, faces_info)) return 1;
     {
         ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
-        jr::launch_softras_forward(ctx->stream, p, face_vertices, textures, faces_info, ctx->ws, aggrs_info,
+        jr::launch_softras_forward(ctx->stream, p, textures, ctx->ws, aggrs_info,
                                    soft_colors, faces_id_buffer);
     }
     JR_HIP(hipGetLastError());
@@ -366,9 +371,8 @@ int jr_softras_backward(jr_ctx* ctx, const float* face_vertices, const float* te
     if (!reuse && build_bins(ctx, p, face_vertices, nullptr)) return 1;
     {
         ProfScope ps(ctx, JR_PHASE_BWD_RASTER);
-        jr::launch_softras_backward(ctx->stream, p, face_vertices, textures, soft_colors, faces_info,
-                                    aggrs_info, faces_id_buffer, grad_soft_colors, ctx->ws, grad_faces,
-                                    grad_textures);
+        jr::launch_softras_backward(ctx->stream, p, textures, soft_colors, aggrs_info, faces_id_buffer,
+                                    grad_soft_colors, ctx->ws, grad_faces, grad_textures);
     }
     JR_HIP(hipGetLastError());
     return 0;

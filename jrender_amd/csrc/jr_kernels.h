@@ -7,28 +7,28 @@
 
 namespace jr {
 
-// Per-context scratch for the tile lists (owned by jr_ctx, grown lazily, never freed per call).
+// Per-context scratch for the bin lists (owned by jr_ctx, grown lazily, never freed per call).
 struct BinWorkspace {
-    uint32_t* face_rect = nullptr;             // [B*NF] packed tile rectangle per face
-    int* tile_count = nullptr;                 // [B*tiles]
-    int* tile_base = nullptr;                  // [B*tiles] segment start in pool
-    int* tile_cursor = nullptr;                // [B*tiles]
-    unsigned long long* counters = nullptr;    // [4] device: total pairs, non-empty tiles, max count
-    int* pool = nullptr;                       // [pool_cap] face ids, per tile ascending
-    int* pool_scratch = nullptr;               // [pool_cap] only used by the huge-segment sort
-    size_t faces_cap = 0, tiles_cap = 0, pool_cap = 0;
+    FaceGeo* geo = nullptr;                    // [B*NF] packed geometry records
+    ushort4* face_rect = nullptr;              // [B*NF] conservative pixel rectangle (x0,x1,row0,row1)
+    int* bin_count = nullptr;                  // [B*bins]
+    int* bin_base = nullptr;                   // [B*bins] segment start in pool
+    int* bin_cursor = nullptr;                 // [B*bins]
+    unsigned long long* counters = nullptr;    // [4] device: total pairs, non-empty bins, max count
+    unsigned long long* pool = nullptr;        // [pool_cap] (face id << 32 | tile mask), per bin ascending
+    unsigned long long* pool_scratch = nullptr;// [pool_cap] only used by the huge-segment sort
+    size_t faces_cap = 0, bins_cap = 0, pool_cap = 0;
 };
 
 void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, float* faces_info,
                     BinWorkspace& ws);
 void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws);
 
-void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* faces,
-                            const float* textures, const float* faces_info, const BinWorkspace& ws,
-                            float* aggrs_info, float* soft_colors, int32_t* faces_id_buffer);
-void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* faces,
-                             const float* textures, const float* soft_colors,
-                             const float* faces_info, const float* aggrs_info,
+void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
+                            const BinWorkspace& ws, float* aggrs_info, float* soft_colors,
+                            int32_t* faces_id_buffer);
+void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,
+                             const float* soft_colors, const float* aggrs_info,
                              const int32_t* faces_id_buffer, const float* grad_soft_colors,
                              const BinWorkspace& ws, float* grad_faces, float* grad_textures);
 

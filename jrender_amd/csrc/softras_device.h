@@ -7,22 +7,24 @@
 // built with -ffp-contract=off (no FMA contraction) and without fast-math; the
 // `double` islands below are where the reference's bare literals promote.
 //
-// What is NOT the reference's: the data organisation.  A face is staged once per
-// screen tile into an LDS record (FaceRec) holding pre-derived per-face constants
-// (border box incl. cull radius, edge-difference vectors of the Gram matrix, the
-// edge denominators, obtuse vertex, facing) so that the per-pixel code has no
-// dynamic register indexing and reads everything by LDS broadcast.
+// What is NOT the reference's: the data organisation.  Every face gets one packed
+// 144-byte geometry record (FaceGeo) written once per forward by the setup kernel:
+// border box incl. cull radius, face_inv, vertices, edge-difference vectors of the
+// Gram matrix and the edge denominators, obtuse vertex, facing.  The raster kernels
+// copy the records of the faces a wavefront needs into LDS and every lane reads the
+// record of ITS current face — no dynamic register indexing, no scattered global
+// gathers in the inner loop.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace jr {
 
-constexpr int TILE = 16;        // screen tile side in pixels (one 256-thread workgroup)
-constexpr int WG_THREADS = 256;
-constexpr int CHUNK = 128;      // faces staged into LDS per pass
-constexpr int REC_F4 = 12;      // float4's per LDS face record
-constexpr int REC_FLOATS = REC_F4 * 4;
+constexpr int TILE = 8;          // pixels per side of a wavefront's tile (8x8 = 64 lanes)
+constexpr int BIN = 32;          // pixels per side of a binning cell (4x4 tiles)
+constexpr int SUBS = BIN / TILE; // tiles per bin side
+constexpr int CHUNK = 64;        // faces staged per pass = one per lane
+constexpr int MAX_IMAGE = 4096;
 
 struct RasterParams {
     int B, NF, T, R, IS, K;
@@ -31,56 +33,31 @@ struct RasterParams {
     float rad;   // sqrtf(thr)                 (SRK:316)
     int dist, rgb, alpha, tex, double_side;
     float bg[3];
-    int tiles_x, tiles_y;
+    int bins_x, bins_y;   // ceil(IS / BIN)
 };
 
-// LDS face record (48 floats, 16-byte aligned so that it is read with ds_read_b128 broadcasts)
-//  f4[0]      xlo xhi ylo yhi        border box incl. cull radius   (SRK:28-34)
-//  f4[1..2]   inv[0..7]              face_inv                        (SRK:205-217)
-//  f4[3]      inv[8] z0 z1 z2
-//  f4[4]      x0 y0 x1 y1
-//  f4[5]      x2 y2 obt(int) flags(int: bit0 = front side)
-//  f4[6..8]   A[e][c] (9) Dn[0] Dn[1] Dn[2]: A[e] = sym[e] - sym[e+1], Dn[e] = A[e][e]-A[e][e+1]
-//  f4[9..11]  col[0..8] (T==1 surface colour or 3 vertex colours), face id (int), pad
-struct FaceRec {
-    float xlo, xhi, ylo, yhi;
-    float inv[9];
+// Packed per-face geometry, 36 floats = 9 x 16 B (global, one per face per forward).
+struct FaceGeo {
+    float xlo, xhi, ylo, yhi;      // border box incl. cull radius        (SRK:28-34, :316)
+    float inv[9];                  // face_inv                            (SRK:205-217)
     float z[3];
     float x0, y0, x1, y1, x2, y2;
-    int obt;      // index of the (first) obtuse vertex or -1   (SRK:227-235)
-    int front;    // check_face_frontside                      (SRK:37-40)
-    float A[9];
-    float Dn[3];
-    float col[9];
-    int id;
-    int pad[2];
+    int obt;                       // index of the (first) obtuse vertex or -1   (SRK:227-235)
+    int front;                     // check_face_frontside                (SRK:37-40)
+    float A[9];                    // A[e] = sym[e] - sym[e+1]            (SRK:77-79)
+    float Dn[3];                   // A[e][e] - A[e][e+1]                 (SRK:81 denominator)
 };
-static_assert(sizeof(FaceRec) == REC_FLOATS * 4, "FaceRec layout");
+static_assert(sizeof(FaceGeo) == 144, "FaceGeo layout");
 
-// Build a record from the global face / faces_info arrays (one thread per face of the chunk).
-__device__ inline void build_face_rec(FaceRec& r, const float* __restrict__ f,
-                                      const float* __restrict__ fi, float rad, int id) {
-    const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
-    r.xhi = fmaxf(fmaxf(x0, x1), x2) + rad;
-    r.xlo = fminf(fminf(x0, x1), x2) - rad;
-    r.yhi = fmaxf(fmaxf(y0, y1), y2) + rad;
-    r.ylo = fminf(fminf(y0, y1), y2) - rad;
-#pragma unroll
-    for (int k = 0; k < 9; k++) r.inv[k] = fi[k];
-    r.z[0] = f[2]; r.z[1] = f[5]; r.z[2] = f[8];
-    r.x0 = x0; r.y0 = y0; r.x1 = x1; r.y1 = y1; r.x2 = x2; r.y2 = y2;
-    const float* sym = fi + 9;
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-        const int e1 = (e + 1) % 3;
-#pragma unroll
-        for (int c = 0; c < 3; c++) r.A[3 * e + c] = sym[3 * e + c] - sym[3 * e1 + c];   // SRK:77-79
-        r.Dn[e] = r.A[3 * e + e] - r.A[3 * e + e1];                                      // SRK:81 denominator
-    }
-    r.obt = fi[18] == 1.f ? 0 : (fi[19] == 1.f ? 1 : (fi[20] == 1.f ? 2 : -1));
-    r.front = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1 : 0;
-    r.id = id;
-}
+// LDS record = geometry + what the colour path needs.  52 dwords = 13 x 16 B: an ODD number of
+// 16-byte slots, so lanes that read records of different faces spread over all LDS bank groups.
+struct FaceRec {
+    FaceGeo g;
+    int id;
+    float col[9];                  // T==1 surface colour (3) or the three vertex colours (9)
+    int pad[6];
+};
+static_assert(sizeof(FaceRec) == 208, "FaceRec layout");
 
 // Per-face preprocessing = faces_info of the reference (SRK:176-236).
 __device__ inline void face_setup(const float* __restrict__ f, float* __restrict__ info) {
@@ -109,6 +86,30 @@ __device__ inline void face_setup(const float* __restrict__ f, float* __restrict
     for (int k = 21; k < 27; k++) info[k] = 0.f;
 }
 
+// Geometry record from the face and its faces_info.
+__device__ inline void build_face_geo(FaceGeo& r, const float* __restrict__ f,
+                                      const float* __restrict__ fi, float rad) {
+    const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
+    r.xhi = fmaxf(fmaxf(x0, x1), x2) + rad;
+    r.xlo = fminf(fminf(x0, x1), x2) - rad;
+    r.yhi = fmaxf(fmaxf(y0, y1), y2) + rad;
+    r.ylo = fminf(fminf(y0, y1), y2) - rad;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.inv[k] = fi[k];
+    r.z[0] = f[2]; r.z[1] = f[5]; r.z[2] = f[8];
+    r.x0 = x0; r.y0 = y0; r.x1 = x1; r.y1 = y1; r.x2 = x2; r.y2 = y2;
+    const float* sym = fi + 9;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const int e1 = (e + 1) % 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) r.A[3 * e + c] = sym[3 * e + c] - sym[3 * e1 + c];
+        r.Dn[e] = r.A[3 * e + e] - r.A[3 * e + e1];
+    }
+    r.obt = fi[18] == 1.f ? 0 : (fi[19] == 1.f ? 1 : (fi[20] == 1.f ? 2 : -1));
+    r.front = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1 : 0;
+}
+
 // pixel centre in NDC: (2*i + 1 - IS) / IS evaluated in double, rounded once (SRK:280-283)
 __device__ inline float pixel_centre(int i, int is) {
     return (float)((2. * i + 1. - is) / is);
@@ -116,7 +117,7 @@ __device__ inline float pixel_centre(int i, int is) {
 
 struct Bary { float w0, w1, w2; };
 
-__device__ inline Bary barycentric(const FaceRec& r, float x, float y) {             // SRK:20-25
+__device__ inline Bary barycentric(const FaceGeo& r, float x, float y) {             // SRK:20-25
     Bary b;
     b.w0 = (r.inv[0] * x + r.inv[1] * y) + r.inv[2];
     b.w1 = (r.inv[3] * x + r.inv[4] * y) + r.inv[5];
@@ -128,24 +129,27 @@ __device__ inline bool pixel_inside(const Bary& b) {                            
     return b.w0 <= 1 && b.w0 >= 0 && b.w1 <= 1 && b.w1 >= 0 && b.w2 <= 1 && b.w2 >= 0;
 }
 
-__device__ inline float clamp01(float v) {   // max(min(v, 1.), 0.) in double is exact (SRK:51, :138 order differs, value same for non-NaN)
-    return (float)fmax(fmin((double)v, 1.), 0.);
-}
-__device__ inline float clamp01_maxfirst(float v) {                                  // SRK:138 min(max(t,0.),1.)
-    return (float)fmin(fmax((double)v, 0.), 1.);
-}
+// max(min(v, 1.), 0.) / min(max(v, 0.), 1.): the reference evaluates these in double because of
+// the bare literals; both are exact selections, so the float form returns the same value
+// (NaN -> 1 resp. 0 in both, like CUDA's fmin/fmax; only the sign of a zero may differ, which
+// nothing downstream observes).
+__device__ inline float clamp01(float v) { return fmaxf(fminf(v, 1.f), 0.f); }           // SRK:51
+__device__ inline float clamp01_maxfirst(float v) { return fminf(fmaxf(v, 0.f), 1.f); }  // SRK:138
 
 __device__ inline Bary barycentric_clip(Bary b) {                                    // SRK:49-54
     b.w0 = clamp01(b.w0); b.w1 = clamp01(b.w1); b.w2 = clamp01(b.w2);
-    const float s = (float)fmax((double)((b.w0 + b.w1) + b.w2), 1e-5);
+    // max(w_sum, 1e-5) compares in double and stores (float)1e-5 when clamped == fmaxf(s, 1e-5f)
+    const float s = fmaxf((b.w0 + b.w1) + b.w2, 1e-5f);
     b.w0 = b.w0 / s; b.w1 = b.w1 / s; b.w2 = b.w2 / s;
     return b;
 }
 
-// depth of the clipped barycentric point, 1./(sum w/z) with a double reciprocal (SRK:364, :1296)
-__device__ inline float depth_of(const FaceRec& r, const Bary& c) {
+// depth of the clipped barycentric point, 1./(sum w/z) (SRK:364, :1296).  The reference divides in
+// double and rounds to float; for a float divisor that equals the correctly rounded float quotient
+// (53 >= 2*24+2 bits: double rounding is innocuous for division), i.e. IEEE 1.0f/s.
+__device__ inline float depth_of(const FaceGeo& r, const Bary& c) {
     const float s = (c.w0 / r.z[0] + c.w1 / r.z[1]) + c.w2 / r.z[2];
-    return (float)(1. / (double)s);
+    return 1.0f / s;
 }
 
 struct Dist {
@@ -153,14 +157,13 @@ struct Dist {
     float t0, t1, t2;     // nearest-point barycentric minus w   (SRK:98-100, :139)
 };
 
-// one edge's projection: parameter along edge e (SRK:81 / SRK:132)
 __device__ inline float edge_param(const Bary& b, const float* A3, float a_v1, float dn) {
-    return (((b.w0 * A3[0] + b.w1 * A3[1]) + b.w2 * A3[2]) - a_v1) / dn;
+    return (((b.w0 * A3[0] + b.w1 * A3[1]) + b.w2 * A3[2]) - a_v1) / dn;       // SRK:81 / :132
 }
 
 // squared-distance machinery, euclidean mode (SRK:57-147).  No dynamic register indexing:
 // the edge is selected with v_cndmask chains.
-__device__ inline Dist euclidean_p2f(const FaceRec& r, const Bary& b, float xp, float yp) {
+__device__ inline Dist euclidean_p2f(const FaceGeo& r, const Bary& b, float xp, float yp) {
     Dist d;
     if (b.w0 > 0 && b.w1 > 0 && b.w2 > 0 && b.w0 < 1 && b.w1 < 1 && b.w2 < 1) {
         float best = 100000000.f, bx = 0.f, by = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -237,6 +240,18 @@ __device__ inline int surface_texel(const Bary& c, int R) {
     const int wy = (int)fminf(c.w1 * R, (float)(R - 1));
     if (((c.w0 + c.w1) * R - wx) - wy <= 1) return wy * R + wx;
     return (R - 1 - wy) * R + (R - 1 - wx);
+}
+
+// ---- wavefront helpers (64 lanes) ----------------------------------------------------------
+__device__ inline unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// Value of a 64-bit wave-uniform table entry selected by a small per-lane index (0..7): the
+// compiler lowers this to v_cndmask chains on SGPR operands.
+__device__ inline unsigned long long select8(const unsigned long long (&tab)[8], int idx) {
+    unsigned long long m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) m = idx == c ? tab[c] : m;
+    return m;
 }
 
 }  // namespace jr

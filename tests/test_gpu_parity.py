@@ -137,7 +137,7 @@ def test_huge_tile_segment_uses_rank_sort(ctx, port):
         + np.array([0.1, 0.1, 0], np.float32)
     tex = rng.uniform(0, 1, (1, n, 1, 3)).astype(np.float32)
     ref, fn = run_case(ctx, port, fv, tex, image_size=32, sigma_val=1e-6)
-    assert ctx.last_stats()["max_faces_in_tile"] > 4096
+    assert ctx.last_stats()["max_faces_in_bin"] > 4096
 
 
 def test_degenerate_faces_do_not_break_parity(ctx, port):
