@@ -9,14 +9,32 @@
 //     searches ITS ids in the chunk (LDS) and builds a private 64-bit mask of chunk positions;
 //     the OR of the masks tells which faces anyone needs, and only those records are staged
 //     from the packed geometry array into LDS;
-//   * lanes pop their own mask bits in lock step and run the exact per-pair arithmetic on the LDS
-//     record of THEIR face (all lanes busy, as in the reference, but with LDS instead of 63
-//     scattered global loads);
-//   * per-face partial gradients are accumulated with LDS float atomics (ds_add_f32) and flushed
-//     with ONE global atomic per component per (tile, face) instead of one per pixel.
+//   * the needed faces are visited one by one (wave-uniform loop, record read by LDS broadcast):
+//     the lanes that hold the face run the exact per-pair arithmetic, their contributions are
+//     summed across the wavefront with DPP row shifts / broadcasts, and lane 63 issues ONE global
+//     atomic per gradient component per (tile, face) instead of one per pixel.
+//
+// (Measured on MI355X: LDS float atomics — ds_add_f32 — retire about one lane per clock, so a
+// per-lane scatter into LDS accumulators is 2x slower than this DPP reduction; profiles/.)
 #include "jr_kernels.h"
 
 namespace jr {
+
+// Wavefront sum (64 lanes, all active): inclusive DPP scan, total lands in lane 63.
+__device__ inline float wave_sum_to_lane63(float v) {
+    int x;
+#define JR_DPP_ADD(ctrl, rmask)                                                            \
+    x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false); \
+    v += __builtin_bit_cast(float, x);
+    JR_DPP_ADD(0x111, 0xf)  // row_shr:1
+    JR_DPP_ADD(0x112, 0xf)  // row_shr:2
+    JR_DPP_ADD(0x114, 0xf)  // row_shr:4
+    JR_DPP_ADD(0x118, 0xf)  // row_shr:8
+    JR_DPP_ADD(0x142, 0xa)  // row_bcast:15 into rows 1,3
+    JR_DPP_ADD(0x143, 0xc)  // row_bcast:31 into rows 2,3
+#undef JR_DPP_ADD
+    return v;
+}
 
 template <int N>
 __device__ inline void sort_ascending(int (&s)[N]) {
@@ -37,7 +55,113 @@ __device__ inline void sort_ascending(int (&s)[N]) {
             }
 }
 
-constexpr int ACC_W = 19;   // 9 vertex + up to 9 colour gradient components, odd stride for the banks
+struct PixelGrad {           // per-pixel inputs of the backward (SRK:1230-1231, :1281, :1315, :1323)
+    float g0, g1, g2, g3;    // upstream gradient of r g b a
+    float o0, o1, o2, o3;    // forward outputs r g b a
+    float ssum, smax;        // aggrs_info
+};
+
+// Contribution of one (pixel, face) pair: gv = d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2), gt = colour gradient
+// (3 values for a single-texel surface, 9 for vertex colours).  Returns the sampled texel.
+template <int DIST, int RGB>
+__device__ inline int backward_pair(const RasterParams& p, const FaceRec& fr, const PixelGrad& px,
+                                    float xp, float yp, const float* __restrict__ tbase,
+                                    float (&gv)[9], float (&gt)[9], float& tgs, bool& tex_on) {
+    const FaceGeo& r = fr.g;
+    const int fn = fr.id;
+    const Bary w = barycentric(r, xp, yp);
+    float D, dis = 0.f;
+    Dist dd;
+    dd.sign = 0.f; dd.dx = 0.f; dd.dy = 0.f; dd.t0 = 0.f; dd.t1 = 0.f; dd.t2 = 0.f;
+    if (DIST == 0) D = 1.f;                                               // SRK:1258-1270
+    else if (DIST == 1) { dis = barycentric_dist(w); D = coverage(-dis / p.sigma); }
+    else {
+        dd = euclidean_p2f(r, w, xp, yp);
+        dis = dd.dx * dd.dx + dd.dy * dd.dy;
+        D = coverage(-dd.sign * dis / p.sigma);
+    }
+    float ca = px.g3;                                                     // SRK:1281-1291
+    if (p.alpha == 1) ca /= p.NF;
+    else if (p.alpha == 2)
+        ca = (float)((double)ca * ((double)(1 - px.o3) / fmax((double)(1 - D), 1e-6)));
+    float cxy = 0.f;
+    cxy += ca;
+    const Bary wc = barycentric_clip(w);                                  // SRK:1294-1296
+    const float zp = depth_of(r, wc);
+    const int texel = p.tex == 0 ? surface_texel(wc, p.R) : 0;
+    tgs = 0.f;
+    tex_on = false;
+    if (RGB == 0) {                                                       // SRK:1299-1306
+        if ((float)fn == px.smax) { tgs = 1.f; tex_on = true; }
+    } else if (RGB == 1) {                                                // SRK:1308-1332
+        const float zn = (p.far_ - zp) / (p.far_ - p.near_);
+        const float zs = D * expf((zn - px.smax) / p.gamma) / px.ssum;
+        tgs = zs; tex_on = true;
+        float k0, k1, k2;
+        if (p.tex == 0) {
+            if (p.T == 1) { k0 = fr.col[0]; k1 = fr.col[1]; k2 = fr.col[2]; }
+            else {
+                const float* tx_ = tbase + ((size_t)fn * p.T + texel) * 3;
+                k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
+            }
+        } else {                                                           // SRK:1147-1149 (affine)
+            k0 = (wc.w0 * fr.col[0] + wc.w1 * fr.col[3]) + wc.w2 * fr.col[6];
+            k1 = (wc.w0 * fr.col[1] + wc.w1 * fr.col[4]) + wc.w2 * fr.col[7];
+            k2 = (wc.w0 * fr.col[2] + wc.w1 * fr.col[5]) + wc.w2 * fr.col[8];
+        }
+        float crgb = 0.f;
+        crgb += px.g0 * (k0 - px.o0);
+        crgb += px.g1 * (k1 - px.o1);
+        crgb += px.g2 * (k2 - px.o2);
+        crgb *= zs;
+        cxy += crgb / D;
+        const float cz = crgb / p.gamma / (p.near_ - p.far_) * zp * zp;
+        gv[2] = cz * wc.w0 / r.z[0] / r.z[0];
+        gv[5] = cz * wc.w1 / r.z[1] / r.z[1];
+        gv[8] = cz * wc.w2 / r.z[2] / r.z[2];
+    }
+    if (tex_on) {
+        if (p.tex == 1) {                    // backward_sample_texture vertex: w[j]*grad (SRK:1170-1172)
+            const float wj[3] = {wc.w0, wc.w1, wc.w2};
+#pragma unroll
+            for (int jv = 0; jv < 3; jv++) {
+                gt[3 * jv + 0] = tgs * (wj[jv] * px.g0);
+                gt[3 * jv + 1] = tgs * (wj[jv] * px.g1);
+                gt[3 * jv + 2] = tgs * (wj[jv] * px.g2);
+            }
+        } else if (p.T == 1) {
+            gt[0] = tgs * px.g0; gt[1] = tgs * px.g1; gt[2] = tgs * px.g2;
+        }
+    }
+    cxy *= D * (1 - D) / p.sigma;                                         // SRK:1336
+    if (DIST == 1) {                                                      // SRK:1118-1132
+        const int q = w.w0 > w.w1 ? (w.w1 > w.w2 ? 2 : 1) : (w.w0 > w.w2 ? 2 : 0);
+        const double mul = dis > 0 ? (2. * (double)sqrtf(dis)) : (2. * (double)sqrtf(-dis));
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            const float ql = q == 0 ? r.inv[l] : (q == 1 ? r.inv[3 + l] : r.inv[6 + l]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float s = 0.f;
+                s += -ql * r.inv[3 * k + 0] * xp;
+                s += -ql * r.inv[3 * k + 1] * yp;
+                s += -ql * r.inv[3 * k + 2] * 1.f;
+                float v = s * cxy;
+                v = (float)((double)v * mul);
+                gv[3 * k + l] = v;
+            }
+        }
+    } else if (DIST == 2) {                                               // SRK:1341-1347
+        const float w0s[3] = {w.w0, w.w1, w.w2};
+        const float ts[3] = {dd.t0, dd.t1, dd.t2};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            gv[3 * k + 0] = 2 * dd.sign * cxy * (ts[k] + w0s[k]) * dd.dx;
+            gv[3 * k + 1] = 2 * dd.sign * cxy * (ts[k] + w0s[k]) * dd.dy;
+        }
+    }
+    return texel;
+}
 
 template <int DIST, int RGB, int KCAP>
 __global__ __launch_bounds__(64) void k_softras_backward(
@@ -48,7 +172,6 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
     float* __restrict__ grad_faces, float* __restrict__ grad_textures) {
     __shared__ FaceRec s_rec[CHUNK];
-    __shared__ float s_acc[CHUNK * ACC_W];
     __shared__ int s_ids[CHUNK];
     __shared__ unsigned long long s_need;
 
@@ -91,15 +214,17 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     sort_ascending(mine);
     int cur = mine[0];
 
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    float ssum = 1.f, smax = 0.f;
+    PixelGrad px;
+    px.g0 = px.g1 = px.g2 = px.g3 = 0.f;
+    px.o0 = px.o1 = px.o2 = px.o3 = 0.f;
+    px.ssum = 1.f; px.smax = 0.f;
     if (valid) {
         const float* gp = grad_rgba + (size_t)b * 4 * pp + pn;
         const float* op = rgba + (size_t)b * 4 * pp + pn;
-        g0 = gp[0]; g1 = gp[pp]; g2 = gp[2 * pp]; g3 = gp[3 * pp];
-        o0 = op[0]; o1 = op[pp]; o2 = op[2 * pp]; o3 = op[3 * pp];
-        ssum = aggrs[(size_t)b * 2 * pp + pn];                                  // SRK:1230-1231
-        smax = aggrs[(size_t)b * 2 * pp + pp + pn];
+        px.g0 = gp[0]; px.g1 = gp[pp]; px.g2 = gp[2 * pp]; px.g3 = gp[3 * pp];
+        px.o0 = op[0]; px.o1 = op[pp]; px.o2 = op[2 * pp]; px.o3 = op[3 * pp];
+        px.ssum = aggrs[(size_t)b * 2 * pp + pn];
+        px.smax = aggrs[(size_t)b * 2 * pp + pp + pn];
     }
 
     const unsigned long long* seg = pool + bin_base[bin];
@@ -107,8 +232,7 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     const float* tbase = textures + (size_t)b * p.NF * p.T * 3;
     float* gfbase = grad_faces + (size_t)b * p.NF * 9;
     float* gtbase = grad_textures + (size_t)b * p.NF * p.T * 3;
-    const bool tex_shared = p.tex == 1 || p.T == 1;   // texture gradient has the same target for all pixels
-    const int ntex = p.tex == 1 ? 9 : (p.T == 1 ? 3 : 0);
+    const int ntex = p.tex == 1 ? 9 : (p.T == 1 ? 3 : 0);   // colour-gradient components shared by all pixels
 
     for (int s0 = 0; s0 < n; s0 += CHUNK) {
         if (!ballot(cur != BIG)) break;             // every pixel has consumed its buffer
@@ -116,6 +240,7 @@ __global__ __launch_bounds__(64) void k_softras_backward(
         const int idx = s0 + lane;
         const unsigned long long e = idx < n ? seg[idx] : 0ull;
         const int fn_f = idx < n ? (int)(e >> 32) : BIG;
+        if (!ballot((e >> sub) & 1ull)) continue;   // no face of this chunk touches this tile
         __syncthreads();
         s_ids[lane] = fn_f;
         if (lane == 0) s_need = 0ull;
@@ -141,10 +266,10 @@ __global__ __launch_bounds__(64) void k_softras_backward(
         }
         if (M) atomicOr(&s_need, M);
         __syncthreads();
-        const unsigned long long need = s_need;
+        unsigned long long need = s_need;
         if (!need) continue;
 
-        // ---- stage the needed records (lane = face) and clear their accumulators ----
+        // ---- stage the needed records (lane = face) ----
         if ((need >> lane) & 1ull) {
             const FaceGeo* gp = gbase + fn_f;
             const float4* src = reinterpret_cast<const float4*>(gp);
@@ -159,139 +284,43 @@ __global__ __launch_bounds__(64) void k_softras_backward(
             } else if (p.T == 1) {
                 s_rec[lane].col[0] = tx_[0]; s_rec[lane].col[1] = tx_[1]; s_rec[lane].col[2] = tx_[2];
             }
-#pragma unroll
-            for (int k = 0; k < ACC_W; k++) s_acc[lane * ACC_W + k] = 0.f;
         }
         __syncthreads();
 
-        // ---- per-pair arithmetic: lane = pixel, each on the record of ITS face ----
-        while (M) {
-            const int j = __builtin_ctzll(M);
-            M &= M - 1;
-            const FaceRec& fr = s_rec[j];
-            const FaceGeo& r = fr.g;
-            // check_border is repeated by the reference's backward (SRK:1244)
-            if (xp > r.xhi || xp < r.xlo || yp > r.yhi || yp < r.ylo) continue;
-            const int fn = fr.id;
+        // ---- one needed face at a time (wave-uniform): pairs -> wave sum -> one atomic each ----
+        while (need) {
+            const int f = __builtin_ctzll(need);
+            need &= need - 1;
+            const FaceRec& fr = s_rec[f];
+            const bool has = (M >> f) & 1ull;
             float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // x0 y0 z0 x1 y1 z1 x2 y2 z2
-            const Bary w = barycentric(r, xp, yp);
-            float D, dis = 0.f;
-            Dist dd;
-            dd.sign = 0.f; dd.dx = 0.f; dd.dy = 0.f; dd.t0 = 0.f; dd.t1 = 0.f; dd.t2 = 0.f;
-            if (DIST == 0) D = 1.f;                                       // SRK:1258-1270
-            else if (DIST == 1) { dis = barycentric_dist(w); D = coverage(-dis / p.sigma); }
-            else {
-                dd = euclidean_p2f(r, w, xp, yp);
-                dis = dd.dx * dd.dx + dd.dy * dd.dy;
-                D = coverage(-dd.sign * dis / p.sigma);
-            }
-            float ca = g3;                                                // SRK:1281-1291
-            if (p.alpha == 1) ca /= p.NF;
-            else if (p.alpha == 2)
-                ca = (float)((double)ca * ((double)(1 - o3) / fmax((double)(1 - D), 1e-6)));
-            float cxy = 0.f;
-            cxy += ca;
-            const Bary wc = barycentric_clip(w);                          // SRK:1294-1296
-            const float zp = depth_of(r, wc);
-            const int texel = p.tex == 0 ? surface_texel(wc, p.R) : 0;
-            float tgs = 0.f;   // scale of the texture gradient for this pair
-            bool tex_on = false;
-            if (RGB == 0) {                                               // SRK:1299-1306
-                if ((float)fn == smax) { tgs = 1.f; tex_on = true; }
-            } else if (RGB == 1) {                                        // SRK:1308-1332
-                const float zn = (p.far_ - zp) / (p.far_ - p.near_);
-                const float zs = D * expf((zn - smax) / p.gamma) / ssum;
-                tgs = zs; tex_on = true;
-                float k0, k1, k2;
-                if (p.tex == 0) {
-                    if (p.T == 1) { k0 = fr.col[0]; k1 = fr.col[1]; k2 = fr.col[2]; }
-                    else {
-                        const float* tx_ = tbase + ((size_t)fn * p.T + texel) * 3;
-                        k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
-                    }
-                } else {                                                   // SRK:1147-1149 (affine)
-                    k0 = (wc.w0 * fr.col[0] + wc.w1 * fr.col[3]) + wc.w2 * fr.col[6];
-                    k1 = (wc.w0 * fr.col[1] + wc.w1 * fr.col[4]) + wc.w2 * fr.col[7];
-                    k2 = (wc.w0 * fr.col[2] + wc.w1 * fr.col[5]) + wc.w2 * fr.col[8];
-                }
-                float crgb = 0.f;
-                crgb += g0 * (k0 - o0);
-                crgb += g1 * (k1 - o1);
-                crgb += g2 * (k2 - o2);
-                crgb *= zs;
-                cxy += crgb / D;
-                const float cz = crgb / p.gamma / (p.near_ - p.far_) * zp * zp;
-                gv[2] = cz * wc.w0 / r.z[0] / r.z[0];
-                gv[5] = cz * wc.w1 / r.z[1] / r.z[1];
-                gv[8] = cz * wc.w2 / r.z[2] / r.z[2];
-            }
-            float* acc = &s_acc[j * ACC_W];
-            if (tex_on) {
-                if (p.tex == 1) {            // backward_sample_texture vertex: w[j]*grad (SRK:1170-1172)
-                    const float wj[3] = {wc.w0, wc.w1, wc.w2};
-#pragma unroll
-                    for (int jv = 0; jv < 3; jv++) {
-                        atomicAdd(acc + 9 + 3 * jv + 0, tgs * (wj[jv] * g0));
-                        atomicAdd(acc + 9 + 3 * jv + 1, tgs * (wj[jv] * g1));
-                        atomicAdd(acc + 9 + 3 * jv + 2, tgs * (wj[jv] * g2));
-                    }
-                } else if (p.T == 1) {
-                    atomicAdd(acc + 9, tgs * g0); atomicAdd(acc + 10, tgs * g1); atomicAdd(acc + 11, tgs * g2);
-                } else {                     // per-pixel texel: straight to global
-                    float* gtx = gtbase + ((size_t)fn * p.T + texel) * 3;
-                    atomicAdd(gtx + 0, tgs * g0);
-                    atomicAdd(gtx + 1, tgs * g1);
-                    atomicAdd(gtx + 2, tgs * g2);
+            float gt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // check_border is repeated by the reference's backward (SRK:1244)
+            if (has && !(xp > fr.g.xhi || xp < fr.g.xlo || yp > fr.g.yhi || yp < fr.g.ylo)) {
+                float tgs;
+                bool tex_on;
+                const int texel = backward_pair<DIST, RGB>(p, fr, px, xp, yp, tbase, gv, gt, tgs, tex_on);
+                if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: straight to global
+                    float* gtx = gtbase + ((size_t)fr.id * p.T + texel) * 3;
+                    atomicAdd(gtx + 0, tgs * px.g0);
+                    atomicAdd(gtx + 1, tgs * px.g1);
+                    atomicAdd(gtx + 2, tgs * px.g2);
                 }
             }
-            cxy *= D * (1 - D) / p.sigma;                                 // SRK:1336
-            if (DIST == 1) {                                              // SRK:1118-1132
-                const int q = w.w0 > w.w1 ? (w.w1 > w.w2 ? 2 : 1) : (w.w0 > w.w2 ? 2 : 0);
-                const double mul = dis > 0 ? (2. * (double)sqrtf(dis)) : (2. * (double)sqrtf(-dis));
-#pragma unroll
-                for (int l = 0; l < 2; l++) {
-                    const float ql = q == 0 ? r.inv[l] : (q == 1 ? r.inv[3 + l] : r.inv[6 + l]);
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        float s = 0.f;
-                        s += -ql * r.inv[3 * k + 0] * xp;
-                        s += -ql * r.inv[3 * k + 1] * yp;
-                        s += -ql * r.inv[3 * k + 2] * 1.f;
-                        float v = s * cxy;
-                        v = (float)((double)v * mul);
-                        gv[3 * k + l] = v;
-                    }
-                }
-            } else if (DIST == 2) {                                       // SRK:1341-1347
-                const float w0s[3] = {w.w0, w.w1, w.w2};
-                const float ts[3] = {dd.t0, dd.t1, dd.t2};
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    gv[3 * k + 0] = 2 * dd.sign * cxy * (ts[k] + w0s[k]) * dd.dx;
-                    gv[3 * k + 1] = 2 * dd.sign * cxy * (ts[k] + w0s[k]) * dd.dy;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 9; k++) atomicAdd(acc + k, gv[k]);        // LDS ds_add_f32
-        }
-        __syncthreads();
-
-        // ---- flush: one global atomic per component per (tile, face)  (SRK:1349-1358 does one per pixel) ----
-        if ((need >> lane) & 1ull) {
-            const float* acc = &s_acc[lane * ACC_W];
-            float* gf = gfbase + (size_t)fn_f * 9;
+            const int fn = fr.id;
+            float* gf = gfbase + (size_t)fn * 9;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
-                const float v = acc[k];
-                if (v != 0.f) atomicAdd(gf + k, v);
+                const float s = wave_sum_to_lane63(gv[k]);
+                if (lane == 63 && s != 0.f) atomicAdd(gf + k, s);            // SRK:1349-1358 does one per pixel
             }
-            if (tex_shared) {
-                float* gtx = gtbase + (size_t)fn_f * p.T * 3;
+            if (ntex) {
+                float* gtx = gtbase + (size_t)fn * p.T * 3;
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
                     if (k < ntex) {
-                        const float v = acc[9 + k];
-                        if (v != 0.f) atomicAdd(gtx + k, v);
+                        const float s = wave_sum_to_lane63(gt[k]);
+                        if (lane == 63 && s != 0.f) atomicAdd(gtx + k, s);
                     }
                 }
             }

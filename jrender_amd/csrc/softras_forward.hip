@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64) void k_softras_forward(
         const unsigned long long e = idx < n ? seg[idx] : 0ull;
         const int fn_f = (int)(e >> 32);
         const bool need = (e >> sub) & 1ull;
+        if (!ballot(need)) continue;            // no face of this chunk touches this tile
         const FaceGeo* gp = gbase + fn_f;
         float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
         if (need) box = *reinterpret_cast<const float4*>(gp);                 // xlo xhi ylo yhi
