@@ -124,6 +124,11 @@ enum { JR_PHASE_BIN_COUNT = 0, JR_PHASE_BIN_FILL_SORT = 1, JR_PHASE_FWD_RASTER =
 int jr_profile_enable(jr_ctx* ctx, int on);
 int jr_profile_collect(jr_ctx* ctx, double ms[JR_NUM_PHASES], int64_t launches[JR_NUM_PHASES]);
 
+/* ---- self-test of the exact-division identity the kernels rely on (softras_device.h):
+ * evaluates n pseudo-random (a, b) pairs on the GPU and counts results of the reciprocal-refinement
+ * quotient that differ in any bit from the IEEE quotient a / b.  Must return 0 mismatches. */
+int jr_selftest_division(jr_ctx* ctx, uint64_t n, uint32_t seed, uint64_t* mismatches);
+
 /* ---- introspection for tests / benchmarks ---------------------------------------- */
 /* statistics of the last forward on this context: [0]=bin-face pairs, [1]=non-empty 32x32 bins,
  * [2]=max faces in a bin, [3]=bins per image */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "jr_face_vertices_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3),
     "jr_avgpool2x2_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_avgpool2x2_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
+    "jr_selftest_division": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "jr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "jr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "jr_softras_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
@@ -240,6 +241,12 @@ class Context:
         n = (C.c_int64 * 4)()
         _check(load().jr_profile_collect(self.handle, ms, n))
         return {name: (ms[i], n[i]) for i, name in enumerate(self.PHASES)}
+
+    def selftest_division(self, n=1 << 31, seed=1):
+        """Bit mismatches between the kernels' reciprocal-refinement quotient and IEEE a / b."""
+        bad = C.c_uint64(0)
+        _check(load().jr_selftest_division(self.handle, int(n), int(seed), C.byref(bad)))
+        return bad.value
 
     def last_stats(self):
         s = (C.c_int64 * 4)()

@@ -86,3 +86,36 @@ void launch_avgpool2x2_backward(hipStream_t st, const float* gout, float* gin, i
 }
 
 }  // namespace jr
+
+// ---- self-test: div_known<true>(a, b, RN(1/b)) == a / b on its guarantee domain ----------------
+// a == 0 or 2^-80 <= |a| <= 2^60, 2^-40 <= |b| <= 2^40 (softras_device.h).  Counts mismatching bits.
+namespace jr {
+__device__ inline uint32_t xs32(uint32_t& s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+__device__ inline float rnd_float(uint32_t& s, int emin, int emax) {
+    const uint32_t m = xs32(s) & 0x7fffffu;
+    const uint32_t e = 127u + (uint32_t)(emin + (int)(xs32(s) % (uint32_t)(emax - emin + 1)));
+    const uint32_t sign = xs32(s) & 0x80000000u;
+    return __builtin_bit_cast(float, sign | (e << 23) | m);
+}
+__global__ __launch_bounds__(256) void k_selftest_div(unsigned long long per_thread, uint32_t seed,
+                                                      unsigned long long* mismatches) {
+    uint32_t s = seed ^ (0x9e3779b9u * (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x + 1));
+    unsigned long long bad = 0;
+    for (unsigned long long i = 0; i < per_thread; i++) {
+        const float b = rnd_float(s, -40, 40);
+        float a = rnd_float(s, -80, 60);
+        const uint32_t kind = xs32(s) & 15u;
+        if (kind == 0) a = 0.f;
+        else if (kind < 6) a = fabsf(rnd_float(s, -24, 0)) * 0.999f;      // like clipped barycentrics
+        const float q_ref = a / b;
+        const float q = div_known<true>(a, b, 1.0f / b);
+        bad += __builtin_bit_cast(uint32_t, q) != __builtin_bit_cast(uint32_t, q_ref);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+void launch_selftest_div(hipStream_t st, unsigned long long n, uint32_t seed, unsigned long long* mismatches) {
+    const int blocks = 2048, threads = 256;
+    const unsigned long long per = (n + (unsigned long long)blocks * threads - 1) / ((unsigned long long)blocks * threads);
+    k_selftest_div<<<blocks, threads, 0, st>>>(per, seed, mismatches);
+}
+}  // namespace jr

@@ -38,6 +38,7 @@ __device__ inline void pixel_range(float vlo, float vhi, int is, int& lo, int& h
 }
 
 __global__ __launch_bounds__(256) void k_face_setup(RasterParams p, const float* __restrict__ faces,
+                                                    const float* __restrict__ textures,
                                                     float* __restrict__ faces_info,
                                                     FaceGeo* __restrict__ geo,
                                                     ushort4* __restrict__ face_rect,
@@ -53,7 +54,11 @@ __global__ __launch_bounds__(256) void k_face_setup(RasterParams p, const float*
         for (int k = 0; k < 27; k++) out[k] = info[k];
     }
     FaceGeo g;
-    build_face_geo(g, f, info, p.rad);
+    build_face_geo(g, f, info, p.rad, i % p.NF);
+    if (p.T == 1) {      // single-texel surface colour travels with the record
+        const float* tx = textures + (size_t)i * 3;
+        g.col[0] = tx[0]; g.col[1] = tx[1]; g.col[2] = tx[2];
+    }
     geo[i] = g;
 
     int px0, px1, py0, py1;
@@ -168,13 +173,13 @@ __global__ __launch_bounds__(256) void k_bin_sort(const int* __restrict__ bin_co
     }
 }
 
-void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, float* faces_info,
-                    BinWorkspace& ws) {
+void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, const float* textures,
+                    float* faces_info, BinWorkspace& ws) {
     const int nfaces = p.B * p.NF;
     const int nbins = p.B * p.bins_x * p.bins_y;
     (void)hipMemsetAsync(ws.bin_count, 0, sizeof(int) * (size_t)nbins, st);
     (void)hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * 4, st);
-    k_face_setup<<<(nfaces + 255) / 256, 256, 0, st>>>(p, faces, faces_info, ws.geo, ws.face_rect, ws.bin_count);
+    k_face_setup<<<(nfaces + 255) / 256, 256, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_count);
     k_bin_alloc<<<(nbins + 255) / 256, 256, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.counters);
 }
 

@@ -42,6 +42,8 @@ struct jr_ctx {
     unsigned long long* h_counters = nullptr;   // pinned, 4 entries
     // identity of the bin lists currently held in ws (reused by the backward)
     const void* bins_faces = nullptr;
+    const void* bins_tex = nullptr;
+    int bins_T = 0;
     int bins_B = 0, bins_NF = 0, bins_IS = 0;
     float bins_rad = 0.f;
     bool bins_valid = false;
@@ -124,11 +126,22 @@ jr::RasterParams make_params(int B, int NF, int T, int IS, int K, float near_, f
     for (int k = 0; k < 3; k++) p.bg[k] = bg ? bg[k] : 0.f;
     p.bins_x = (IS + jr::BIN - 1) / jr::BIN;
     p.bins_y = p.bins_x;
+    // correctly rounded reciprocals of the per-call divisors (float IEEE divisions on the host)
+    p.far_minus_near = far_ - near_;
+    p.near_minus_far = near_ - far_;
+    p.r_sigma = 1.0f / sigma;
+    p.r_gamma = 1.0f / gamma;
+    p.r_far_minus_near = 1.0f / p.far_minus_near;
+    p.r_near_minus_far = 1.0f / p.near_minus_far;
+    auto in_range = [](float v) { const float a = std::fabs(v); return a >= 9.094947017729282e-13f && a <= 1.099511627776e12f; };
+    p.consts_safe = in_range(sigma) && in_range(gamma) && in_range(p.far_minus_near) && in_range(near_) &&
+                    in_range(far_) && (eps == 0.f || in_range(eps));
     return p;
 }
 
 // Build (or rebuild) the per-bin ascending face lists for this geometry.
-int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, float* faces_info) {
+int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
+               float* faces_info) {
     const size_t nfaces = (size_t)p.B * p.NF, nbins = (size_t)p.B * p.bins_x * p.bins_y;
     jr::BinWorkspace& ws = ctx->ws;
     if (nfaces > ws.faces_cap || !ws.geo) {
@@ -146,7 +159,7 @@ int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, float
     }
     {
         ProfScope ps(ctx, JR_PHASE_BIN_COUNT);
-        jr::launch_binning(ctx->stream, p, faces, faces_info, ws);
+        jr::launch_binning(ctx->stream, p, faces, textures, faces_info, ws);
     }
     JR_HIP(hipMemcpyAsync(ctx->h_counters, ws.counters, sizeof(unsigned long long) * 4,
                           hipMemcpyDeviceToHost, ctx->stream));
@@ -168,7 +181,7 @@ int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, float
     }
     JR_HIP(hipGetLastError());
     ctx->bins_faces = faces; ctx->bins_B = p.B; ctx->bins_NF = p.NF; ctx->bins_IS = p.IS;
-    ctx->bins_rad = p.rad; ctx->bins_valid = true;
+    ctx->bins_rad = p.rad; ctx->bins_tex = textures; ctx->bins_T = p.T; ctx->bins_valid = true;
     return 0;
 }
 
@@ -244,7 +257,7 @@ int jr_malloc(jr_ctx* ctx, size_t bytes, void** dptr) {
 int jr_free(jr_ctx* ctx, void* dptr) {
     if (!ctx) return fail("jr_free: NULL context");
     if (!dptr) return 0;
-    if (ctx->bins_faces == dptr) ctx->bins_valid = false;
+    if (ctx->bins_faces == dptr || ctx->bins_tex == dptr) ctx->bins_valid = false;
     auto it = ctx->live.find(dptr);
     if (it == ctx->live.end()) return fail("jr_free: pointer %p was not allocated by this context", dptr);
     ctx->cache[it->second].push_back(dptr);
@@ -265,7 +278,7 @@ int jr_ctx_trim(jr_ctx* ctx) {
 int jr_memcpy_h2d(jr_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return fail("NULL context");
     JR_HIP(hipSetDevice(ctx->device));
-    if (ctx->bins_faces == dst) ctx->bins_valid = false;
+    if (ctx->bins_faces == dst || ctx->bins_tex == dst) ctx->bins_valid = false;
     JR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     JR_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -280,14 +293,14 @@ int jr_memcpy_d2h(jr_ctx* ctx, void* dst, const void* src, size_t bytes) {
 int jr_memcpy_d2d(jr_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return fail("NULL context");
     JR_HIP(hipSetDevice(ctx->device));
-    if (ctx->bins_faces == dst) ctx->bins_valid = false;
+    if (ctx->bins_faces == dst || ctx->bins_tex == dst) ctx->bins_valid = false;
     JR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 int jr_memset(jr_ctx* ctx, void* dptr, int value, size_t bytes) {
     if (!ctx) return fail("NULL context");
     JR_HIP(hipSetDevice(ctx->device));
-    if (ctx->bins_faces == dptr) ctx->bins_valid = false;
+    if (ctx->bins_faces == dptr || ctx->bins_tex == dptr) ctx->bins_valid = false;
     JR_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
     return 0;
 }
@@ -338,7 +351,7 @@ int jr_softras_forward(jr_ctx* ctx, const float* face_vertices, const float* tex
     const jr::RasterParams p = make_params(B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
                                            dist_eps, gamma_val, func_id_rgb, func_id_alpha,
                                            texture_sample_type, double_side, background_rgb);
-    if (build_bins(ctx, p, face_vertices, faces_info)) return 1;
+    if (build_bins(ctx, p, face_vertices, textures, faces_info)) return 1;
     {
         ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
         jr::launch_softras_forward(ctx->stream, p, textures, ctx->ws, aggrs_info,
@@ -367,8 +380,9 @@ int jr_softras_backward(jr_ctx* ctx, const float* face_vertices, const float* te
                                            texture_sample_type, double_side, nullptr);
     // Tile lists of the matching forward are reused; anything else rebuilds them (no faces_info write).
     const bool reuse = ctx->bins_valid && ctx->bins_faces == face_vertices && ctx->bins_B == B &&
-                       ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad;
-    if (!reuse && build_bins(ctx, p, face_vertices, nullptr)) return 1;
+                       ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad &&
+                       ctx->bins_tex == textures && ctx->bins_T == T;
+    if (!reuse && build_bins(ctx, p, face_vertices, textures, nullptr)) return 1;
     {
         ProfScope ps(ctx, JR_PHASE_BWD_RASTER);
         jr::launch_softras_backward(ctx->stream, p, textures, soft_colors, aggrs_info, faces_id_buffer,
@@ -411,6 +425,18 @@ int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, i
     JR_HIP(hipSetDevice(ctx->device));
     jr::launch_avgpool2x2_backward(ctx->stream, grad_out, grad_in, planes, H, W);
     JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_selftest_division(jr_ctx* ctx, uint64_t n, uint32_t seed, uint64_t* mismatches) {
+    if (!ctx || !mismatches) return fail("NULL argument");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipMemsetAsync(ctx->ws.counters, 0, sizeof(unsigned long long) * 4, ctx->stream));
+    jr::launch_selftest_div(ctx->stream, n, seed, ctx->ws.counters);
+    JR_HIP(hipMemcpyAsync(ctx->h_counters, ctx->ws.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    *mismatches = ctx->h_counters[0];
     return 0;
 }
 

@@ -20,8 +20,8 @@ struct BinWorkspace {
     size_t faces_cap = 0, bins_cap = 0, pool_cap = 0;
 };
 
-void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, float* faces_info,
-                    BinWorkspace& ws);
+void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, const float* textures,
+                    float* faces_info, BinWorkspace& ws);
 void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws);
 
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
@@ -38,5 +38,6 @@ void launch_face_vertices_backward(hipStream_t st, const float* gfv, const int32
                                    float* gv, int B, int NV, int NF);
 void launch_avgpool2x2_forward(hipStream_t st, const float* in, float* out, int planes, int H, int W);
 void launch_avgpool2x2_backward(hipStream_t st, const float* gout, float* gin, int planes, int H, int W);
+void launch_selftest_div(hipStream_t st, unsigned long long n, uint32_t seed, unsigned long long* mismatches);
 
 }  // namespace jr

@@ -59,66 +59,74 @@ struct PixelGrad {           // per-pixel inputs of the backward (SRK:1230-1231,
     float g0, g1, g2, g3;    // upstream gradient of r g b a
     float o0, o1, o2, o3;    // forward outputs r g b a
     float ssum, smax;        // aggrs_info
+    float r_ssum;            // 1/ssum (gradient-only quantity: reciprocal multiply, <= 1 ulp)
 };
+
+// x / c for gradient-only quantities: reciprocal multiply when the constant is in the safe range
+__device__ inline float gdiv(float x, float c, float rc, const RasterParams& p) {
+    return p.consts_safe ? x * rc : x / c;
+}
 
 // Contribution of one (pixel, face) pair: gv = d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2), gt = colour gradient
 // (3 values for a single-texel surface, 9 for vertex colours).  Returns the sampled texel.
-template <int DIST, int RGB>
-__device__ inline int backward_pair(const RasterParams& p, const FaceRec& fr, const PixelGrad& px,
-                                    float xp, float yp, const float* __restrict__ tbase,
-                                    float (&gv)[9], float (&gt)[9], float& tgs, bool& tex_on) {
-    const FaceGeo& r = fr.g;
-    const int fn = fr.id;
+// The forward quantities it re-derives (w, distance, coverage, clipped depth, normalised depth) go
+// through the SAME device functions as the forward kernel, so they carry the forward's exact bits
+// (the softmax weight exp((zn - smax)/gamma) is extremely sensitive to zn).  Everything that only
+// feeds gradients uses reciprocal multiplies: float atomics already make the sums order dependent.
+template <int DIST, int RGB, bool FAST>
+__device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
+                                    const PixelGrad& px, float xp, float yp,
+                                    const float* __restrict__ tbase, float (&gv)[9], float (&gt)[9],
+                                    float& tgs, bool& tex_on) {
+    const int fn = r.id;
     const Bary w = barycentric(r, xp, yp);
     float D, dis = 0.f;
     Dist dd;
     dd.sign = 0.f; dd.dx = 0.f; dd.dy = 0.f; dd.t0 = 0.f; dd.t1 = 0.f; dd.t2 = 0.f;
     if (DIST == 0) D = 1.f;                                               // SRK:1258-1270
-    else if (DIST == 1) { dis = barycentric_dist(w); D = coverage(-dis / p.sigma); }
+    else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_fast(-dis, p); }
     else {
         dd = euclidean_p2f(r, w, xp, yp);
         dis = dd.dx * dd.dx + dd.dy * dd.dy;
-        D = coverage(-dd.sign * dis / p.sigma);
+        D = coverage_fast(-dd.sign * dis, p);
     }
     float ca = px.g3;                                                     // SRK:1281-1291
     if (p.alpha == 1) ca /= p.NF;
-    else if (p.alpha == 2)
-        ca = (float)((double)ca * ((double)(1 - px.o3) / fmax((double)(1 - D), 1e-6)));
-    float cxy = 0.f;
-    cxy += ca;
-    const Bary wc = barycentric_clip(w);                                  // SRK:1294-1296
-    const float zp = depth_of(r, wc);
+    else if (p.alpha == 2) ca = ca * (1 - px.o3) * __builtin_amdgcn_rcpf(fmaxf(1 - D, 1e-6f));
+    float cxy = ca;
+    const Bary wc = barycentric_clip<FAST>(w);                            // SRK:1294-1296
+    const float zp = depth_of<FAST>(r, wc);
     const int texel = p.tex == 0 ? surface_texel(wc, p.R) : 0;
     tgs = 0.f;
     tex_on = false;
     if (RGB == 0) {                                                       // SRK:1299-1306
         if ((float)fn == px.smax) { tgs = 1.f; tex_on = true; }
     } else if (RGB == 1) {                                                // SRK:1308-1332
-        const float zn = (p.far_ - zp) / (p.far_ - p.near_);
-        const float zs = D * expf((zn - px.smax) / p.gamma) / px.ssum;
+        const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
+        const float zs = D * expf(over_gamma<FAST>(zn - px.smax, p)) * px.r_ssum;
         tgs = zs; tex_on = true;
         float k0, k1, k2;
         if (p.tex == 0) {
-            if (p.T == 1) { k0 = fr.col[0]; k1 = fr.col[1]; k2 = fr.col[2]; }
+            if (p.T == 1) { k0 = r.col[0]; k1 = r.col[1]; k2 = r.col[2]; }
             else {
                 const float* tx_ = tbase + ((size_t)fn * p.T + texel) * 3;
                 k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
             }
         } else {                                                           // SRK:1147-1149 (affine)
-            k0 = (wc.w0 * fr.col[0] + wc.w1 * fr.col[3]) + wc.w2 * fr.col[6];
-            k1 = (wc.w0 * fr.col[1] + wc.w1 * fr.col[4]) + wc.w2 * fr.col[7];
-            k2 = (wc.w0 * fr.col[2] + wc.w1 * fr.col[5]) + wc.w2 * fr.col[8];
+            k0 = (wc.w0 * vc[0] + wc.w1 * vc[3]) + wc.w2 * vc[6];
+            k1 = (wc.w0 * vc[1] + wc.w1 * vc[4]) + wc.w2 * vc[7];
+            k2 = (wc.w0 * vc[2] + wc.w1 * vc[5]) + wc.w2 * vc[8];
         }
         float crgb = 0.f;
         crgb += px.g0 * (k0 - px.o0);
         crgb += px.g1 * (k1 - px.o1);
         crgb += px.g2 * (k2 - px.o2);
         crgb *= zs;
-        cxy += crgb / D;
-        const float cz = crgb / p.gamma / (p.near_ - p.far_) * zp * zp;
-        gv[2] = cz * wc.w0 / r.z[0] / r.z[0];
-        gv[5] = cz * wc.w1 / r.z[1] / r.z[1];
-        gv[8] = cz * wc.w2 / r.z[2] / r.z[2];
+        cxy += crgb * __builtin_amdgcn_rcpf(D);
+        const float cz = gdiv(gdiv(crgb, p.gamma, p.r_gamma, p), p.near_minus_far, p.r_near_minus_far, p) * zp * zp;
+        gv[2] = cz * wc.w0 * r.rz[0] * r.rz[0];
+        gv[5] = cz * wc.w1 * r.rz[1] * r.rz[1];
+        gv[8] = cz * wc.w2 * r.rz[2] * r.rz[2];
     }
     if (tex_on) {
         if (p.tex == 1) {                    // backward_sample_texture vertex: w[j]*grad (SRK:1170-1172)
@@ -133,10 +141,10 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& fr, co
             gt[0] = tgs * px.g0; gt[1] = tgs * px.g1; gt[2] = tgs * px.g2;
         }
     }
-    cxy *= D * (1 - D) / p.sigma;                                         // SRK:1336
+    cxy *= gdiv(D * (1 - D), p.sigma, p.r_sigma, p);                      // SRK:1336
     if (DIST == 1) {                                                      // SRK:1118-1132
         const int q = w.w0 > w.w1 ? (w.w1 > w.w2 ? 2 : 1) : (w.w0 > w.w2 ? 2 : 0);
-        const double mul = dis > 0 ? (2. * (double)sqrtf(dis)) : (2. * (double)sqrtf(-dis));
+        const float mul = 2.f * sqrtf(fabsf(dis));
 #pragma unroll
         for (int l = 0; l < 2; l++) {
             const float ql = q == 0 ? r.inv[l] : (q == 1 ? r.inv[3 + l] : r.inv[6 + l]);
@@ -146,18 +154,18 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& fr, co
                 s += -ql * r.inv[3 * k + 0] * xp;
                 s += -ql * r.inv[3 * k + 1] * yp;
                 s += -ql * r.inv[3 * k + 2] * 1.f;
-                float v = s * cxy;
-                v = (float)((double)v * mul);
-                gv[3 * k + l] = v;
+                gv[3 * k + l] = s * cxy * mul;
             }
         }
     } else if (DIST == 2) {                                               // SRK:1341-1347
         const float w0s[3] = {w.w0, w.w1, w.w2};
         const float ts[3] = {dd.t0, dd.t1, dd.t2};
+        const float cx2 = 2 * dd.sign * cxy;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            gv[3 * k + 0] = 2 * dd.sign * cxy * (ts[k] + w0s[k]) * dd.dx;
-            gv[3 * k + 1] = 2 * dd.sign * cxy * (ts[k] + w0s[k]) * dd.dy;
+            const float c = cx2 * (ts[k] + w0s[k]);
+            gv[3 * k + 0] = c * dd.dx;
+            gv[3 * k + 1] = c * dd.dy;
         }
     }
     return texel;
@@ -171,7 +179,9 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
     const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
     float* __restrict__ grad_faces, float* __restrict__ grad_textures) {
-    __shared__ FaceRec s_rec[CHUNK];
+    extern __shared__ float4 s_dyn[];
+    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
+    float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
     __shared__ int s_ids[CHUNK];
     __shared__ unsigned long long s_need;
 
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(64) void k_softras_backward(
         px.ssum = aggrs[(size_t)b * 2 * pp + pn];
         px.smax = aggrs[(size_t)b * 2 * pp + pp + pn];
     }
+    px.r_ssum = __builtin_amdgcn_rcpf(px.ssum);
 
     const unsigned long long* seg = pool + bin_base[bin];
     const FaceGeo* gbase = geo + (size_t)b * p.NF;
@@ -275,14 +286,11 @@ __global__ __launch_bounds__(64) void k_softras_backward(
             const float4* src = reinterpret_cast<const float4*>(gp);
             float4* dst = reinterpret_cast<float4*>(&s_rec[lane]);
 #pragma unroll
-            for (int k = 0; k < 9; k++) dst[k] = src[k];
-            s_rec[lane].id = fn_f;
-            const float* tx_ = tbase + (size_t)fn_f * p.T * 3;
+            for (int k = 0; k < 11; k++) dst[k] = src[k];
             if (p.tex == 1) {
+                const float* tx_ = tbase + (size_t)fn_f * p.T * 3;
 #pragma unroll
-                for (int k = 0; k < 9; k++) s_rec[lane].col[k] = tx_[k];
-            } else if (p.T == 1) {
-                s_rec[lane].col[0] = tx_[0]; s_rec[lane].col[1] = tx_[1]; s_rec[lane].col[2] = tx_[2];
+                for (int k = 0; k < 9; k++) s_vcol[lane * 9 + k] = tx_[k];
             }
         }
         __syncthreads();
@@ -296,10 +304,13 @@ __global__ __launch_bounds__(64) void k_softras_backward(
             float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // x0 y0 z0 x1 y1 z1 x2 y2 z2
             float gt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             // check_border is repeated by the reference's backward (SRK:1244)
-            if (has && !(xp > fr.g.xhi || xp < fr.g.xlo || yp > fr.g.yhi || yp < fr.g.ylo)) {
+            if (has && !(xp > fr.xhi || xp < fr.xlo || yp > fr.yhi || yp < fr.ylo)) {
                 float tgs;
                 bool tex_on;
-                const int texel = backward_pair<DIST, RGB>(p, fr, px, xp, yp, tbase, gv, gt, tgs, tex_on);
+                const float* vc = s_vcol + f * 9;
+                const int texel = ((fr.flags & FLAG_SAFE) && p.consts_safe)
+                    ? backward_pair<DIST, RGB, true>(p, fr, vc, px, xp, yp, tbase, gv, gt, tgs, tex_on)
+                    : backward_pair<DIST, RGB, false>(p, fr, vc, px, xp, yp, tbase, gv, gt, tgs, tex_on);
                 if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: straight to global
                     float* gtx = gtbase + ((size_t)fr.id * p.T + texel) * 3;
                     atomicAdd(gtx + 0, tgs * px.g0);
@@ -333,12 +344,13 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
                      const BinWorkspace& ws, const float* rgba, const float* aggrs, const int32_t* ids,
                      const float* grad_rgba, float* grad_faces, float* grad_textures) {
     const int grid = ((ntiles + 7) / 8) * 8;
+    const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
     if (p.K <= 16)
-        k_softras_backward<DIST, RGB, 16><<<grid, 64, 0, st>>>(
+        k_softras_backward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_count, ws.bin_base, ws.pool, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures);
     else
-        k_softras_backward<DIST, RGB, 64><<<grid, 64, 0, st>>>(
+        k_softras_backward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_count, ws.bin_base, ws.pool, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures);
 }

@@ -4,16 +4,22 @@
 // (jrender/renderer/dr/softras/cuda/soft_rasterize.py, "SRK"), in the same
 // precision and association order, because the per-pixel face-index buffer has
 // to match bit for bit.  This translation unit MUST be
-// built with -ffp-contract=off (no FMA contraction) and without fast-math; the
-// `double` islands below are where the reference's bare literals promote.
+// built with -ffp-contract=off (no FMA contraction) and without fast-math.
 //
-// What is NOT the reference's: the data organisation.  Every face gets one packed
-// 144-byte geometry record (FaceGeo) written once per forward by the setup kernel:
-// border box incl. cull radius, face_inv, vertices, edge-difference vectors of the
-// Gram matrix and the edge denominators, obtuse vertex, facing.  The raster kernels
-// copy the records of the faces a wavefront needs into LDS and every lane reads the
-// record of ITS current face — no dynamic register indexing, no scattered global
-// gathers in the inner loop.
+// What is NOT the reference's: the data organisation and how the IEEE quotients are obtained.
+//  * Every face gets one packed 176-byte record (FaceGeo) written once per forward by the setup
+//    kernel: border box incl. cull radius, face_inv, vertices, edge-difference vectors of the
+//    Gram matrix, obtuse vertex, facing, colour, and the correctly rounded reciprocals of the
+//    per-face divisors.  The raster kernels copy the records a wavefront needs into LDS and every
+//    lane reads the record of ITS current face — no dynamic register indexing, no scattered
+//    global gathers in the inner loop.
+//  * A float quotient a/b whose divisor is a per-face or per-call constant is computed from
+//    y = RN(1/b) (one true division, done once) with the two-step FMA refinement
+//        q0 = a*y; r0 = fma(-b,q0,a); q1 = fma(r0,y,q0); r1 = fma(-b,q1,a); q = fma(r1,y,q1)
+//    which is the tail of the compiler's own correctly-rounded division expansion and returns
+//    RN(a/b) — the SAME bits as `a / b` — whenever no intermediate leaves the normal range.
+//    Faces / constants outside a conservative range are flagged and take the plain division.
+//    tests/test_gpu_parity.py::test_fast_division_identity checks the identity on 2^31 operands.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,30 +40,52 @@ struct RasterParams {
     int dist, rgb, alpha, tex, double_side;
     float bg[3];
     int bins_x, bins_y;   // ceil(IS / BIN)
+    // correctly rounded reciprocals of the per-call divisors + "they are in the safe range"
+    float far_minus_near, near_minus_far;
+    float r_sigma, r_gamma, r_far_minus_near, r_near_minus_far;
+    int consts_safe;
 };
 
-// Packed per-face geometry, 36 floats = 9 x 16 B (global, one per face per forward).
+constexpr int FLAG_FRONT = 1;    // check_face_frontside (SRK:37-40)
+constexpr int FLAG_SAFE = 2;     // per-face divisors/operands inside the fast-division range
+
+// Packed per-face record, 44 floats = 11 x 16 B (an ODD number of 16-byte slots: lanes that read
+// records of different faces from LDS spread over all bank groups).
 struct FaceGeo {
     float xlo, xhi, ylo, yhi;      // border box incl. cull radius        (SRK:28-34, :316)
     float inv[9];                  // face_inv                            (SRK:205-217)
     float z[3];
     float x0, y0, x1, y1, x2, y2;
     int obt;                       // index of the (first) obtuse vertex or -1   (SRK:227-235)
-    int front;                     // check_face_frontside                (SRK:37-40)
+    int flags;
     float A[9];                    // A[e] = sym[e] - sym[e+1]            (SRK:77-79)
     float Dn[3];                   // A[e][e] - A[e][e+1]                 (SRK:81 denominator)
+    float rz[3];                   // RN(1/z[k])
+    int id;                        // face index inside its image
+    float col[3];                  // surface colour when T == 1
+    int pad;
 };
-static_assert(sizeof(FaceGeo) == 144, "FaceGeo layout");
+static_assert(sizeof(FaceGeo) == 176, "FaceGeo layout");
+typedef FaceGeo FaceRec;
 
-// LDS record = geometry + what the colour path needs.  52 dwords = 13 x 16 B: an ODD number of
-// 16-byte slots, so lanes that read records of different faces spread over all LDS bank groups.
-struct FaceRec {
-    FaceGeo g;
-    int id;
-    float col[9];                  // T==1 surface colour (3) or the three vertex colours (9)
-    int pad[6];
-};
-static_assert(sizeof(FaceRec) == 208, "FaceRec layout");
+// ---- exact division by a divisor whose correctly rounded reciprocal is known ------------------
+template <bool FAST>
+__device__ inline float div_known(float a, float b, float rb) {
+    if (FAST) {
+        const float q0 = a * rb;
+        const float r0 = __builtin_fmaf(-b, q0, a);
+        const float q1 = __builtin_fmaf(r0, rb, q0);
+        const float r1 = __builtin_fmaf(-b, q1, a);
+        return __builtin_fmaf(r1, rb, q1);
+    }
+    return a / b;
+}
+
+__device__ inline bool in_fast_range(float v) {       // finite, 2^-40 <= |v| <= 2^40
+    const float a = fabsf(v);
+    return a >= 9.094947017729282e-13f && a <= 1.099511627776e12f;
+}
+__device__ inline bool zero_or_in_fast_range(float v) { return v == 0.f || in_fast_range(v); }
 
 // Per-face preprocessing = faces_info of the reference (SRK:176-236).
 __device__ inline void face_setup(const float* __restrict__ f, float* __restrict__ info) {
@@ -86,16 +114,17 @@ __device__ inline void face_setup(const float* __restrict__ f, float* __restrict
     for (int k = 21; k < 27; k++) info[k] = 0.f;
 }
 
-// Geometry record from the face and its faces_info.
+// Record from the face, its faces_info and (T == 1) its colour.
 __device__ inline void build_face_geo(FaceGeo& r, const float* __restrict__ f,
-                                      const float* __restrict__ fi, float rad) {
+                                      const float* __restrict__ fi, float rad, int id) {
     const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
     r.xhi = fmaxf(fmaxf(x0, x1), x2) + rad;
     r.xlo = fminf(fminf(x0, x1), x2) - rad;
     r.yhi = fmaxf(fmaxf(y0, y1), y2) + rad;
     r.ylo = fminf(fminf(y0, y1), y2) - rad;
+    bool safe = true;
 #pragma unroll
-    for (int k = 0; k < 9; k++) r.inv[k] = fi[k];
+    for (int k = 0; k < 9; k++) { r.inv[k] = fi[k]; safe = safe && zero_or_in_fast_range(fi[k]); }
     r.z[0] = f[2]; r.z[1] = f[5]; r.z[2] = f[8];
     r.x0 = x0; r.y0 = y0; r.x1 = x1; r.y1 = y1; r.x2 = x2; r.y2 = y2;
     const float* sym = fi + 9;
@@ -103,16 +132,28 @@ __device__ inline void build_face_geo(FaceGeo& r, const float* __restrict__ f,
     for (int e = 0; e < 3; e++) {
         const int e1 = (e + 1) % 3;
 #pragma unroll
-        for (int c = 0; c < 3; c++) r.A[3 * e + c] = sym[3 * e + c] - sym[3 * e1 + c];
+        for (int c = 0; c < 3; c++) {
+            r.A[3 * e + c] = sym[3 * e + c] - sym[3 * e1 + c];
+            safe = safe && zero_or_in_fast_range(r.A[3 * e + c]);
+        }
         r.Dn[e] = r.A[3 * e + e] - r.A[3 * e + e1];
+        r.rz[e] = 1.0f / r.z[e];
+        safe = safe && in_fast_range(r.Dn[e]) && in_fast_range(r.z[e]);
     }
+    safe = safe && fabsf(x0) <= 1024.f && fabsf(y0) <= 1024.f && fabsf(x1) <= 1024.f &&
+           fabsf(y1) <= 1024.f && fabsf(x2) <= 1024.f && fabsf(y2) <= 1024.f;
     r.obt = fi[18] == 1.f ? 0 : (fi[19] == 1.f ? 1 : (fi[20] == 1.f ? 2 : -1));
-    r.front = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1 : 0;
+    r.flags = (((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? FLAG_FRONT : 0) | (safe ? FLAG_SAFE : 0);
+    r.id = id;
+    r.col[0] = 0.f; r.col[1] = 0.f; r.col[2] = 0.f; r.pad = 0;
 }
 
 // pixel centre in NDC: (2*i + 1 - IS) / IS evaluated in double, rounded once (SRK:280-283)
+// Both integers are exact floats (|2i+1-IS| < 2^24), and rounding the double quotient to float
+// equals the correctly rounded float quotient (double rounding is innocuous for division at
+// 53 >= 2*24+2 bits), so one IEEE float division yields the reference's bits.
 __device__ inline float pixel_centre(int i, int is) {
-    return (float)((2. * i + 1. - is) / is);
+    return (float)(2 * i + 1 - is) / (float)is;
 }
 
 struct Bary { float w0, w1, w2; };
@@ -136,19 +177,27 @@ __device__ inline bool pixel_inside(const Bary& b) {                            
 __device__ inline float clamp01(float v) { return fmaxf(fminf(v, 1.f), 0.f); }           // SRK:51
 __device__ inline float clamp01_maxfirst(float v) { return fminf(fmaxf(v, 0.f), 1.f); }  // SRK:138
 
+template <bool FAST>
 __device__ inline Bary barycentric_clip(Bary b) {                                    // SRK:49-54
     b.w0 = clamp01(b.w0); b.w1 = clamp01(b.w1); b.w2 = clamp01(b.w2);
     // max(w_sum, 1e-5) compares in double and stores (float)1e-5 when clamped == fmaxf(s, 1e-5f)
     const float s = fmaxf((b.w0 + b.w1) + b.w2, 1e-5f);
-    b.w0 = b.w0 / s; b.w1 = b.w1 / s; b.w2 = b.w2 / s;
+    // three quotients by the same divisor s in [1e-5, 3]: one true reciprocal, three refinements
+    const float rs = FAST ? 1.0f / s : 0.f;
+    b.w0 = div_known<FAST>(b.w0, s, rs);
+    b.w1 = div_known<FAST>(b.w1, s, rs);
+    b.w2 = div_known<FAST>(b.w2, s, rs);
     return b;
 }
 
 // depth of the clipped barycentric point, 1./(sum w/z) (SRK:364, :1296).  The reference divides in
 // double and rounds to float; for a float divisor that equals the correctly rounded float quotient
 // (53 >= 2*24+2 bits: double rounding is innocuous for division), i.e. IEEE 1.0f/s.
+// The clipped weights are 0 or >= 2^-24-ish multiples, well inside the fast-division range.
+template <bool FAST>
 __device__ inline float depth_of(const FaceGeo& r, const Bary& c) {
-    const float s = (c.w0 / r.z[0] + c.w1 / r.z[1]) + c.w2 / r.z[2];
+    const float s = (div_known<FAST>(c.w0, r.z[0], r.rz[0]) + div_known<FAST>(c.w1, r.z[1], r.rz[1])) +
+                    div_known<FAST>(c.w2, r.z[2], r.rz[2]);
     return 1.0f / s;
 }
 
@@ -157,33 +206,51 @@ struct Dist {
     float t0, t1, t2;     // nearest-point barycentric minus w   (SRK:98-100, :139)
 };
 
-__device__ inline float edge_param(const Bary& b, const float* A3, float a_v1, float dn) {
-    return (((b.w0 * A3[0] + b.w1 * A3[1]) + b.w2 * A3[2]) - a_v1) / dn;       // SRK:81 / :132
+// Projection of the pixel onto edge e (vertices e, e+1): t along the edge, the point's barycentric
+// coordinates minus w, the offset to the pixel and its squared length (SRK:73-92 / :123-144).
+// CLAMP selects the outside-the-triangle variant (t clamped to the segment, SRK:137-140).
+struct EdgeCand { float u0, u1, u2, ex, ey, dd; };
+
+template <bool STATIC_E, int E>
+__device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e_dyn, bool clamp) {
+    float a0, a1, a2, av1, dn;
+    int e;
+    if (STATIC_E) {
+        e = E;
+        a0 = r.A[3 * E]; a1 = r.A[3 * E + 1]; a2 = r.A[3 * E + 2];
+        av1 = r.A[3 * E + (E + 1) % 3];
+        dn = r.Dn[E];
+    } else {
+        e = e_dyn;
+        a0 = e == 0 ? r.A[0] : (e == 1 ? r.A[3] : r.A[6]);
+        a1 = e == 0 ? r.A[1] : (e == 1 ? r.A[4] : r.A[7]);
+        a2 = e == 0 ? r.A[2] : (e == 1 ? r.A[5] : r.A[8]);
+        av1 = e == 0 ? a1 : (e == 1 ? a2 : a0);
+        dn = e == 0 ? r.Dn[0] : (e == 1 ? r.Dn[1] : r.Dn[2]);
+    }
+    // the numerator can be a rounding crumb (pixel projecting exactly onto a vertex), which is
+    // outside the fast-division guarantee: plain IEEE division here
+    const float tv = (((b.w0 * a0 + b.w1 * a1) + b.w2 * a2) - av1) / dn;                 // SRK:81 / :132
+    const float tn = 1 - tv;
+    // t[e] = tv, t[e+1] = 1 - tv, t[e+2] = 0 (indices mod 3)
+    float u0 = e == 0 ? tv : (e == 2 ? tn : 0.f);
+    float u1 = e == 1 ? tv : (e == 0 ? tn : 0.f);
+    float u2 = e == 2 ? tv : (e == 1 ? tn : 0.f);
+    if (clamp) { u0 = clamp01_maxfirst(u0); u1 = clamp01_maxfirst(u1); u2 = clamp01_maxfirst(u2); }
+    EdgeCand c;
+    c.u0 = u0 - b.w0; c.u1 = u1 - b.w1; c.u2 = u2 - b.w2;
+    c.ex = (c.u0 * r.x0 + c.u1 * r.x1) + c.u2 * r.x2;
+    c.ey = (c.u0 * r.y0 + c.u1 * r.y1) + c.u2 * r.y2;
+    c.dd = c.ex * c.ex + c.ey * c.ey;
+    return c;
 }
 
-// squared-distance machinery, euclidean mode (SRK:57-147).  No dynamic register indexing:
-// the edge is selected with v_cndmask chains.
+// squared-distance machinery, euclidean mode (SRK:57-147).  The inside case (three edge
+// projections, keep the nearest) and the outside case (one edge chosen from the sign pattern of
+// w, clamped) share the first projection so that a wavefront with both kinds of pixels does not
+// execute two separate code paths; the two further projections run only if some lane is inside.
 __device__ inline Dist euclidean_p2f(const FaceGeo& r, const Bary& b, float xp, float yp) {
-    Dist d;
-    if (b.w0 > 0 && b.w1 > 0 && b.w2 > 0 && b.w0 < 1 && b.w1 < 1 && b.w2 < 1) {
-        float best = 100000000.f, bx = 0.f, by = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 3; e++) {
-            const int e1 = (e + 1) % 3;
-            const float tv = edge_param(b, &r.A[3 * e], r.A[3 * e + e1], r.Dn[e]);
-            const float tn = 1 - tv;
-            float u0 = (e == 0) ? tv : ((e1 == 0) ? tn : 0.f);
-            float u1 = (e == 1) ? tv : ((e1 == 1) ? tn : 0.f);
-            float u2 = (e == 2) ? tv : ((e1 == 2) ? tn : 0.f);
-            u0 -= b.w0; u1 -= b.w1; u2 -= b.w2;
-            const float ex = (u0 * r.x0 + u1 * r.x1) + u2 * r.x2;
-            const float ey = (u0 * r.y0 + u1 * r.y1) + u2 * r.y2;
-            const float dd = ex * ex + ey * ey;
-            if (dd < best) { best = dd; bx = ex; by = ey; s0 = u0; s1 = u1; s2 = u2; }
-        }
-        d.sign = 1.f; d.dx = bx; d.dy = by; d.t0 = s0; d.t1 = s1; d.t2 = s2;
-        return d;
-    }
+    const bool inside = b.w0 > 0 && b.w1 > 0 && b.w2 > 0 && b.w0 < 1 && b.w1 < 1 && b.w2 < 1;
     int v0 = -1;                                                                      // SRK:107-121
     if (b.w1 <= 0 && b.w2 <= 0) {
         v0 = 0;
@@ -197,30 +264,26 @@ __device__ inline Dist euclidean_p2f(const FaceGeo& r, const Bary& b, float xp, 
     } else if (b.w0 <= 0) v0 = 1;
     else if (b.w1 <= 0) v0 = 2;
     else if (b.w2 <= 0) v0 = 0;
-    d.sign = -1.f;
-    if (v0 < 0) {
+
+    Dist d;
+    const EdgeCand c = edge_candidate<false, 0>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
+    if (inside) {
+        // SRK:68-105: dis_min starts at 1e8, strict '<' keeps the first of equal candidates
+        float best = 100000000.f;
+        d.dx = 0.f; d.dy = 0.f; d.t0 = 0.f; d.t1 = 0.f; d.t2 = 0.f;
+        if (c.dd < best) { best = c.dd; d.dx = c.ex; d.dy = c.ey; d.t0 = c.u0; d.t1 = c.u1; d.t2 = c.u2; }
+        const EdgeCand c1 = edge_candidate<true, 1>(r, b, 1, false);
+        if (c1.dd < best) { best = c1.dd; d.dx = c1.ex; d.dy = c1.ey; d.t0 = c1.u0; d.t1 = c1.u1; d.t2 = c1.u2; }
+        const EdgeCand c2 = edge_candidate<true, 2>(r, b, 2, false);
+        if (c2.dd < best) { best = c2.dd; d.dx = c2.ex; d.dy = c2.ey; d.t0 = c2.u0; d.t1 = c2.u1; d.t2 = c2.u2; }
+        d.sign = 1.f;
+    } else if (v0 < 0) {
         // Reference indexes t[-1]/a0[-1] here (undefined behaviour; only reachable when some
         // w >= 1 by rounding while none is <= 0).  Defined like the oracle: distance 0.
-        d.dx = 0.f; d.dy = 0.f; d.t0 = 0.f - b.w0; d.t1 = 0.f - b.w1; d.t2 = 0.f - b.w2;
-        return d;
+        d.sign = -1.f; d.dx = 0.f; d.dy = 0.f; d.t0 = 0.f - b.w0; d.t1 = 0.f - b.w1; d.t2 = 0.f - b.w2;
+    } else {
+        d.sign = -1.f; d.dx = c.ex; d.dy = c.ey; d.t0 = c.u0; d.t1 = c.u1; d.t2 = c.u2;
     }
-    const float a0 = v0 == 0 ? r.A[0] : (v0 == 1 ? r.A[3] : r.A[6]);
-    const float a1 = v0 == 0 ? r.A[1] : (v0 == 1 ? r.A[4] : r.A[7]);
-    const float a2 = v0 == 0 ? r.A[2] : (v0 == 1 ? r.A[5] : r.A[8]);
-    const float av1 = v0 == 0 ? a1 : (v0 == 1 ? a2 : a0);
-    const float dn = v0 == 0 ? r.Dn[0] : (v0 == 1 ? r.Dn[1] : r.Dn[2]);
-    const float tv = (((b.w0 * a0 + b.w1 * a1) + b.w2 * a2) - av1) / dn;                 // SRK:132
-    const float tn = 1 - tv;
-    // t[v0] = tv, t[v1] = 1 - tv, t[v2] = 0 with v1 = v0+1, v2 = v0+2 (mod 3)
-    float u0 = v0 == 0 ? tv : (v0 == 2 ? tn : 0.f);
-    float u1 = v0 == 1 ? tv : (v0 == 0 ? tn : 0.f);
-    float u2 = v0 == 2 ? tv : (v0 == 1 ? tn : 0.f);
-    u0 = clamp01_maxfirst(u0) - b.w0;                                                     // SRK:137-140
-    u1 = clamp01_maxfirst(u1) - b.w1;
-    u2 = clamp01_maxfirst(u2) - b.w2;
-    d.dx = (u0 * r.x0 + u1 * r.x1) + u2 * r.x2;
-    d.dy = (u0 * r.y0 + u1 * r.y1) + u2 * r.y2;
-    d.t0 = u0; d.t1 = u1; d.t2 = u2;
     return d;
 }
 
@@ -229,9 +292,21 @@ __device__ inline float barycentric_dist(const Bary& b) {                       
     return m > 0 ? m * m : -m * m;
 }
 
-// sigmoid coverage: 1./(1.+exp(x)) with float exp and a double add/divide (SRK:338, :344)
-__device__ inline float coverage(float neg_arg) {
-    return (float)(1. / (1. + (double)expf(neg_arg)));
+// ---- colour path (1e-4 tolerance, not bit-critical: nothing here feeds the face-index buffer) ----
+// x / sigma and x / gamma as reciprocal multiplies (<= 1 ulp off the IEEE quotient)
+__device__ inline float over_sigma(float x, const RasterParams& p) {
+    return p.consts_safe ? x * p.r_sigma : x / p.sigma;
+}
+// x / gamma feeds exp() with arguments of magnitude up to 1e4: keep the IEEE quotient (the
+// refinement form is exact for these operands: differences of normalised depths are multiples
+// of 2^-48 or larger).
+template <bool FAST>
+__device__ inline float over_gamma(float x, const RasterParams& p) {
+    return div_known<FAST>(x, p.gamma, p.r_gamma);
+}
+// sigmoid coverage 1/(1+exp(neg_num/sigma)) (SRK:338, :344; the reference adds and divides in double)
+__device__ inline float coverage_fast(float neg_num, const RasterParams& p) {
+    return __builtin_amdgcn_rcpf(1.0f + expf(over_sigma(neg_num, p)));
 }
 
 // 'surface' sampler texel choice (SRK:159-166, identical in SRK:1138-1145)

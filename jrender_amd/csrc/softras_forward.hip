@@ -9,15 +9,20 @@
 //                         reference's border test (SRK:28-34) against the tile's 8 column and 8 row
 //                         pixel centres.  Every compare is a v_cmp whose 64-bit result IS the
 //                         wavefront ballot over the 64 faces: 32 compares cull 64 faces x 64 pixels.
-//   stage (lane = face)   surviving faces copy their packed geometry record into LDS.
+//   stage (lane = face)   surviving faces copy their packed record into LDS.
 //   raster(lane = pixel)  each pixel ANDs its column ballot with its row ballot: a private bitmask
 //                         of the faces that pass ITS border test.  It then pops its own bits in
-//                         ascending face order and runs the exact per-(pixel,face) arithmetic on
-//                         the LDS record of ITS face — lanes stay busy although neighbouring pixels
-//                         see different face subsets (lane compaction by bitmask).
+//                         ascending face order and runs the per-(pixel,face) arithmetic on the LDS
+//                         record of ITS face — lanes stay busy although neighbouring pixels see
+//                         different face subsets (lane compaction by bitmask).
 //
 // The per-pixel state machine (alpha, online softmax over depth, K-nearest buffer) lives in VGPRs;
 // it is sequential in face order, which is why the lists are sorted.  No MFMA: no dense contraction.
+//
+// Exactness: everything that decides the face-index buffer (border test, barycentrics, distance,
+// distance cull, clipped depth, depth cull, K-buffer) reproduces the reference bit for bit.  The
+// colour path (coverage sigmoid, softmax weights) only has to stay within 1e-4 and uses
+// reciprocal multiplies where the reference divides by sigma / gamma (error <= 1-2 ulp).
 #include "jr_kernels.h"
 
 namespace jr {
@@ -65,13 +70,92 @@ struct KBuffer {
     }
 };
 
+template <int KCAP>
+struct PixelState {                 // SRK:291-309
+    float c0, c1, c2, alpha, ssum, smax, depth_min;
+    int face_min;
+    KBuffer<KCAP> q;
+};
+
+// colour of the face at the clipped barycentric point (SRK:156-173)
+template <bool FAST>
+__device__ inline void sample_colour(const RasterParams& p, const FaceRec& r, const float* vc,
+                                     const float* __restrict__ tbase, const Bary& wc, float zp,
+                                     float& k0, float& k1, float& k2) {
+    if (p.tex == 0) {
+        if (p.T == 1) { k0 = r.col[0]; k1 = r.col[1]; k2 = r.col[2]; }
+        else {
+            const float* tx_ = tbase + ((size_t)r.id * p.T + surface_texel(wc, p.R)) * 3;
+            k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
+        }
+    } else {                                                                   // SRK:168-171
+        k0 = ((wc.w0 * vc[0] / r.z[0] + wc.w1 * vc[3] / r.z[1]) + wc.w2 * vc[6] / r.z[2]) * zp;
+        k1 = ((wc.w0 * vc[1] / r.z[0] + wc.w1 * vc[4] / r.z[1]) + wc.w2 * vc[7] / r.z[2]) * zp;
+        k2 = ((wc.w0 * vc[2] / r.z[0] + wc.w1 * vc[5] / r.z[1]) + wc.w2 * vc[8] / r.z[2]) * zp;
+    }
+}
+
+template <int DIST, int RGB, bool FAST, int KCAP>
+__device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
+                                    const float* __restrict__ tbase, float xp, float yp,
+                                    PixelState<KCAP>& s) {
+    const Bary w = barycentric(r, xp, yp);
+    float D;
+    if (DIST == 0) {                                                           // SRK:331-333
+        if (!pixel_inside(w)) return;
+        D = 1.f;
+    } else if (DIST == 1) {                                                    // SRK:335-338
+        const float dis = barycentric_dist(w);
+        if (-dis >= p.thr) return;
+        D = coverage_fast(-dis, p);
+    } else {                                                                   // SRK:340-344
+        const Dist dd = euclidean_p2f(r, w, xp, yp);
+        const float dis = dd.dx * dd.dx + dd.dy * dd.dy;
+        if (dd.sign < 0 && dis >= p.thr) return;
+        D = coverage_fast(-dd.sign * dis, p);
+    }
+    // alpha aggregation happens before the depth cull (SRK:350-358)
+    if (p.alpha == 0) { if (D > 0.5f) s.alpha = 1.f; }
+    else if (p.alpha == 1) s.alpha += D;
+    else s.alpha = (float)((double)s.alpha * (1. - (double)D));
+
+    const Bary wc = barycentric_clip<FAST>(w);
+    const float zp = depth_of<FAST>(r, wc);
+    if (zp < p.near_ || zp > p.far_) return;                                  // SRK:365
+    const int fn = r.id;
+    s.q.insert(fn, zp, p.K);
+
+    if (RGB == 0) {                                                            // SRK:390-397
+        if (zp < s.depth_min && pixel_inside(w) && (p.double_side || (r.flags & FLAG_FRONT))) {
+            s.depth_min = zp; s.face_min = fn;
+            sample_colour<FAST>(p, r, vc, tbase, wc, zp, s.c0, s.c1, s.c2);
+        }
+    } else if (RGB == 1) {                                                     // SRK:399-419
+        if ((r.flags & FLAG_FRONT) || p.double_side) {
+            // zn must carry the reference's exact bits: the softmax divides differences of it by gamma
+            const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
+            float ed = 1.f;
+            if (zn > s.smax) { ed = expf(over_gamma<FAST>(s.smax - zn, p)); s.smax = zn; }
+            const float ez = expf(over_gamma<FAST>(zn - s.smax, p));
+            s.ssum = ed * s.ssum + ez * D;
+            float k0, k1, k2;
+            sample_colour<FAST>(p, r, vc, tbase, wc, zp, k0, k1, k2);
+            s.c0 = ed * s.c0 + ez * D * k0;
+            s.c1 = ed * s.c1 + ez * D * k1;
+            s.c2 = ed * s.c2 + ez * D * k2;
+        }
+    }
+}
+
 template <int DIST, int RGB, int KCAP>
 __global__ __launch_bounds__(64) void k_softras_forward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
     float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
-    __shared__ FaceRec s_rec[CHUNK];
+    extern __shared__ float4 s_dyn[];
+    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
+    float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
 
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a
     // contiguous run of tiles so that the 16 tiles of a bin (same list, same records) share an L2.
@@ -98,16 +182,15 @@ __global__ __launch_bounds__(64) void k_softras_forward(
         yc[c] = pixel_centre(p.IS - 1 - (row0 + c), p.IS);
     }
 
-    // ---- per-pixel state (SRK:291-309) ----
-    float c0 = 1.f, c1 = 1.f, c2 = 1.f;
-    float alpha = p.alpha == 2 ? 1.f : 0.f;
-    float ssum = expf(p.eps / p.gamma), smax = p.eps;
-    if (RGB == 0) { c0 = p.bg[0]; c1 = p.bg[1]; c2 = p.bg[2]; }
-    else if (RGB == 1) { c0 = p.bg[0] * ssum; c1 = p.bg[1] * ssum; c2 = p.bg[2] * ssum; }
-    float depth_min = 10000000.f;
-    int face_min = -1;
-    KBuffer<KCAP> q;
-    q.init();
+    PixelState<KCAP> s;
+    s.c0 = 1.f; s.c1 = 1.f; s.c2 = 1.f;
+    s.alpha = p.alpha == 2 ? 1.f : 0.f;
+    s.ssum = expf(p.eps / p.gamma); s.smax = p.eps;
+    if (RGB == 0) { s.c0 = p.bg[0]; s.c1 = p.bg[1]; s.c2 = p.bg[2]; }
+    else if (RGB == 1) { s.c0 = p.bg[0] * s.ssum; s.c1 = p.bg[1] * s.ssum; s.c2 = p.bg[2] * s.ssum; }
+    s.depth_min = 10000000.f;
+    s.face_min = -1;
+    s.q.init();
 
     const int n = bin_count[bin];
     const unsigned long long* seg = pool + bin_base[bin];
@@ -139,14 +222,11 @@ __global__ __launch_bounds__(64) void k_softras_forward(
             const float4* src = reinterpret_cast<const float4*>(gp);
             float4* dst = reinterpret_cast<float4*>(&s_rec[lane]);
 #pragma unroll
-            for (int k = 0; k < 9; k++) dst[k] = src[k];
-            s_rec[lane].id = fn_f;
-            const float* tx_ = tbase + (size_t)fn_f * p.T * 3;
+            for (int k = 0; k < 11; k++) dst[k] = src[k];
             if (p.tex == 1) {
+                const float* tx_ = tbase + (size_t)fn_f * p.T * 3;
 #pragma unroll
-                for (int k = 0; k < 9; k++) s_rec[lane].col[k] = tx_[k];
-            } else if (p.T == 1) {
-                s_rec[lane].col[0] = tx_[0]; s_rec[lane].col[1] = tx_[1]; s_rec[lane].col[2] = tx_[2];
+                for (int k = 0; k < 9; k++) s_vcol[lane * 9 + k] = tx_[k];
             }
         }
         __syncthreads();
@@ -156,73 +236,12 @@ __global__ __launch_bounds__(64) void k_softras_forward(
         while (M) {
             const int j = __builtin_ctzll(M);
             M &= M - 1;
-            const FaceRec& fr = s_rec[j];
-            const FaceGeo& r = fr.g;
-            const Bary w = barycentric(r, xp, yp);
-            float D;
-            if (DIST == 0) {                                                   // SRK:331-333
-                if (!pixel_inside(w)) continue;
-                D = 1.f;
-            } else if (DIST == 1) {                                            // SRK:335-338
-                const float dis = barycentric_dist(w);
-                if (-dis >= p.thr) continue;
-                D = coverage(-dis / p.sigma);
-            } else {                                                           // SRK:340-344
-                const Dist dd = euclidean_p2f(r, w, xp, yp);
-                const float dis = dd.dx * dd.dx + dd.dy * dd.dy;
-                if (dd.sign < 0 && dis >= p.thr) continue;
-                D = coverage(-dd.sign * dis / p.sigma);
-            }
-            // alpha aggregation happens before the depth cull (SRK:350-358)
-            if (p.alpha == 0) { if (D > 0.5f) alpha = 1.f; }
-            else if (p.alpha == 1) alpha += D;
-            else alpha = (float)((double)alpha * (1. - (double)D));
-
-            const Bary wc = barycentric_clip(w);
-            const float zp = depth_of(r, wc);
-            if (zp < p.near_ || zp > p.far_) continue;                        // SRK:365
-            const int fn = fr.id;
-            q.insert(fn, zp, p.K);
-
-            if (RGB == 0) {                                                    // SRK:390-397
-                if (zp < depth_min && pixel_inside(w) && (p.double_side || r.front)) {
-                    depth_min = zp; face_min = fn;
-                    if (p.tex == 0) {
-                        if (p.T == 1) { c0 = fr.col[0]; c1 = fr.col[1]; c2 = fr.col[2]; }
-                        else {
-                            const float* tx_ = tbase + ((size_t)fn * p.T + surface_texel(wc, p.R)) * 3;
-                            c0 = tx_[0]; c1 = tx_[1]; c2 = tx_[2];
-                        }
-                    } else {                                                   // SRK:168-171
-                        c0 = ((wc.w0 * fr.col[0] / r.z[0] + wc.w1 * fr.col[3] / r.z[1]) + wc.w2 * fr.col[6] / r.z[2]) * zp;
-                        c1 = ((wc.w0 * fr.col[1] / r.z[0] + wc.w1 * fr.col[4] / r.z[1]) + wc.w2 * fr.col[7] / r.z[2]) * zp;
-                        c2 = ((wc.w0 * fr.col[2] / r.z[0] + wc.w1 * fr.col[5] / r.z[1]) + wc.w2 * fr.col[8] / r.z[2]) * zp;
-                    }
-                }
-            } else if (RGB == 1) {                                             // SRK:399-419
-                if (r.front || p.double_side) {
-                    const float zn = (p.far_ - zp) / (p.far_ - p.near_);
-                    float ed = 1.f;
-                    if (zn > smax) { ed = expf((smax - zn) / p.gamma); smax = zn; }
-                    const float ez = expf((zn - smax) / p.gamma);
-                    ssum = ed * ssum + ez * D;
-                    float k0, k1, k2;
-                    if (p.tex == 0) {
-                        if (p.T == 1) { k0 = fr.col[0]; k1 = fr.col[1]; k2 = fr.col[2]; }
-                        else {
-                            const float* tx_ = tbase + ((size_t)fn * p.T + surface_texel(wc, p.R)) * 3;
-                            k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
-                        }
-                    } else {
-                        k0 = ((wc.w0 * fr.col[0] / r.z[0] + wc.w1 * fr.col[3] / r.z[1]) + wc.w2 * fr.col[6] / r.z[2]) * zp;
-                        k1 = ((wc.w0 * fr.col[1] / r.z[0] + wc.w1 * fr.col[4] / r.z[1]) + wc.w2 * fr.col[7] / r.z[2]) * zp;
-                        k2 = ((wc.w0 * fr.col[2] / r.z[0] + wc.w1 * fr.col[5] / r.z[1]) + wc.w2 * fr.col[8] / r.z[2]) * zp;
-                    }
-                    c0 = ed * c0 + ez * D * k0;
-                    c1 = ed * c1 + ez * D * k1;
-                    c2 = ed * c2 + ez * D * k2;
-                }
-            }
+            const FaceRec& r = s_rec[j];
+            const float* vc = s_vcol + j * 9;
+            if ((r.flags & FLAG_SAFE) && p.consts_safe)
+                forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
+            else
+                forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
         }
     }
 
@@ -231,16 +250,16 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     const size_t pp = (size_t)p.IS * p.IS;
     const size_t pn = (size_t)row * p.IS + col;
     float a_out;
-    if (p.alpha == 0) a_out = alpha;
-    else if (p.alpha == 1) a_out = alpha / p.NF;
-    else a_out = (float)(1. - (double)alpha);
+    if (p.alpha == 0) a_out = s.alpha;
+    else if (p.alpha == 1) a_out = s.alpha / p.NF;
+    else a_out = (float)(1. - (double)s.alpha);
     float o0 = p.bg[0], o1 = p.bg[1], o2 = p.bg[2], g0 = 0.f, g1 = 0.f;
     if (RGB == 0) {
-        if (face_min != -1) { o0 = c0; o1 = c1; o2 = c2; }
-        g0 = depth_min; g1 = (float)face_min;
+        if (s.face_min != -1) { o0 = s.c0; o1 = s.c1; o2 = s.c2; }
+        g0 = s.depth_min; g1 = (float)s.face_min;
     } else if (RGB == 1) {
-        o0 = c0 / ssum; o1 = c1 / ssum; o2 = c2 / ssum;
-        g0 = ssum; g1 = smax;
+        o0 = s.c0 / s.ssum; o1 = s.c1 / s.ssum; o2 = s.c2 / s.ssum;
+        g0 = s.ssum; g1 = s.smax;
     }
     float* out = rgba + (size_t)b * 4 * pp + pn;
     out[0] = o0; out[pp] = o1; out[2 * pp] = o2; out[3 * pp] = a_out;
@@ -249,18 +268,19 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     int32_t* io = ids + (size_t)b * p.K * pp + pn;
 #pragma unroll
     for (int k = 0; k < KCAP; k++)
-        if (k < p.K) io[(size_t)k * pp] = q.id[k];
+        if (k < p.K) io[(size_t)k * pp] = s.q.id[k];
 }
 
 template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
     const int grid = ((ntiles + 7) / 8) * 8;
+    const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
     if (p.K <= 16)
-        k_softras_forward<DIST, RGB, 16><<<grid, 64, 0, st>>>(
+        k_softras_forward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_count, ws.bin_base, ws.pool, aggrs, rgba, ids);
     else
-        k_softras_forward<DIST, RGB, 64><<<grid, 64, 0, st>>>(
+        k_softras_forward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_count, ws.bin_base, ws.pool, aggrs, rgba, ids);
 }
 
