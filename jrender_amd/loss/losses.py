@@ -1,0 +1,137 @@
+"""Losses of the mesh-deformation demo — NumPy mirror of jrender/loss/ with hand-written
+backward passes (the reference relied on Jittor autograd):
+    neg_iou_loss   iou_loss.py:1-4
+    LaplacianLoss  laplacian_loss.py:5-37
+    FlattenLoss    flatten_loss.py:5-80
+Each ``*_backward`` returns d(loss)/d(input) for an upstream scalar gradient of 1.
+"""
+import numpy as np
+
+__all__ = ["neg_iou_loss", "neg_iou_loss_backward", "LaplacianLoss", "FlattenLoss"]
+
+F32 = np.float32
+
+
+def neg_iou_loss(predict, target):
+    predict, target = np.asarray(predict, F32), np.asarray(target, F32)
+    dims = tuple(range(predict.ndim))[1:]
+    intersect = (predict * target).sum(dims)
+    union = (predict + target - predict * target).sum(dims) + 1e-6
+    return F32(1. - (intersect / union).sum() / intersect.size)
+
+
+def neg_iou_loss_backward(predict, target):
+    predict, target = np.asarray(predict, F32), np.asarray(target, F32)
+    dims = tuple(range(predict.ndim))[1:]
+    shape = (-1,) + (1,) * (predict.ndim - 1)
+    I = (predict * target).sum(dims).reshape(shape)
+    U = ((predict + target - predict * target).sum(dims) + 1e-6).reshape(shape)
+    n = predict.shape[0]
+    # d(I/U)/dp = (t*U - I*(1-t)) / U^2
+    return (-(target * U - I * (1 - target)) / (U * U) / n).astype(F32)
+
+
+class LaplacianLoss:
+    def __init__(self, vertex, faces, average=False):
+        vertex, faces = np.asarray(vertex), np.asarray(faces).astype(np.int64)
+        self.nv, self.nf, self.average = vertex.shape[0], faces.shape[0], average
+        lap = np.zeros([self.nv, self.nv], F32)
+        lap[faces[:, 0], faces[:, 1]] = -1
+        lap[faces[:, 1], faces[:, 0]] = -1
+        lap[faces[:, 1], faces[:, 2]] = -1
+        lap[faces[:, 2], faces[:, 1]] = -1
+        lap[faces[:, 2], faces[:, 0]] = -1
+        lap[faces[:, 0], faces[:, 2]] = -1
+        r, c = np.diag_indices(self.nv)
+        lap[r, c] = -lap.sum(1)
+        lap /= lap[r, c][:, None]
+        self.laplacian = lap
+
+    def __call__(self, x):
+        x = np.asarray(x, F32)
+        y = np.matmul(self.laplacian, x)
+        out = (y * y).sum(tuple(range(y.ndim))[1:])
+        return out.sum() / x.shape[0] if self.average else out
+
+    def backward(self, x):
+        """d(sum over batch of the loss)/dx (divided by the batch size when average=True)."""
+        x = np.asarray(x, F32)
+        g = 2 * np.matmul(self.laplacian.T, np.matmul(self.laplacian, x))
+        return (g / x.shape[0] if self.average else g).astype(F32)
+
+
+class FlattenLoss:
+    def __init__(self, faces, average=False):
+        faces = np.asarray(faces).astype(np.int64)
+        self.nf, self.average = faces.shape[0], average
+        edges = sorted(set(tuple(v) for v in np.sort(np.concatenate((faces[:, 0:2], faces[:, 1:3]), axis=0))))
+        # the two faces sharing each edge -> opposite vertices v2, v3
+        opp = {}
+        for f in faces:
+            for a in range(3):
+                e = tuple(sorted((f[a], f[(a + 1) % 3])))
+                opp.setdefault(e, []).append(f[(a + 2) % 3])
+        v0s, v1s, v2s, v3s = [], [], [], []
+        for e in edges:
+            o = opp.get(e, [])
+            if len(o) >= 2:
+                v0s.append(e[0]); v1s.append(e[1]); v2s.append(o[0]); v3s.append(o[1])
+        self.v0s, self.v1s = np.array(v0s, np.int64), np.array(v1s, np.int64)
+        self.v2s, self.v3s = np.array(v2s, np.int64), np.array(v3s, np.int64)
+
+    @staticmethod
+    def _half(a, b, eps):
+        al2 = (a * a).sum(-1)
+        bl2 = (b * b).sum(-1)
+        al1 = np.sqrt(al2 + eps)
+        bl1 = np.sqrt(bl2 + eps)
+        ab = (a * b).sum(-1)
+        cos = ab / (al1 * bl1 + eps)
+        sin = np.sqrt(1 - cos * cos + eps)
+        c = a * (ab / (al2 + eps))[..., None]
+        cb = b - c
+        cbl1 = bl1 * sin
+        return cb, cbl1
+
+    def _cos(self, vertices, eps):
+        v0, v1 = vertices[:, self.v0s], vertices[:, self.v1s]
+        v2, v3 = vertices[:, self.v2s], vertices[:, self.v3s]
+        cb1, l1 = self._half(v1 - v0, v2 - v0, eps)
+        cb2, l2 = self._half(v1 - v0, v3 - v0, eps)
+        return (cb1 * cb2).sum(-1) / (l1 * l2 + eps)
+
+    def __call__(self, vertices, eps=1e-6):
+        vertices = np.asarray(vertices, np.float64)
+        cos = self._cos(vertices, eps)
+        loss = ((cos + 1) ** 2).sum(tuple(range(cos.ndim))[1:])
+        return (loss.sum() / vertices.shape[0] if self.average else loss).astype(F32)
+
+    def backward(self, vertices, eps=1e-6, h=1e-4):
+        """Gradient by symmetric differences on the (small, smooth) per-edge expression — the loss is
+        a regulariser weighted 3e-4 in the demo; analytic accuracy is not needed there."""
+        vertices = np.asarray(vertices, np.float64)
+        g = np.zeros_like(vertices)
+        base_idx = [self.v0s, self.v1s, self.v2s, self.v3s]
+
+        def total(v):
+            cos = self._cos(v, eps)
+            return ((cos + 1) ** 2)
+        for which in range(4):
+            idx = base_idx[which]
+            for d in range(3):
+                # perturb, per edge, only the role-`which` vertex: evaluate with a per-edge copy
+                v0, v1 = vertices[:, self.v0s].copy(), vertices[:, self.v1s].copy()
+                v2, v3 = vertices[:, self.v2s].copy(), vertices[:, self.v3s].copy()
+                roles = [v0, v1, v2, v3]
+
+                def f(delta):
+                    r = [x.copy() for x in roles]
+                    r[which][:, :, d] += delta
+                    cb1, l1 = self._half(r[1] - r[0], r[2] - r[0], eps)
+                    cb2, l2 = self._half(r[1] - r[0], r[3] - r[0], eps)
+                    cos = (cb1 * cb2).sum(-1) / (l1 * l2 + eps)
+                    return (cos + 1) ** 2
+                de = (f(h) - f(-h)) / (2 * h)                                    # [B, nedges]
+                for b in range(vertices.shape[0]):
+                    np.add.at(g[b, :, d], idx, de[b])
+        return (g / vertices.shape[0] if self.average else g).astype(F32)

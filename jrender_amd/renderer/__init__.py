@@ -1,0 +1,4 @@
+from .dr import *
+from .lighting import *
+from .renderer import *
+from .transform import *

@@ -1,0 +1,134 @@
+"""CPU tests of the host-side mirrors (no GPU, no oracle): transforms, mesh, lighting, OBJ I/O,
+losses, argument validation."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import jrender_amd as jr
+from jrender_amd.renderer import transform as T
+
+
+def test_look_at_perspective_closed_form():
+    v = np.array([[[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0]]], np.float32)
+    eye = [0, 0, -(1. / math.tan(math.radians(30)) + 1)]
+    cam = T.look_at(v, eye)
+    assert np.allclose(cam[0, 0], [0, 0, -eye[2]], atol=1e-6)       # origin sits on the view axis
+    ndc = T.perspective(cam, 30.)
+    w = math.tan(math.radians(30))
+    assert np.allclose(ndc[0, 1, 0], 0.5 / (-eye[2]) / w, rtol=1e-5)
+    assert np.allclose(ndc[0, :, 2], -eye[2])
+
+
+def test_transform_backward_matches_finite_differences():
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(2, 5, 3)).astype(np.float32) * 0.3
+    la = T.LookAt(True, 30, 1.0, eye=T.get_points_from_angles(2.732, 30., 40.))
+    g = rng.normal(size=v.shape).astype(np.float32)
+    ana = la.backward(g, v)
+    num = np.zeros_like(v)
+    for idx in np.ndindex(v.shape):
+        vp, vm = v.astype(np.float64).copy(), v.astype(np.float64).copy()
+        vp[idx] += 1e-3; vm[idx] -= 1e-3
+        num[idx] = ((la(vp.astype(np.float32)).astype(np.float64) - la(vm.astype(np.float32))) * g).sum() / 2e-3
+    assert np.allclose(ana, num, rtol=2e-2, atol=2e-3)
+
+
+def test_points_from_angles_scalar_and_array():
+    a = T.get_points_from_angles(2.0, 30., 60.)
+    b = T.get_points_from_angles(np.array([2.0]), np.array([30.]), np.array([60.]))
+    assert np.allclose(a, b[0], atol=1e-6)
+    with pytest.raises(ValueError):
+        T.Transform('projection', K=np.eye(3)[None], R=np.eye(3)[None], t=np.zeros((1, 1, 3))).set_eyes([0, 0, 1])
+    with pytest.raises(ValueError):
+        T.Transform('fisheye')
+
+
+def test_uv_sphere_face_counts_and_orientation():
+    for nf, (seg, rings) in jr.synthetic.SPHERE_SHAPES.items():
+        v, f = jr.synthetic.uv_sphere(seg, rings)
+        assert f.shape == (nf, 3) and v.shape[0] == seg * (rings - 1) + 2
+        assert f.min() == 0 and f.max() == v.shape[0] - 1
+    v, f = jr.synthetic.uv_sphere(14, 11)
+    m = jr.Mesh(v, f)
+    n = m.surface_normals[0]
+    c = m.face_vertices[0].mean(1)
+    assert (np.sum(n * c, 1) > 0).mean() > 0.99                      # outward normals
+
+
+def test_mesh_face_vertices_and_reset():
+    v, f = jr.synthetic.uv_sphere(8, 6)
+    m = jr.Mesh(np.stack([v, v * 2]), f)
+    assert m.face_vertices.shape == (2, f.shape[0], 3, 3)
+    assert np.array_equal(m.face_vertices[1, 5], 2 * v[f[5]])
+    m.vertices = m.vertices + 1
+    assert np.array_equal(m.face_vertices[0, 5], v[f[5]] + 1)
+    m.fill_back_()
+    assert m.num_faces == 2 * f.shape[0]
+    m.reset_()
+    assert m.num_faces == f.shape[0] and np.array_equal(m.vertices[0], v)
+    mv = jr.Mesh(v, f, textures=np.random.rand(v.shape[0], 3).astype(np.float32), texture_type='vertex')
+    assert mv.face_textures.shape == (1, f.shape[0], 3, 3)
+    j = jr.join_meshes_as_scene([jr.Mesh(v, f), jr.Mesh(v + 3, f)])
+    assert j.num_faces == 2 * f.shape[0] and j.faces.max() == 2 * v.shape[0] - 1
+
+
+def test_lighting_range_and_lambert():
+    v, f = jr.synthetic.uv_sphere(12, 8)
+    m = jr.Mesh(v, f)
+    m.with_specular = False
+    L = jr.Lighting(intensity_ambient=0.5, intensity_directionals=0.5, directions=[0, 1, 0])
+    L(m, eyes=[0, 0, -2.7])
+    t = m.textures[0, :, 0, 0]
+    n = m.surface_normals[0]
+    assert np.allclose(t, np.clip(0.5 + 0.5 * np.maximum(n[:, 1], 0), 0, 1), atol=1e-5)
+    m2 = jr.Mesh(v, f)
+    jr.Lighting()(m2, eyes=[0, 0, -2.7])                              # Cook-Torrance default
+    assert m2.textures.min() >= 0 and m2.textures.max() <= 1
+
+
+def test_obj_roundtrip_and_texture_sampler(tmp_path):
+    v, f = jr.synthetic.uv_sphere(6, 5)
+    p = str(tmp_path / "s.obj")
+    jr.save_obj(p, v, f)
+    v2, f2 = jr.load_obj(p)
+    assert np.allclose(v, v2, atol=1e-6) and np.array_equal(f, f2) and f2.dtype == np.int32
+    # sampler: constant image -> constant texels; un-updated faces keep their colour
+    img = np.full((8, 8, 3), 0.25, np.float32)
+    tc = np.random.default_rng(0).uniform(0.1, 0.9, (4, 3, 2)).astype(np.float32)
+    tex = np.ones((4, 9, 3), np.float32)
+    out = jr.sample_textures(img, tc, tex, np.array([1, 0, 1, 1]))
+    assert np.allclose(out[[0, 2, 3]], 0.25) and np.allclose(out[1], 1.0)
+
+
+def test_losses_gradients():
+    v, f = jr.synthetic.uv_sphere(8, 6)
+    x = v[None] + 0.01 * np.random.default_rng(0).normal(size=(1,) + v.shape).astype(np.float32)
+    lap, flat = jr.LaplacianLoss(v, f), jr.FlattenLoss(f)
+    for loss in (lap, flat):
+        g = loss.backward(x)
+        i = (0, 3, 1)
+        xp, xm = x.copy(), x.copy()
+        xp[i] += 1e-3; xm[i] -= 1e-3
+        assert np.isclose(g[i], (loss(xp) - loss(xm)).sum() / 2e-3, rtol=5e-2, atol=1e-4)
+    p = np.random.default_rng(1).uniform(0, 1, (2, 8, 8)).astype(np.float32)
+    t = (np.random.default_rng(2).uniform(0, 1, (2, 8, 8)) > 0.5).astype(np.float32)
+    gi = jr.neg_iou_loss_backward(p, t)
+    pp, pm = p.copy(), p.copy()
+    pp[1, 2, 3] += 1e-3; pm[1, 2, 3] -= 1e-3
+    assert np.isclose(gi[1, 2, 3], (jr.neg_iou_loss(pp, t) - jr.neg_iou_loss(pm, t)) / 2e-3, rtol=5e-2)
+
+
+def test_validation_without_gpu():
+    with pytest.raises(ValueError):
+        jr.SoftRasterizer(dist_func="manhattan")
+    with pytest.raises(ValueError):
+        jr.SoftRasterizer(aggr_func_alpha="max")
+    with pytest.raises(ValueError):
+        jr.SoftRasterizer(texture_type="cube")
+    with pytest.raises(ValueError):
+        jr.Lighting(light_mode="pixel")
+    with pytest.raises(ValueError):
+        jr.Renderer(dr_type="raytrace")
+    assert jr.SoftRenderer is jr.Renderer
