@@ -20,20 +20,39 @@
 
 namespace jr {
 
-// Wavefront sum (64 lanes, all active): inclusive DPP scan, total lands in lane 63.
-__device__ inline float wave_sum_to_lane63(float v) {
-    int x;
-#define JR_DPP_ADD(ctrl, rmask)                                                            \
-    x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false); \
-    v += __builtin_bit_cast(float, x);
-    JR_DPP_ADD(0x111, 0xf)  // row_shr:1
-    JR_DPP_ADD(0x112, 0xf)  // row_shr:2
-    JR_DPP_ADD(0x114, 0xf)  // row_shr:4
-    JR_DPP_ADD(0x118, 0xf)  // row_shr:8
-    JR_DPP_ADD(0x142, 0xa)  // row_bcast:15 into rows 1,3
-    JR_DPP_ADD(0x143, 0xc)  // row_bcast:31 into rows 2,3
-#undef JR_DPP_ADD
-    return v;
+// ---- DPP row (16 lanes) primitives; every lane of the wavefront must be active ----------------
+template <int CTRL>
+__device__ inline float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ inline unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// OR of a 64-bit mask over the 16 lanes of each row, result in every lane (row_ror 1,2,4,8)
+__device__ inline unsigned long long row_or(unsigned long long m) {
+    unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+    lo |= dpp_u<0x121>(lo); hi |= dpp_u<0x121>(hi);
+    lo |= dpp_u<0x122>(lo); hi |= dpp_u<0x122>(hi);
+    lo |= dpp_u<0x124>(lo); hi |= dpp_u<0x124>(hi);
+    lo |= dpp_u<0x128>(lo); hi |= dpp_u<0x128>(hi);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Sum of 16 per-lane values over the 16 lanes of a row, "transposed": lane i of the row ends up
+// with the row total of v[i].  Butterfly with halving payload (8+4+2+1 exchanges instead of
+// 16 x 4): partners are row_mirror, row_half_mirror, quad_perm[3,2,1,0], quad_perm[1,0,3,2].
+__device__ inline float row_transpose_reduce(const float (&v)[16], int li) {
+    float a[8], b[4], c[2];
+    const bool h8 = li & 8, h4 = li & 4, h2 = li & 2, h1 = li & 1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = (h8 ? v[j + 8] : v[j]) + dpp_f<0x140>(h8 ? v[j] : v[j + 8]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = (h4 ? a[j + 4] : a[j]) + dpp_f<0x141>(h4 ? a[j] : a[j + 4]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) c[j] = (h2 ? b[j + 2] : b[j]) + dpp_f<0x1B>(h2 ? b[j] : b[j + 2]);
+    return (h1 ? c[1] : c[0]) + dpp_f<0xB1>(h1 ? c[0] : c[1]);
 }
 
 template <int N>
@@ -198,8 +217,10 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
     if (col0 >= p.IS || row0 >= p.IS) return;
 
-    const int lane = threadIdx.x;
-    const int col = col0 + (lane & 7), row = row0 + (lane >> 3);
+    // lane -> pixel: every DPP row (16 lanes) owns one 4x4 block of the 8x8 tile, so that the four
+    // rows of the wavefront can work on four different faces at once and reduce with row-local DPP
+    const int lane = threadIdx.x, li = lane & 15, blk = lane >> 4;
+    const int col = col0 + (blk & 1) * 4 + (li & 3), row = row0 + (blk >> 1) * 4 + (li >> 2);
     const bool valid = col < p.IS && row < p.IS;
     const size_t pp = (size_t)p.IS * p.IS;
     const size_t pn = valid ? (size_t)row * p.IS + col : 0;
@@ -295,16 +316,21 @@ __global__ __launch_bounds__(64) void k_softras_backward(
         }
         __syncthreads();
 
-        // ---- one needed face at a time (wave-uniform): pairs -> wave sum -> one atomic each ----
-        while (need) {
-            const int f = __builtin_ctzll(need);
-            need &= need - 1;
+        // ---- each 16-lane row walks the faces ITS 4x4 block needs (four faces in flight per
+        //      wavefront); pairs -> row-local transpose-reduction -> lane k of the row holds
+        //      component k -> ONE atomic instruction per row and face ----
+        unsigned long long nr = row_or(M);
+        while (ballot(nr != 0ull)) {
+            const bool act = nr != 0ull;                         // uniform within a row
+            const int f = act ? __builtin_ctzll(nr) : 0;
+            nr &= nr - 1;
             const FaceRec& fr = s_rec[f];
-            const bool has = (M >> f) & 1ull;
-            float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // x0 y0 z0 x1 y1 z1 x2 y2 z2
+            const bool has = act && ((M >> f) & 1ull);
+            float v[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float gt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             // check_border is repeated by the reference's backward (SRK:1244)
             if (has && !(xp > fr.xhi || xp < fr.xlo || yp > fr.yhi || yp < fr.ylo)) {
+                float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // x0 y0 z0 x1 y1 z1 x2 y2 z2
                 float tgs;
                 bool tex_on;
                 const float* vc = s_vcol + f * 9;
@@ -317,23 +343,22 @@ __global__ __launch_bounds__(64) void k_softras_backward(
                     atomicAdd(gtx + 1, tgs * px.g1);
                     atomicAdd(gtx + 2, tgs * px.g2);
                 }
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = gv[k];
+                if (ntex == 3) { v[9] = gt[0]; v[10] = gt[1]; v[11] = gt[2]; }
             }
             const int fn = fr.id;
-            float* gf = gfbase + (size_t)fn * 9;
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const float s = wave_sum_to_lane63(gv[k]);
-                if (lane == 63 && s != 0.f) atomicAdd(gf + k, s);            // SRK:1349-1358 does one per pixel
+            const float s = row_transpose_reduce(v, li);         // lane li: component li summed over the row
+            if (act && s != 0.f) {                               // SRK:1349-1358 does one atomic per pixel
+                if (li < 9) atomicAdd(gfbase + (size_t)fn * 9 + li, s);
+                else if (li < 9 + (ntex == 3 ? 3 : 0)) atomicAdd(gtbase + (size_t)fn * p.T * 3 + (li - 9), s);
             }
-            if (ntex) {
-                float* gtx = gtbase + (size_t)fn * p.T * 3;
+            if (ntex == 9) {                                     // vertex colours: 9 more components
+                float u[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    if (k < ntex) {
-                        const float s = wave_sum_to_lane63(gt[k]);
-                        if (lane == 63 && s != 0.f) atomicAdd(gtx + k, s);
-                    }
-                }
+                for (int k = 0; k < 9; k++) u[k] = gt[k];
+                const float st = row_transpose_reduce(u, li);
+                if (act && li < 9 && st != 0.f) atomicAdd(gtbase + (size_t)fn * p.T * 3 + li, st);
             }
         }
     }
