@@ -124,6 +124,31 @@ enum { JR_PHASE_BIN_COUNT = 0, JR_PHASE_BIN_FILL_SORT = 1, JR_PHASE_FWD_RASTER =
 int jr_profile_enable(jr_ctx* ctx, int on);
 int jr_profile_collect(jr_ctx* ctx, double ms[JR_NUM_PHASES], int64_t launches[JR_NUM_PHASES]);
 
+/* ---- NMR ("n3mr") hard rasteriser: replaces the five JIT ops of
+ * jrender/renderer/dr/n3mr/cuda/rasterize.py (forward_face_index_map :5-216, forward_texture_sampling
+ * :219-339, backward_pixel_map :342-648, backward_textures :650-727, backward_depth_map :729-821) and
+ * the host ops between them (background compositing, alpha = face_index >= 0; n3mr.py:135-148).
+ * Layouts are the reference's: faces [B,NF,9]; textures [B,NF,ts,ts,ts,3]; maps are NHWC with
+ * BOTTOM-UP rows (the caller flips / permutes like n3mr.py:240-247): face_index_map [B,IS,IS] i32,
+ * weight_map [B,IS,IS,3], depth_map [B,IS,IS] (= far where empty), face_inv_map [B,IS,IS,9],
+ * rgb_map [B,IS,IS,3] (background already composited), alpha_map [B,IS,IS],
+ * sampling_index_map [B,IS,IS,8] i32, sampling_weight_map [B,IS,IS,8], faces_inv [B,NF,9].
+ * Pointers of maps that the return_* flags switch off may be NULL.  Depth ties resolve to the lowest
+ * face index (deterministic; the reference's spin lock is racy there).  near must be >= 0. */
+int jr_n3mr_forward(jr_ctx* ctx, const float* faces, const float* textures, float* faces_inv,
+                    int32_t* face_index_map, float* weight_map, float* depth_map, float* face_inv_map,
+                    float* rgb_map, float* alpha_map, int32_t* sampling_index_map,
+                    float* sampling_weight_map, int B, int NF, int TS, int IS, float near_, float far_,
+                    float eps, const float* background_rgb, int return_rgb, int return_alpha,
+                    int return_depth);
+int jr_n3mr_backward(jr_ctx* ctx, const float* faces, const int32_t* face_index_map,
+                     const float* weight_map, const float* depth_map, const float* face_inv_map,
+                     const float* rgb_map, const float* alpha_map, const float* sampling_weight_map,
+                     const int32_t* sampling_index_map, const float* grad_rgb_map,
+                     const float* grad_alpha_map, const float* grad_depth_map, float* grad_faces,
+                     float* grad_textures, int B, int NF, int TS, int IS, float eps, int return_rgb,
+                     int return_alpha, int return_depth);
+
 /* ---- self-test of the exact-division identity the kernels rely on (softras_device.h):
  * evaluates n pseudo-random (a, b) pairs on the GPU and counts results of the reciprocal-refinement
  * quotient that differ in any bit from the IEEE quotient a / b.  Must return 0 mismatches. */

@@ -48,6 +48,8 @@ struct jr_ctx {
     float bins_rad = 0.f;
     bool bins_valid = false;
     int64_t stats[4] = {0, 0, 0, 0};
+    unsigned long long* zkey = nullptr;     // n3mr z-buffer keys [B*IS*IS]
+    size_t zkey_cap = 0;
     // optional per-phase HIP-event timing (jr_profile_*): pairs of events bracketing each phase
     bool prof_on = false;
     std::vector<hipEvent_t> prof_events;     // pool, reused after every collect
@@ -221,6 +223,7 @@ int jr_ctx_destroy(jr_ctx* ctx) {
         for (void* p : kv.second) (void)hipFree(p);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     jr::BinWorkspace& ws = ctx->ws;
+    (void)hipFree(ctx->zkey);
     (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor);
     (void)hipFree(ws.counters); (void)hipFree(ws.pool); (void)hipFree(ws.pool_scratch);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
@@ -424,6 +427,55 @@ int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, i
     if (planes < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail("jr_avgpool2x2: H and W must be even");
     JR_HIP(hipSetDevice(ctx->device));
     jr::launch_avgpool2x2_backward(ctx->stream, grad_out, grad_in, planes, H, W);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_n3mr_forward(jr_ctx* ctx, const float* faces, const float* textures, float* faces_inv,
+                    int32_t* face_index_map, float* weight_map, float* depth_map, float* face_inv_map,
+                    float* rgb_map, float* alpha_map, int32_t* sampling_index_map,
+                    float* sampling_weight_map, int B, int NF, int TS, int IS, float near_, float far_,
+                    float eps, const float* background_rgb, int return_rgb, int return_alpha,
+                    int return_depth) {
+    if (!ctx) return fail("jr_n3mr_forward: NULL context");
+    if (!faces || !faces_inv || !face_index_map || !weight_map || !depth_map)
+        return fail("jr_n3mr_forward: NULL tensor pointer");
+    if (B < 1 || NF < 1 || IS < 1) return fail("jr_n3mr_forward: B, NF, image_size must be >= 1");
+    if (return_rgb && (!textures || !rgb_map || !sampling_index_map || !sampling_weight_map || TS < 2))
+        return fail("jr_n3mr_forward: return_rgb needs textures (texture_size >= 2), rgb_map and sampling maps");
+    if (return_alpha && !alpha_map) return fail("jr_n3mr_forward: return_alpha needs alpha_map");
+    if (return_depth && !face_inv_map) return fail("jr_n3mr_forward: return_depth needs face_inv_map");
+    if (!(near_ >= 0.f)) return fail("jr_n3mr_forward: near must be >= 0 (depth keys are ordered by bit pattern)");
+    JR_HIP(hipSetDevice(ctx->device));
+    const size_t P = (size_t)B * IS * IS;
+    if (grow(ctx->zkey, ctx->zkey_cap, P, 1.0)) return 1;
+    jr::launch_n3mr_forward(ctx->stream, faces, textures, faces_inv, ctx->zkey, face_index_map, weight_map,
+                            depth_map, face_inv_map, rgb_map, alpha_map, sampling_index_map,
+                            sampling_weight_map, B, NF, TS, IS, near_, far_, eps, background_rgb, return_rgb,
+                            return_alpha, return_depth);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_n3mr_backward(jr_ctx* ctx, const float* faces, const int32_t* face_index_map,
+                     const float* weight_map, const float* depth_map, const float* face_inv_map,
+                     const float* rgb_map, const float* alpha_map, const float* sampling_weight_map,
+                     const int32_t* sampling_index_map, const float* grad_rgb_map,
+                     const float* grad_alpha_map, const float* grad_depth_map, float* grad_faces,
+                     float* grad_textures, int B, int NF, int TS, int IS, float eps, int return_rgb,
+                     int return_alpha, int return_depth) {
+    if (!ctx) return fail("jr_n3mr_backward: NULL context");
+    if (!faces || !face_index_map || !grad_faces) return fail("jr_n3mr_backward: NULL tensor pointer");
+    if (return_rgb && (!rgb_map || !grad_rgb_map || !grad_textures || !sampling_weight_map || !sampling_index_map))
+        return fail("jr_n3mr_backward: return_rgb needs rgb_map, grad_rgb_map, sampling maps, grad_textures");
+    if (return_alpha && (!alpha_map || !grad_alpha_map)) return fail("jr_n3mr_backward: return_alpha needs alpha maps");
+    if (return_depth && (!depth_map || !face_inv_map || !weight_map || !grad_depth_map))
+        return fail("jr_n3mr_backward: return_depth needs depth / face_inv / weight maps and grad_depth_map");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_n3mr_backward(ctx->stream, faces, face_index_map, weight_map, depth_map, face_inv_map, rgb_map,
+                             alpha_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_alpha_map,
+                             grad_depth_map, grad_faces, grad_textures, B, NF, TS, IS, eps, return_rgb,
+                             return_alpha, return_depth);
     JR_HIP(hipGetLastError());
     return 0;
 }

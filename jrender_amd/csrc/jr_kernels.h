@@ -38,6 +38,17 @@ void launch_face_vertices_backward(hipStream_t st, const float* gfv, const int32
                                    float* gv, int B, int NV, int NF);
 void launch_avgpool2x2_forward(hipStream_t st, const float* in, float* out, int planes, int H, int W);
 void launch_avgpool2x2_backward(hipStream_t st, const float* gout, float* gin, int planes, int H, int W);
+void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textures, float* faces_inv,
+                         unsigned long long* zkey, int32_t* face_index_map, float* weight_map, float* depth_map,
+                         float* face_inv_map, float* rgb_map, float* alpha_map, int32_t* sampling_index_map,
+                         float* sampling_weight_map, int B, int NF, int TS, int IS, float near_, float far_,
+                         float eps, const float* bg, int rrgb, int ralpha, int rdepth);
+void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* face_index_map,
+                          const float* weight_map, const float* depth_map, const float* face_inv_map,
+                          const float* rgb_map, const float* alpha_map, const float* sampling_weight_map,
+                          const int32_t* sampling_index_map, const float* grad_rgb_map, const float* grad_alpha_map,
+                          const float* grad_depth_map, float* grad_faces, float* grad_textures, int B, int NF,
+                          int TS, int IS, float eps, int rrgb, int ralpha, int rdepth);
 void launch_selftest_div(hipStream_t st, unsigned long long n, uint32_t seed, unsigned long long* mismatches);
 
 }  // namespace jr

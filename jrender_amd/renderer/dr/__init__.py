@@ -1,1 +1,2 @@
 from .softras import *
+from .n3mr import *

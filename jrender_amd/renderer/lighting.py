@@ -66,6 +66,9 @@ def directional_lighting(diffuseLight, specularLight, normals, light_intensity=0
         total = metallic_textures.shape[2] * 1.0
         metallic_textures = np.sum(metallic_textures, axis=2) / total
         roughness_textures = np.sum(roughness_textures, axis=2) / total
+    elif with_specular and metallic_textures is not None and metallic_textures.ndim == 6:
+        metallic_textures = metallic_textures.mean(axis=(2, 3, 4))          # n3mr cube textures
+        roughness_textures = roughness_textures.mean(axis=(2, 3, 4))
     if with_specular and eye is not None and positions is not None and metallic_textures is not None \
             and roughness_textures is not None:
         eye = np.asarray(eye, F32)

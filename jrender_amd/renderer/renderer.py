@@ -2,10 +2,10 @@
 
 Same constructor keywords and defaults, ``render_mesh(mesh, mode)``, ``execute(vertices, faces,
 textures, ...)``, ``set_sigma / set_gamma / set_texture_mode``.  ``dr_type='softras'`` drives the
-HIP SoftRas kernels; ``dr_type='n3mr'`` is recognised but not part of this round's accelerated path.
+HIP SoftRas kernels, ``dr_type='n3mr'`` the HIP NMR kernels (with NMR's own near/far/eps, REN:46).
 """
 from ..structures import Mesh
-from .dr import SoftRasterizer
+from .dr import N3mrRasterizer, SoftRasterizer
 from .lighting import Lighting
 from .transform import Transform
 
@@ -35,7 +35,7 @@ class Renderer:
                                              aggr_func_rgb, aggr_func_alpha, texture_type, bin_size,
                                              max_elems_per_bin, max_faces_per_pixel_for_grad)
         elif dr_type == 'n3mr':
-            raise NotImplementedError("dr_type='n3mr' (NMR hard rasteriser) is not built yet; see DESIGN.md")
+            self.rasterizer = N3mrRasterizer(image_size, anti_aliasing, background_color, fill_back)   # REN:46
         else:
             raise ValueError("dr_type should be one of None, 'softras' or 'n3mr'")
 

@@ -204,3 +204,70 @@ class Oracle:
         if rc:
             raise RuntimeError("oracle backward_subset failed rc=%d" % rc)
         return gf.reshape(B, NF, 3, 3), gt
+
+
+class N3mrOracle:
+    """The reference's NMR kernels compiled for the host (oracle/_ref/libn3mr_ref.so, serial).
+    Layouts are the reference's op-level ones (NHWC, bottom-up rows); background compositing and
+    alpha are the host ops of n3mr.py:135-148, restated in NumPy."""
+
+    def __init__(self):
+        import importlib
+        path = importlib.import_module(__name__ + ".build_ref").build_n3mr()
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("oracle/_ref/libn3mr_ref.so not built and /root/reference not mounted")
+        self.lib = C.CDLL(path)
+
+    def forward(self, faces, textures=None, image_size=256, near=0.1, far=100, eps=1e-3,
+                background_color=(0, 0, 0), return_rgb=True, return_alpha=True, return_depth=True):
+        f = np.ascontiguousarray(faces, np.float32)
+        B, NF = f.shape[:2]
+        f = f.reshape(B, NF, 9)
+        IS = int(image_size)
+        tex = np.ascontiguousarray(textures, np.float32) if return_rgb else np.zeros(1, np.float32)
+        TS = tex.shape[2] if return_rgb else 0
+        faces_inv = np.zeros((B, NF, 9), np.float32)
+        fim = np.empty((B, IS, IS), np.int32)
+        wm = np.empty((B, IS, IS, 3), np.float32)
+        dm = np.empty((B, IS, IS), np.float32)
+        fivm = np.zeros((B, IS, IS, 9), np.float32)
+        rgb = np.zeros((B, IS, IS, 3), np.float32)
+        sidx = np.zeros((B, IS, IS, 8), np.int32)
+        swt = np.zeros((B, IS, IS, 8), np.float32)
+        f32 = lambda v: C.c_float(float(np.float32(v)))
+        rc = self.lib.ref_n3mr_forward(_fp(f), _fp(tex), _fp(faces_inv), _ip(fim), _fp(wm), _fp(dm), _fp(fivm),
+                                       _fp(rgb), _ip(sidx), _fp(swt), B, NF, TS, IS, f32(near), f32(far), f32(eps),
+                                       int(return_rgb), int(return_depth))
+        if rc:
+            raise RuntimeError("n3mr reference forward failed rc=%d (image size not instantiated?)" % rc)
+        mask = (fim >= 0).astype(np.float32)
+        if return_rgb:                                                                       # n3mr.py:135-143
+            bg = np.asarray(background_color, np.float32)
+            rgb = rgb * mask[..., None] + (1 - mask[..., None]) * bg[None, None, None]
+        return dict(faces=f, textures=tex, face_index_map=fim, weight_map=wm, depth_map=dm, face_inv_map=fivm,
+                    rgb_map=rgb.astype(np.float32), alpha_map=mask, sampling_index_map=sidx,
+                    sampling_weight_map=swt, faces_inv=faces_inv,
+                    params=dict(image_size=IS, eps=eps, return_rgb=return_rgb, return_alpha=return_alpha,
+                                return_depth=return_depth, TS=TS))
+
+    def backward(self, s, grad_rgb=None, grad_alpha=None, grad_depth=None):
+        p = s["params"]
+        f = s["faces"]
+        B, NF = f.shape[:2]
+        IS, TS = p["image_size"], p["TS"]
+        z = lambda like: np.zeros(like.shape, np.float32)
+        g_rgb = np.ascontiguousarray(grad_rgb, np.float32) if grad_rgb is not None else z(s["rgb_map"])
+        g_a = np.ascontiguousarray(grad_alpha, np.float32) if grad_alpha is not None else z(s["alpha_map"])
+        g_d = np.ascontiguousarray(grad_depth, np.float32) if grad_depth is not None else z(s["depth_map"])
+        gf = np.empty((B, NF, 9), np.float32)
+        gt = np.zeros((B, NF, max(TS, 1), max(TS, 1), max(TS, 1), 3), np.float32)
+        f32 = lambda v: C.c_float(float(np.float32(v)))
+        rc = self.lib.ref_n3mr_backward(_fp(f), _ip(s["face_index_map"]), _fp(s["weight_map"]), _fp(s["depth_map"]),
+                                        _fp(s["face_inv_map"]), _fp(np.ascontiguousarray(s["rgb_map"])),
+                                        _fp(s["alpha_map"]), _fp(s["sampling_weight_map"]),
+                                        _ip(s["sampling_index_map"]), _fp(g_rgb), _fp(g_a), _fp(g_d), _fp(gf),
+                                        _fp(gt), B, NF, TS, IS, f32(p["eps"]), int(p["return_rgb"]),
+                                        int(p["return_alpha"]), int(p["return_depth"]))
+        if rc:
+            raise RuntimeError("n3mr reference backward failed rc=%d" % rc)
+        return gf.reshape(B, NF, 3, 3), gt

@@ -34,6 +34,8 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_ROOT = os.environ.get("JRENDER_REFERENCE", "/root/reference")
 SRK = os.path.join(REF_ROOT, "jrender/renderer/dr/softras/cuda/soft_rasterize.py")
+N3K = os.path.join(REF_ROOT, "jrender/renderer/dr/n3mr/cuda/rasterize.py")
+N3_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libn3mr_ref.so")
 OUT_DIR = os.path.join(HERE, "_ref")
 LIB = os.path.join(OUT_DIR, "libsoftras_ref.so")
 
@@ -83,6 +85,66 @@ def _extract():
     return fwd, bwd
 
 
+def _extract_n3mr():
+    """The five `cuda_header` strings of the NMR ops (N3K), same stub-jittor recipe."""
+    captured = []
+    stub = types.ModuleType("jittor")
+
+    def code(*args, **kw):
+        captured.append(kw)
+        shapes = args[0] if args and isinstance(args[0], (list, tuple)) and args[0] and isinstance(args[0][0], tuple) else [(1,)]
+        return [_Var(s) for s in shapes] if isinstance(shapes, list) else _Var(shapes)
+
+    stub.code = code
+    stub.empty = lambda shape, dtype="float32": _Var(shape, dtype)
+    saved = sys.modules.get("jittor")
+    sys.modules["jittor"] = stub
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_n3k", N3K)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        B, NF, IS, TS = 1, 1, 4, 2
+        faces = _Var((B, NF, 3, 3))
+        m1, m3, m8, m9 = _Var((B, IS, IS), "int32"), _Var((B, IS, IS, 3)), _Var((B, IS, IS, 8)), _Var((B, IS, IS, 3, 3))
+        tex = _Var((B, NF, TS, TS, TS, 3))
+        mod.forward_face_index_map(faces, m1, m3, m1, m9, faces, IS, 0.1, 100, 1, 1, 1)
+        mod.forward_texture_sampling(faces, tex, m1, m3, m1, m3, m8, m8, IS, 1e-3)
+        mod.backward_pixel_map(faces, m1, m3, m1, m3, m1, faces, IS, 1e-3, 1, 1)
+        mod.backward_textures(m1, m8, m8, m3, tex, NF)
+        mod.backward_depth_map(faces, m1, m1, m9, m3, m1, faces, IS)
+    finally:
+        if saved is None:
+            del sys.modules["jittor"]
+        else:
+            sys.modules["jittor"] = saved
+    if len(captured) != 5:
+        raise RuntimeError("expected 5 jt.code sites in the n3mr kernels, got %d" % len(captured))
+    return [c["cuda_header"] for c in captured]
+
+
+def build_n3mr(force=False):
+    """Build (or reuse) oracle/_ref/libn3mr_ref.so; None when the reference tree is not mounted."""
+    if not os.path.exists(N3K):
+        return N3_LIB if os.path.exists(N3_LIB) else None
+    deps = [N3K, os.path.join(HERE, "ref_n3mr_driver.cpp"), os.path.join(HERE, "ref_shim/cuda_runtime.h"),
+            os.path.abspath(__file__)]
+    if (not force and os.path.exists(N3_LIB)
+            and os.path.getmtime(N3_LIB) >= max(os.path.getmtime(d) for d in deps)):
+        return N3_LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    names = ["n3k_fwd_index", "n3k_fwd_tex", "n3k_bwd_pix", "n3k_bwd_tex", "n3k_bwd_depth"]
+    for name, src in zip(names, _extract_n3mr()):
+        with open(os.path.join(OUT_DIR, name + ".inc"), "w") as f:
+            f.write(src)
+    tmp = tempfile.mktemp(suffix=".so", dir=OUT_DIR)
+    flags = [f for f in CXXFLAGS if f != "-fopenmp"]
+    cmd = ["g++", *flags, "-I", HERE, "-I", os.path.join(HERE, "ref_shim"),
+           os.path.join(HERE, "ref_n3mr_driver.cpp"), "-o", tmp]
+    subprocess.check_call(cmd, cwd=HERE)
+    os.replace(tmp, N3_LIB)
+    return N3_LIB
+
+
 def build(force=False):
     """Build (or reuse) oracle/_ref/libsoftras_ref.so.  Returns its path, or
     None when the reference tree is not mounted (e.g. on the GPU box)."""
@@ -109,3 +171,4 @@ def build(force=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_n3mr(force="--force" in sys.argv))
