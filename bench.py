@@ -68,8 +68,47 @@ def cpu_baseline(NF, K, budget_s=20.0):
                       "scaled by pixel count to 1024x1024" % (NF, IS, IS, t, cores)}
 
 
+def bench_n3mr(args):
+    """Secondary workload (BASELINE.json configs[4]): NMR hard raster + approximate gradients,
+    39k-face sphere with fill_back (78k faces), 1024x1024, B=1, fwd+bwd on one GPU.  Not the headline
+    metric; prints its own JSON line when called with --workload n3mr."""
+    from jrender_amd import _ffi
+    import jrender_amd as jr
+    from jrender_amd.renderer.dr.n3mr import RasterizeFunction
+    ctx = _ffi.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    IS, B, ts = args.image_size, 1, 2
+    v, f = jr.synthetic.sphere_mesh(args.faces)
+    eye = np.asarray(jr.get_points_from_angles(2.732, 30., 0.), np.float32)
+    ndc = jr.perspective(jr.look_at(v[None], eye), 30.)
+    ff = np.concatenate([f, f[:, ::-1]])
+    faces = ctx.array(np.ascontiguousarray(ndc[:, ff]))
+    tex = ctx.array(np.random.default_rng(0).uniform(0, 1, (B, ff.shape[0], ts, ts, ts, 3)).astype(np.float32))
+    rng = np.random.default_rng(1)
+    g_rgb = ctx.array(rng.uniform(-1, 1, (B, IS, IS, 3)).astype(np.float32))
+    g_a = ctx.array(rng.uniform(-1, 1, (B, IS, IS)).astype(np.float32))
+    g_d = ctx.array(rng.uniform(-1, 1, (B, IS, IS)).astype(np.float32))
+    fn = RasterizeFunction(IS, 0.1, 100, 1e-3, (0, 0, 0), True, True, True, ctx=ctx)
+
+    def step():
+        fn.execute(faces, tex)
+        fn.grad(g_rgb, g_a, g_d)
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    print(json.dumps({"metric": "NMR fwd+bwd ms @%dx%d, %d faces (fill_back x2)" % (IS, IS, args.faces),
+                      "value": ms, "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": ms, "higher_is_better": False, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "n3mr rgb+alpha+depth, texture_size 2, batch 1"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="softras", choices=["softras", "n3mr"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -79,6 +118,8 @@ def main():
     ap.add_argument("--K", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "n3mr":
+        return bench_n3mr(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
