@@ -129,8 +129,13 @@ def main():
         # torch is plumbing here: process-group rendezvous, barrier and the max-over-ranks reduction
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if ndev >= world:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:       # fewer GPUs than ranks (plumbing test on a 1-GPU box): ranks share GPUs, gloo carries the control traffic
+            dist.init_process_group("gloo")
+            local_rank = local_rank % max(ndev, 1)
 
     from jrender_amd import _ffi, synthetic as syn
     from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
@@ -167,7 +172,8 @@ def main():
     ctx.profile_enable(False)
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
