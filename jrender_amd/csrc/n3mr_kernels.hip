@@ -174,9 +174,11 @@ __global__ __launch_bounds__(256) void k_n3mr_resolve(
     for (int k = 0; k < 8; k++) { sampling_index_map[8 * i + k] = sidx[k]; sampling_weight_map[8 * i + k] = swt[k]; }
 }
 
-// NMR's approximate image gradient (N3K:352-610): one wavefront per face, lanes over the scan
-// positions d0 crossed by the current edge; per-lane partial gradients are summed at the end and
-// stored once per face (no atomics, like the reference).
+// NMR's approximate image gradient (N3K:352-610): one wavefront per face.  The scan positions d0
+// crossed by an edge are few, but each one walks up to image_size pixels towards the image border
+// (N3K:450-507) — so the wavefront takes the d0 one after the other and spreads the PIXEL WALK over
+// its 64 lanes (coalesced along rows for axis 1).  Per-lane partial gradients are summed at the end
+// and stored once per face (no atomics, like the reference).
 __global__ __launch_bounds__(256) void k_n3mr_backward_pixel_map(
     N3Params p, const float* __restrict__ faces, const int32_t* __restrict__ face_index_map,
     const float* __restrict__ rgb_map, const float* __restrict__ alpha_map,
@@ -207,8 +209,7 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_pixel_map(
             else direction = q[0][0] < q[1][0] ? 1 : -1;
             const int d0_from = (int)fmax((double)ceilf(fminf(q[0][0], q[1][0])), 0.);
             const int d0_to = (int)fmin((double)fmaxf(q[0][0], q[1][0]), is - 1.);
-            const int moff = axis == 0 ? is : 1;
-            for (int d0 = d0_from + lane; d0 <= d0_to; d0 += 64) {
+            for (int d0 = d0_from; d0 <= d0_to; d0++) {          // wave-uniform
                 const float d1_cross = (q[1][1] - q[0][1]) / (q[1][0] - q[0][0]) * (d0 - q[0][0]) + q[0][1];
                 const int d1_in = 0 < direction ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
                 const int d1_out = d1_in + direction;
@@ -239,8 +240,8 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_pixel_map(
                 if (face_index_map[idx_in] == fn) {
                     const int d1_limit = 0 < direction ? is - 1 : 0;
                     const int d1_from = max(min(d1_out, d1_limit), 0), d1_to = min(max(d1_out, d1_limit), is - 1);
-                    size_t m = axis == 0 ? mbase + (size_t)d1_from * is + d0 : mbase + (size_t)d0 * is + d1_from;
-                    for (int d1 = d1_from; d1 <= d1_to; d1++, m += moff) {
+                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += 64) {
+                        const size_t m = axis == 0 ? mbase + (size_t)d1 * is + d0 : mbase + (size_t)d0 * is + d1;
                         float diff = 0;
                         if (use_a) diff += (alpha_map[m] - a_in) * grad_alpha_map[m];
                         if (use_rgb)
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_pixel_map(
                         cross2 = (q[1][1] - q[2][1]) / (q[1][0] - q[2][0]) * (d0 - q[2][0]) + q[2][1];
                     const int d1_limit = 0 < direction ? (int)ceilf(cross2) : (int)floorf(cross2);
                     const int d1_from = max(min(d1_in, d1_limit), 0), d1_to = min(max(d1_in, d1_limit), is - 1);
-                    size_t m = axis == 0 ? mbase + (size_t)d1_from * is + d0 : mbase + (size_t)d0 * is + d1_from;
-                    for (int d1 = d1_from; d1 <= d1_to; d1++, m += moff) {
+                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += 64) {
+                        const size_t m = axis == 0 ? mbase + (size_t)d1 * is + d0 : mbase + (size_t)d0 * is + d1;
                         if (face_index_map[m] != fn) continue;
                         float diff = 0;
                         if (use_a) diff += (alpha_map[m] - a_out) * grad_alpha_map[m];
