@@ -105,7 +105,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     if (DIST == 0) D = 1.f;                                               // SRK:1258-1270
     else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_fast(-dis, p); }
     else {
-        dd = euclidean_p2f(r, w, xp, yp);
+        dd = euclidean_p2f<FAST>(r, w, xp, yp);
         dis = dd.dx * dd.dx + dd.dy * dd.dy;
         D = coverage_fast(-dd.sign * dis, p);
     }
@@ -122,7 +122,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
         if ((float)fn == px.smax) { tgs = 1.f; tex_on = true; }
     } else if (RGB == 1) {                                                // SRK:1308-1332
         const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
-        const float zs = D * expf(over_gamma<FAST>(zn - px.smax, p)) * px.r_ssum;
+        const float zs = D * fast_exp(over_gamma<FAST>(zn - px.smax, p)) * px.r_ssum;
         tgs = zs; tex_on = true;
         float k0, k1, k2;
         if (p.tex == 0) {

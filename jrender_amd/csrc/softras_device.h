@@ -170,20 +170,39 @@ __device__ inline bool pixel_inside(const Bary& b) {                            
     return b.w0 <= 1 && b.w0 >= 0 && b.w1 <= 1 && b.w1 >= 0 && b.w2 <= 1 && b.w2 >= 0;
 }
 
+// Instruction costs measured on MI355X (tools/ubench/valu_rates.hip, cycles per wave-instruction):
+// v_mul/v_add/v_fma 2 | v_cmp, v_cndmask, v_min, v_max 4 | f64 4-5 | v_rcp/v_exp 8 | IEEE a/b 45.
+// The code below is written against those prices: no select chains where an LDS-indexed read
+// does the job, v_med3 for clamps, Newton-refined v_rcp where it is PROVEN equal to the IEEE
+// reciprocal, refinement quotients where the divisor's exact reciprocal is known.
+
+// IEEE 1.0f/x from v_rcp_f32 + one Newton step.  Verified EXHAUSTIVELY equal to the correctly
+// rounded quotient for every float with exponent in [-40, 40] (tools/ubench/rcp_exact.hip and
+// jr_selftest_reciprocal: 1.36e9 values, 0 mismatches).  12 cycles instead of 45.
+__device__ inline float recip_exact(float x) {
+    const float y = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, y, 1.f), y, y);
+}
+
 // max(min(v, 1.), 0.) / min(max(v, 0.), 1.): the reference evaluates these in double because of
-// the bare literals; both are exact selections, so the float form returns the same value
-// (NaN -> 1 resp. 0 in both, like CUDA's fmin/fmax; only the sign of a zero may differ, which
-// nothing downstream observes).
-__device__ inline float clamp01(float v) { return fmaxf(fminf(v, 1.f), 0.f); }           // SRK:51
-__device__ inline float clamp01_maxfirst(float v) { return fminf(fmaxf(v, 0.f), 1.f); }  // SRK:138
+// the bare literals; both are exact selections, so the float form returns the same value.  For
+// non-NaN input both equal the median of (v, 0, 1) = one v_med3_f32; NaN input (only possible for
+// degenerate faces, which are never flagged FAST) keeps the two-instruction form, which matches
+// CUDA's fmin/fmax NaN behaviour.  Only the sign of a zero may differ, which nothing observes.
+template <bool FAST> __device__ inline float clamp01(float v) {                          // SRK:51
+    return FAST ? __builtin_amdgcn_fmed3f(v, 0.f, 1.f) : fmaxf(fminf(v, 1.f), 0.f);
+}
+template <bool FAST> __device__ inline float clamp01_maxfirst(float v) {                 // SRK:138
+    return FAST ? __builtin_amdgcn_fmed3f(v, 0.f, 1.f) : fminf(fmaxf(v, 0.f), 1.f);
+}
 
 template <bool FAST>
 __device__ inline Bary barycentric_clip(Bary b) {                                    // SRK:49-54
-    b.w0 = clamp01(b.w0); b.w1 = clamp01(b.w1); b.w2 = clamp01(b.w2);
+    b.w0 = clamp01<FAST>(b.w0); b.w1 = clamp01<FAST>(b.w1); b.w2 = clamp01<FAST>(b.w2);
     // max(w_sum, 1e-5) compares in double and stores (float)1e-5 when clamped == fmaxf(s, 1e-5f)
     const float s = fmaxf((b.w0 + b.w1) + b.w2, 1e-5f);
-    // three quotients by the same divisor s in [1e-5, 3]: one true reciprocal, three refinements
-    const float rs = FAST ? 1.0f / s : 0.f;
+    // three quotients by the same divisor s in [1e-5, 3]: one exact reciprocal, three refinements
+    const float rs = FAST ? recip_exact(s) : 0.f;
     b.w0 = div_known<FAST>(b.w0, s, rs);
     b.w1 = div_known<FAST>(b.w1, s, rs);
     b.w2 = div_known<FAST>(b.w2, s, rs);
@@ -193,11 +212,11 @@ __device__ inline Bary barycentric_clip(Bary b) {                               
 // depth of the clipped barycentric point, 1./(sum w/z) (SRK:364, :1296).  The reference divides in
 // double and rounds to float; for a float divisor that equals the correctly rounded float quotient
 // (53 >= 2*24+2 bits: double rounding is innocuous for division), i.e. IEEE 1.0f/s.
-// The clipped weights are 0 or >= 2^-24-ish multiples, well inside the fast-division range.
 template <bool FAST>
 __device__ inline float depth_of(const FaceGeo& r, const Bary& c) {
     const float s = (div_known<FAST>(c.w0, r.z[0], r.rz[0]) + div_known<FAST>(c.w1, r.z[1], r.rz[1])) +
                     div_known<FAST>(c.w2, r.z[2], r.rz[2]);
+    if (FAST && in_fast_range(s)) return recip_exact(s);     // s == 0 (all weights clipped) etc. -> IEEE path
     return 1.0f / s;
 }
 
@@ -208,35 +227,25 @@ struct Dist {
 
 // Projection of the pixel onto edge e (vertices e, e+1): t along the edge, the point's barycentric
 // coordinates minus w, the offset to the pixel and its squared length (SRK:73-92 / :123-144).
-// CLAMP selects the outside-the-triangle variant (t clamped to the segment, SRK:137-140).
+// `clamp` selects the outside-the-triangle variant (t clamped to the segment, SRK:137-140).
+// `r` refers to an LDS record: a per-lane edge index is an LDS address, not a select chain.
 struct EdgeCand { float u0, u1, u2, ex, ey, dd; };
 
-template <bool STATIC_E, int E>
-__device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e_dyn, bool clamp) {
-    float a0, a1, a2, av1, dn;
-    int e;
-    if (STATIC_E) {
-        e = E;
-        a0 = r.A[3 * E]; a1 = r.A[3 * E + 1]; a2 = r.A[3 * E + 2];
-        av1 = r.A[3 * E + (E + 1) % 3];
-        dn = r.Dn[E];
-    } else {
-        e = e_dyn;
-        a0 = e == 0 ? r.A[0] : (e == 1 ? r.A[3] : r.A[6]);
-        a1 = e == 0 ? r.A[1] : (e == 1 ? r.A[4] : r.A[7]);
-        a2 = e == 0 ? r.A[2] : (e == 1 ? r.A[5] : r.A[8]);
-        av1 = e == 0 ? a1 : (e == 1 ? a2 : a0);
-        dn = e == 0 ? r.Dn[0] : (e == 1 ? r.Dn[1] : r.Dn[2]);
-    }
+template <bool FAST>
+__device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e, bool clamp) {
+    const int e1 = e == 2 ? 0 : e + 1;
+    const float a0 = r.A[3 * e], a1 = r.A[3 * e + 1], a2 = r.A[3 * e + 2];
+    const float av1 = r.A[3 * e + e1];
+    const float dn = r.Dn[e];
     // the numerator can be a rounding crumb (pixel projecting exactly onto a vertex), which is
-    // outside the fast-division guarantee: plain IEEE division here
+    // outside the refinement-division guarantee: plain IEEE division here
     const float tv = (((b.w0 * a0 + b.w1 * a1) + b.w2 * a2) - av1) / dn;                 // SRK:81 / :132
     const float tn = 1 - tv;
     // t[e] = tv, t[e+1] = 1 - tv, t[e+2] = 0 (indices mod 3)
     float u0 = e == 0 ? tv : (e == 2 ? tn : 0.f);
     float u1 = e == 1 ? tv : (e == 0 ? tn : 0.f);
     float u2 = e == 2 ? tv : (e == 1 ? tn : 0.f);
-    if (clamp) { u0 = clamp01_maxfirst(u0); u1 = clamp01_maxfirst(u1); u2 = clamp01_maxfirst(u2); }
+    if (clamp) { u0 = clamp01_maxfirst<FAST>(u0); u1 = clamp01_maxfirst<FAST>(u1); u2 = clamp01_maxfirst<FAST>(u2); }
     EdgeCand c;
     c.u0 = u0 - b.w0; c.u1 = u1 - b.w1; c.u2 = u2 - b.w2;
     c.ex = (c.u0 * r.x0 + c.u1 * r.x1) + c.u2 * r.x2;
@@ -249,32 +258,38 @@ __device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e
 // projections, keep the nearest) and the outside case (one edge chosen from the sign pattern of
 // w, clamped) share the first projection so that a wavefront with both kinds of pixels does not
 // execute two separate code paths; the two further projections run only if some lane is inside.
+template <bool FAST>
 __device__ inline Dist euclidean_p2f(const FaceGeo& r, const Bary& b, float xp, float yp) {
     const bool inside = b.w0 > 0 && b.w1 > 0 && b.w2 > 0 && b.w0 < 1 && b.w1 < 1 && b.w2 < 1;
-    int v0 = -1;                                                                      // SRK:107-121
-    if (b.w1 <= 0 && b.w2 <= 0) {
-        v0 = 0;
-        if (r.obt == 0 && (xp - r.x0) * (r.x2 - r.x0) + (yp - r.y0) * (r.y2 - r.y0) > 0) v0 = 2;
-    } else if (b.w2 <= 0 && b.w0 <= 0) {
-        v0 = 1;
-        if (r.obt == 1 && (xp - r.x1) * (r.x0 - r.x1) + (yp - r.y1) * (r.y0 - r.y1) > 0) v0 = 0;
-    } else if (b.w0 <= 0 && b.w1 <= 0) {
-        v0 = 2;
-        if (r.obt == 2 && (xp - r.x2) * (r.x1 - r.x2) + (yp - r.y2) * (r.y1 - r.y2) > 0) v0 = 1;
-    } else if (b.w0 <= 0) v0 = 1;
-    else if (b.w1 <= 0) v0 = 2;
-    else if (b.w2 <= 0) v0 = 0;
-
+    // SRK:107-121: two non-positive weights -> the vertex region `corner` (edge = corner, unless the
+    // vertex is the obtuse one and the pixel lies beyond it: then the previous edge); one -> that edge
+    const bool n0 = b.w0 <= 0, n1 = b.w1 <= 0, n2 = b.w2 <= 0;
+    int v0 = -1, corner = -1;
+    if (n1 && n2) corner = 0;
+    else if (n2 && n0) corner = 1;
+    else if (n0 && n1) corner = 2;
+    else if (n0) v0 = 1;
+    else if (n1) v0 = 2;
+    else if (n2) v0 = 0;
+    if (corner >= 0) {
+        v0 = corner;
+        if (r.obt == corner) {                       // rare: obtuse vertex region
+            const int other = corner == 0 ? 2 : corner - 1;
+            const float* xy = &r.x0;
+            const float xc = xy[2 * corner], yc = xy[2 * corner + 1];
+            if ((xp - xc) * (xy[2 * other] - xc) + (yp - yc) * (xy[2 * other + 1] - yc) > 0) v0 = other;
+        }
+    }
     Dist d;
-    const EdgeCand c = edge_candidate<false, 0>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
+    const EdgeCand c = edge_candidate<FAST>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
     if (inside) {
         // SRK:68-105: dis_min starts at 1e8, strict '<' keeps the first of equal candidates
         float best = 100000000.f;
         d.dx = 0.f; d.dy = 0.f; d.t0 = 0.f; d.t1 = 0.f; d.t2 = 0.f;
         if (c.dd < best) { best = c.dd; d.dx = c.ex; d.dy = c.ey; d.t0 = c.u0; d.t1 = c.u1; d.t2 = c.u2; }
-        const EdgeCand c1 = edge_candidate<true, 1>(r, b, 1, false);
+        const EdgeCand c1 = edge_candidate<FAST>(r, b, 1, false);
         if (c1.dd < best) { best = c1.dd; d.dx = c1.ex; d.dy = c1.ey; d.t0 = c1.u0; d.t1 = c1.u1; d.t2 = c1.u2; }
-        const EdgeCand c2 = edge_candidate<true, 2>(r, b, 2, false);
+        const EdgeCand c2 = edge_candidate<FAST>(r, b, 2, false);
         if (c2.dd < best) { best = c2.dd; d.dx = c2.ex; d.dy = c2.ey; d.t0 = c2.u0; d.t1 = c2.u1; d.t2 = c2.u2; }
         d.sign = 1.f;
     } else if (v0 < 0) {
@@ -293,7 +308,10 @@ __device__ inline float barycentric_dist(const Bary& b) {                       
 }
 
 // ---- colour path (1e-4 tolerance, not bit-critical: nothing here feeds the face-index buffer) ----
-// x / sigma and x / gamma as reciprocal multiplies (<= 1 ulp off the IEEE quotient)
+// exp(x) as v_exp_f32(x * log2 e): relative error ~ 1.2e-7 * (1 + |x|), i.e. < 3e-6 for every
+// argument whose result is not negligible (|x| < 20); libm's expf costs 3x more.
+__device__ inline float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+// x / sigma as a reciprocal multiply (<= 1 ulp off the IEEE quotient)
 __device__ inline float over_sigma(float x, const RasterParams& p) {
     return p.consts_safe ? x * p.r_sigma : x / p.sigma;
 }
@@ -306,7 +324,7 @@ __device__ inline float over_gamma(float x, const RasterParams& p) {
 }
 // sigmoid coverage 1/(1+exp(neg_num/sigma)) (SRK:338, :344; the reference adds and divides in double)
 __device__ inline float coverage_fast(float neg_num, const RasterParams& p) {
-    return __builtin_amdgcn_rcpf(1.0f + expf(over_sigma(neg_num, p)));
+    return __builtin_amdgcn_rcpf(1.0f + fast_exp(over_sigma(neg_num, p)));
 }
 
 // 'surface' sampler texel choice (SRK:159-166, identical in SRK:1138-1145)

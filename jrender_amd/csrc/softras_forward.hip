@@ -109,7 +109,7 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
         if (-dis >= p.thr) return;
         D = coverage_fast(-dis, p);
     } else {                                                                   // SRK:340-344
-        const Dist dd = euclidean_p2f(r, w, xp, yp);
+        const Dist dd = euclidean_p2f<FAST>(r, w, xp, yp);
         const float dis = dd.dx * dd.dx + dd.dy * dd.dy;
         if (dd.sign < 0 && dis >= p.thr) return;
         D = coverage_fast(-dd.sign * dis, p);
@@ -135,8 +135,8 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
             // zn must carry the reference's exact bits: the softmax divides differences of it by gamma
             const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
             float ed = 1.f;
-            if (zn > s.smax) { ed = expf(over_gamma<FAST>(s.smax - zn, p)); s.smax = zn; }
-            const float ez = expf(over_gamma<FAST>(zn - s.smax, p));
+            if (zn > s.smax) { ed = fast_exp(over_gamma<FAST>(s.smax - zn, p)); s.smax = zn; }
+            const float ez = fast_exp(over_gamma<FAST>(zn - s.smax, p));
             s.ssum = ed * s.ssum + ez * D;
             float k0, k1, k2;
             sample_colour<FAST>(p, r, vc, tbase, wc, zp, k0, k1, k2);
