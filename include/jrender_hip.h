@@ -153,6 +153,8 @@ int jr_n3mr_backward(jr_ctx* ctx, const float* faces, const int32_t* face_index_
  * evaluates n pseudo-random (a, b) pairs on the GPU and counts results of the reciprocal-refinement
  * quotient that differ in any bit from the IEEE quotient a / b.  Must return 0 mismatches. */
 int jr_selftest_division(jr_ctx* ctx, uint64_t n, uint32_t seed, uint64_t* mismatches);
+/* exhaustive: v_rcp_f32 + one Newton step vs IEEE 1.0f/x for every float with exponent in [-40, 40] */
+int jr_selftest_reciprocal(jr_ctx* ctx, uint64_t* mismatches);
 
 /* ---- introspection for tests / benchmarks ---------------------------------------- */
 /* statistics of the last forward on this context: [0]=bin-face pairs, [1]=non-empty 32x32 bins,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "jr_n3mr_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float] * 3 + [c_float_p] + [C.c_int] * 3),
     "jr_n3mr_backward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_float] + [C.c_int] * 3),
     "jr_selftest_division": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "jr_selftest_reciprocal": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "jr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "jr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "jr_softras_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
@@ -248,6 +249,12 @@ class Context:
         """Bit mismatches between the kernels' reciprocal-refinement quotient and IEEE a / b."""
         bad = C.c_uint64(0)
         _check(load().jr_selftest_division(self.handle, int(n), int(seed), C.byref(bad)))
+        return bad.value
+
+    def selftest_reciprocal(self):
+        """Bit mismatches of the Newton-refined v_rcp_f32 against IEEE 1.0f/x, exhaustive over 1.36e9 floats."""
+        bad = C.c_uint64(0)
+        _check(load().jr_selftest_reciprocal(self.handle, C.byref(bad)))
         return bad.value
 
     def last_stats(self):

@@ -119,3 +119,20 @@ void launch_selftest_div(hipStream_t st, unsigned long long n, uint32_t seed, un
     k_selftest_div<<<blocks, threads, 0, st>>>(per, seed, mismatches);
 }
 }  // namespace jr
+
+// ---- self-test: recip_exact(x) == 1.0f / x for EVERY float with exponent in [-40, 40] -----------
+namespace jr {
+__global__ __launch_bounds__(256) void k_selftest_rcp(unsigned long long* mismatches) {
+    const unsigned m = blockIdx.x * blockDim.x + threadIdx.x;       // all 2^23 mantissas
+    unsigned long long bad = 0;
+    for (int e = -40; e <= 40; e++)
+        for (unsigned s = 0; s < 2; s++) {
+            const float x = __builtin_bit_cast(float, (s << 31) | ((unsigned)(127 + e) << 23) | m);
+            bad += __builtin_bit_cast(unsigned, recip_exact(x)) != __builtin_bit_cast(unsigned, 1.0f / x);
+        }
+    if (bad) atomicAdd(mismatches, bad);
+}
+void launch_selftest_rcp(hipStream_t st, unsigned long long* mismatches) {
+    k_selftest_rcp<<<(1u << 23) / 256, 256, 0, st>>>(mismatches);
+}
+}  // namespace jr

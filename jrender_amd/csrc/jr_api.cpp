@@ -179,7 +179,7 @@ int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const
     }
     {
         ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
-        jr::launch_bin_fill_sort(ctx->stream, p, ws);
+        jr::launch_bin_fill_sort(ctx->stream, p, ws, pairs);
     }
     JR_HIP(hipGetLastError());
     ctx->bins_faces = faces; ctx->bins_B = p.B; ctx->bins_NF = p.NF; ctx->bins_IS = p.IS;
@@ -485,6 +485,18 @@ int jr_selftest_division(jr_ctx* ctx, uint64_t n, uint32_t seed, uint64_t* misma
     JR_HIP(hipSetDevice(ctx->device));
     JR_HIP(hipMemsetAsync(ctx->ws.counters, 0, sizeof(unsigned long long) * 4, ctx->stream));
     jr::launch_selftest_div(ctx->stream, n, seed, ctx->ws.counters);
+    JR_HIP(hipMemcpyAsync(ctx->h_counters, ctx->ws.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    *mismatches = ctx->h_counters[0];
+    return 0;
+}
+
+int jr_selftest_reciprocal(jr_ctx* ctx, uint64_t* mismatches) {
+    if (!ctx || !mismatches) return fail("NULL argument");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipMemsetAsync(ctx->ws.counters, 0, sizeof(unsigned long long) * 4, ctx->stream));
+    jr::launch_selftest_rcp(ctx->stream, ctx->ws.counters);
     JR_HIP(hipMemcpyAsync(ctx->h_counters, ctx->ws.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                           ctx->stream));
     JR_HIP(hipStreamSynchronize(ctx->stream));

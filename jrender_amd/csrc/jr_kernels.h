@@ -16,13 +16,13 @@ struct BinWorkspace {
     int* bin_cursor = nullptr;                 // [B*bins]
     unsigned long long* counters = nullptr;    // [4] device: total pairs, non-empty bins, max count
     unsigned long long* pool = nullptr;        // [pool_cap] (face id << 32 | tile mask), per bin ascending
-    unsigned long long* pool_scratch = nullptr;// [pool_cap] only used by the huge-segment sort
+    unsigned long long* pool_scratch = nullptr;// [pool_cap] the same segments as filled (unordered)
     size_t faces_cap = 0, bins_cap = 0, pool_cap = 0;
 };
 
 void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, const float* textures,
                     float* faces_info, BinWorkspace& ws);
-void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws);
+void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws, size_t pairs);
 
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
                             const BinWorkspace& ws, float* aggrs_info, float* soft_colors,
@@ -49,6 +49,7 @@ void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* fac
                           const int32_t* sampling_index_map, const float* grad_rgb_map, const float* grad_alpha_map,
                           const float* grad_depth_map, float* grad_faces, float* grad_textures, int B, int NF,
                           int TS, int IS, float eps, int rrgb, int ralpha, int rdepth);
+void launch_selftest_rcp(hipStream_t st, unsigned long long* mismatches);
 void launch_selftest_div(hipStream_t st, unsigned long long n, uint32_t seed, unsigned long long* mismatches);
 
 }  // namespace jr

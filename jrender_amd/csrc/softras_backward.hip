@@ -9,13 +9,15 @@
 //     searches ITS ids in the chunk (LDS) and builds a private 64-bit mask of chunk positions;
 //     the OR of the masks tells which faces anyone needs, and only those records are staged
 //     from the packed geometry array into LDS;
-//   * the needed faces are visited one by one (wave-uniform loop, record read by LDS broadcast):
-//     the lanes that hold the face run the exact per-pair arithmetic, their contributions are
-//     summed across the wavefront with DPP row shifts / broadcasts, and lane 63 issues ONE global
-//     atomic per gradient component per (tile, face) instead of one per pixel.
+//   * lanes map to pixels so that every DPP row (16 lanes) owns one 4x4 block; each row walks the
+//     faces ITS block needs (four faces in flight per wavefront, record read by per-row LDS address):
+//     the lanes that hold the face run the per-pair arithmetic, the 12 gradient components are reduced
+//     with a row-local butterfly transpose-reduction (row_mirror / row_half_mirror / quad_perm, payload
+//     halving every step) that leaves component k in lane k, and ONE atomic instruction per row covers
+//     all components of the face (instead of one atomic per pixel and component).
 //
-// (Measured on MI355X: LDS float atomics — ds_add_f32 — retire about one lane per clock, so a
-// per-lane scatter into LDS accumulators is 2x slower than this DPP reduction; profiles/.)
+// (Measured on MI355X, tools/: LDS float atomics — ds_add_f32 — retire about one lane per clock, so a
+// per-lane scatter into LDS accumulators is 2x slower; a whole-wavefront reduction per face 1.5x slower.)
 #include "jr_kernels.h"
 
 namespace jr {

@@ -95,3 +95,26 @@ def test_forward_deterministic_at_full_size(scene):
     out = fn2(fv, tex).numpy()
     assert bits_equal(out, saved[2])
     assert bits_equal(fn2.save_vars[5].numpy(), saved[5])
+
+
+@pytest.mark.parametrize("image_size,npix", [(512, 1500), (48, 600)])
+def test_mesh_above_bitmap_capacity(image_size, npix):
+    """More than 262 144 faces: the per-bin order falls back from the LDS id bitmap to the comparison
+    sorts (LDS bitonic at 512^2 where bins hold < 4096 faces; rank sort at 48^2 where they hold ~70 000)."""
+    ctx = _ffi.Context.default()
+    nf = 270000
+    fv, tex = syn.triangle_soup(nf, 1, seed=21, scale=1.5)
+    fn = SoftRasterizeFunction(image_size=image_size, max_faces_per_pixel_for_grad=K, sigma_val=1e-5, ctx=ctx)
+    fn(fv, tex)
+    st = ctx.last_stats()
+    assert (st["max_faces_in_bin"] <= 4096) == (image_size == 512)
+    ids_all = fn.save_vars[5].numpy()
+    rgba_all = fn.save_vars[2].numpy()
+    pix = np.unique(np.random.default_rng(5).choice(image_size * image_size, npix, replace=False))
+    port = Oracle("port", nthreads=0)
+    sub = port.forward_subset(fv, tex, pix, image_size=image_size, max_faces_per_pixel_for_grad=K, sigma_val=1e-5)
+    ids = ids_all.reshape(1, K, -1)[0][:, pix].T
+    rgba = rgba_all.reshape(1, 4, -1)[0][:, pix].T
+    assert bits_equal(ids, sub["ids"])
+    assert rel_err(rgba, sub["rgba"], RGBA_ATOL) <= 1.0
+    assert (ids[:, 0] >= 0).mean() > 0.2

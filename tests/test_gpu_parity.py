@@ -81,6 +81,8 @@ def test_fast_division_identity(ctx):
     # quotient bit for bit on its guarantee domain (softras_device.h): 2^31 random operand pairs
     assert ctx.selftest_division(1 << 31, seed=12345) == 0
     assert ctx.selftest_division(1 << 28, seed=777) == 0
+    # and the Newton-refined hardware reciprocal is the IEEE reciprocal for EVERY float in its range
+    assert ctx.selftest_reciprocal() == 0
 
 
 def test_default_sphere(ctx, port):
@@ -134,8 +136,8 @@ def test_empty_scene(ctx, port):
     assert (fn.save_vars[5].numpy() == -1).all()
 
 
-def test_huge_tile_segment_uses_rank_sort(ctx, port):
-    # > 4096 faces inside ONE 16x16 tile: exercises the out-of-LDS sort path of the binning
+def test_crowded_bin(ctx, port):
+    # > 4096 faces inside ONE 32x32 bin (more than one LDS chunk, more than the bitonic capacity)
     rng = np.random.default_rng(3)
     n = 4500
     c = rng.uniform(-0.05, 0.05, (n, 1, 2))
