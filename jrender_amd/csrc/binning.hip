@@ -250,6 +250,26 @@ __global__ __launch_bounds__(256) void k_bin_order(int NF, const int* __restrict
     }
 }
 
+// Launch order of the bins for the raster kernels: heaviest lists first (longest-processing-time-first
+// keeps the tail of the launch short: the list length of a bin varies from 1 to >1000 faces), empty bins
+// last.  One workgroup: histogram over ~12 buckets per octave of the count, descending prefix, scatter.
+__global__ __launch_bounds__(1024) void k_bin_schedule(int nbins_total, const int* __restrict__ bin_count,
+                                                       int* __restrict__ bin_order) {
+    __shared__ int s_hist[256], s_start[256];
+    auto bucket = [](int n) { return n <= 0 ? 0 : min(255, 1 + (int)(__log2f((float)n) * 12.f)); };
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < nbins_total; t += 1024) atomicAdd(&s_hist[bucket(bin_count[t])], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 255; b >= 0; b--) { s_start[b] = run; run += s_hist[b]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nbins_total; t += 1024)
+        bin_order[atomicAdd(&s_start[bucket(bin_count[t])], 1)] = t;
+}
+
 constexpr int SORT_LDS = 4096;   // 64-bit entries sortable in LDS by one workgroup (32 KB)
 
 // One workgroup per bin.  Ascending sort of the bin's entries by face id (unique keys).
@@ -316,6 +336,7 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, c
 void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws, size_t pairs) {
     const int nfaces = p.B * p.NF;
     const int nbins = p.B * p.bins_x * p.bins_y;
+    k_bin_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_order);
     k_bin_fill<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.bin_base, ws.bin_cursor, ws.pool_scratch);
     if (p.NF <= BITMAP_MAX_FACES) {
         const size_t lds = sizeof(unsigned) * 2 * (size_t)((p.NF + 31) >> 5);

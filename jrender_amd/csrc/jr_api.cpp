@@ -153,10 +153,11 @@ int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const
         ws.faces_cap = c0;
     }
     if (nbins > ws.bins_cap || !ws.bin_count) {
-        size_t c0 = ws.bins_cap, c1 = ws.bins_cap, c2 = ws.bins_cap;
+        size_t c0 = ws.bins_cap, c1 = ws.bins_cap, c2 = ws.bins_cap, c3 = ws.bins_cap;
         if (grow(ws.bin_count, c0, nbins, 1.0)) return 1;
         if (grow(ws.bin_base, c1, nbins, 1.0)) return 1;
         if (grow(ws.bin_cursor, c2, nbins, 1.0)) return 1;
+        if (grow(ws.bin_order, c3, nbins, 1.0)) return 1;
         ws.bins_cap = c0;
     }
     {
@@ -224,7 +225,7 @@ int jr_ctx_destroy(jr_ctx* ctx) {
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     jr::BinWorkspace& ws = ctx->ws;
     (void)hipFree(ctx->zkey);
-    (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor);
+    (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor); (void)hipFree(ws.bin_order);
     (void)hipFree(ws.counters); (void)hipFree(ws.pool); (void)hipFree(ws.pool_scratch);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipHostFree(ctx->h_counters);

@@ -14,6 +14,7 @@ struct BinWorkspace {
     int* bin_count = nullptr;                  // [B*bins]
     int* bin_base = nullptr;                   // [B*bins] segment start in pool
     int* bin_cursor = nullptr;                 // [B*bins]
+    int* bin_order = nullptr;                  // [B*bins] launch rank -> bin, heaviest list first
     unsigned long long* counters = nullptr;    // [4] device: total pairs, non-empty bins, max count
     unsigned long long* pool = nullptr;        // [pool_cap] (face id << 32 | tile mask), per bin ascending
     unsigned long long* pool_scratch = nullptr;// [pool_cap] the same segments as filled (unordered)

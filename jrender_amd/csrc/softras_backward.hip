@@ -195,7 +195,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
 template <int DIST, int RGB, int KCAP>
 __global__ __launch_bounds__(64) void k_softras_backward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
-    const FaceGeo* __restrict__ geo, const int* __restrict__ bin_count,
+    const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
     const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     __shared__ int s_ids[CHUNK];
     __shared__ unsigned long long s_need;
 
-    const int per_xcd = gridDim.x >> 3;
-    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (t >= ntiles_total) return;
-    const int bin = t >> 4, sub = t & 15;
+    const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
+    const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
+    if (brank * 16 >= ntiles_total) return;
+    const int bin = bin_order[brank], sub = k & 15;      // ... heaviest first (k_bin_schedule)
     const int n = bin_count[bin];
     if (n == 0) return;
     const int bins_per_img = p.bins_x * p.bins_y;
@@ -370,15 +370,15 @@ template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, const float* rgba, const float* aggrs, const int32_t* ids,
                      const float* grad_rgba, float* grad_faces, float* grad_textures) {
-    const int grid = ((ntiles + 7) / 8) * 8;
+    const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
     const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
     if (p.K <= 16)
         k_softras_backward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_count, ws.bin_base, ws.pool, rgba, aggrs, ids, grad_rgba,
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures);
     else
         k_softras_backward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_count, ws.bin_base, ws.pool, rgba, aggrs, ids, grad_rgba,
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures);
 }
 

@@ -150,19 +150,19 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
 template <int DIST, int RGB, int KCAP>
 __global__ __launch_bounds__(64) void k_softras_forward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
-    const FaceGeo* __restrict__ geo, const int* __restrict__ bin_count,
+    const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
     float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     extern __shared__ float4 s_dyn[];
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
     float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
 
-    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a
-    // contiguous run of tiles so that the 16 tiles of a bin (same list, same records) share an L2.
-    const int per_xcd = gridDim.x >> 3;
-    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (t >= ntiles_total) return;
-    const int bin = t >> 4, sub = t & 15;
+    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
+    // bin (same list, same records) go to ONE XCD so that they share its L2.
+    const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
+    const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
+    if (brank * 16 >= ntiles_total) return;
+    const int bin = bin_order[brank], sub = k & 15;      // ... heaviest first (k_bin_schedule)
     const int bins_per_img = p.bins_x * p.bins_y;
     const int b = bin / bins_per_img;
     const int bb = bin - b * bins_per_img;
@@ -197,52 +197,82 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     const FaceGeo* gbase = geo + (size_t)b * p.NF;
     const float* tbase = textures + (size_t)b * p.NF * p.T * 3;
 
-    for (int s0 = 0; s0 < n; s0 += CHUNK) {
-        // ---- cull + stage: lane = face ----
-        const int idx = s0 + lane;
-        const unsigned long long e = idx < n ? seg[idx] : 0ull;
-        const int fn_f = (int)(e >> 32);
-        const bool need = (e >> sub) & 1ull;
-        if (!ballot(need)) continue;            // no face of this chunk touches this tile
-        const FaceGeo* gp = gbase + fn_f;
-        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (need) box = *reinterpret_cast<const float4*>(gp);                 // xlo xhi ylo yhi
-        unsigned long long cx[8], ry[8];
-        bool anyx = false, anyy = false;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            // check_border (SRK:28-34, :316): a pixel is culled when strictly outside the grown box
-            const bool px = need && !(xc[c] > box.y) && !(xc[c] < box.x);
-            const bool py = need && !(yc[c] > box.w) && !(yc[c] < box.z);
-            cx[c] = ballot(px); ry[c] = ballot(py);
-            anyx |= px; anyy |= py;
-        }
-        __syncthreads();                        // previous chunk's readers are done with s_rec
-        if (anyx && anyy) {
-            const float4* src = reinterpret_cast<const float4*>(gp);
-            float4* dst = reinterpret_cast<float4*>(&s_rec[lane]);
-#pragma unroll
-            for (int k = 0; k < 11; k++) dst[k] = src[k];
-            if (p.tex == 1) {
-                const float* tx_ = tbase + (size_t)fn_f * p.T * 3;
-#pragma unroll
-                for (int k = 0; k < 9; k++) s_vcol[lane * 9 + k] = tx_[k];
+    // The bin's list is walked 64 entries at a time, but only a fraction of them concerns THIS tile.
+    // Survivors are compacted (ascending order kept) into the 64 LDS slots across list chunks and the
+    // raster loop only runs on a full batch: its trip count is the MAXIMUM number of faces any pixel
+    // needs, and max/mean over 64 lanes shrinks with the batch (measured: 17 survivors per list chunk
+    // -> 64 per batch), and the per-batch ballots are paid 4x less often.
+    int s0 = 0, fill = 0, cnt = 0;
+    bool pending = false, keep = false;
+    const FaceGeo* gp = gbase;
+    int rank = 0;                                   // of this lane's entry among the chunk's survivors
+    for (;;) {
+        // ---- cull + stage: lane = list entry ----
+        while (pending || s0 < n) {
+            if (!pending) {
+                const int idx = s0 + lane;
+                s0 += CHUNK;
+                const unsigned long long e = idx < n ? seg[idx] : 0ull;
+                const bool need = (e >> sub) & 1ull;
+                if (!ballot(need)) continue;        // no face of this chunk touches this tile
+                gp = gbase + (int)(e >> 32);
+                float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (need) box = *reinterpret_cast<const float4*>(gp);         // xlo xhi ylo yhi
+                // conservative tile test with check_border's own compare form (SRK:28-34: NaN passes);
+                // column centres ascend with c, row centres descend
+                keep = need && !(xc[0] > box.y) && !(xc[7] < box.x) && !(yc[7] > box.w) && !(yc[0] < box.z);
+                const unsigned long long surv = ballot(keep);
+                if (!surv) continue;
+                cnt = __builtin_popcountll(surv);
+                rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(surv >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((unsigned)surv, 0u));
             }
+            if (fill + cnt > CHUNK) { pending = true; break; }
+            pending = false;
+            if (keep) {
+                const int slot = fill + rank;
+                const float4* src = reinterpret_cast<const float4*>(gp);
+                float4* dst = reinterpret_cast<float4*>(&s_rec[slot]);
+#pragma unroll
+                for (int k = 0; k < 11; k++) dst[k] = src[k];
+                if (p.tex == 1) {
+                    const float* tx_ = tbase + (size_t)(gp - gbase) * p.T * 3;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) s_vcol[slot * 9 + k] = tx_[k];
+                }
+            }
+            fill += cnt;
         }
+        if (fill == 0) break;
         __syncthreads();
 
-        // ---- raster: lane = pixel; private mask of the faces that pass this pixel's border test ----
-        unsigned long long M = valid ? (select8(cx, lx) & select8(ry, ly)) : 0ull;
-        while (M) {
-            const int j = __builtin_ctzll(M);
-            M &= M - 1;
-            const FaceRec& r = s_rec[j];
-            const float* vc = s_vcol + j * 9;
-            if ((r.flags & FLAG_SAFE) && p.consts_safe)
-                forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
-            else
-                forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
+        // ---- raster: lane = slot for the ballots, then lane = pixel ----
+        {
+            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool have = lane < fill;
+            if (have) box = *reinterpret_cast<const float4*>(&s_rec[lane]);
+            unsigned long long cx[8], ry[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                // check_border (SRK:28-34, :316): a pixel is culled when strictly outside the grown box
+                cx[c] = ballot(have && !(xc[c] > box.y) && !(xc[c] < box.x));
+                ry[c] = ballot(have && !(yc[c] > box.w) && !(yc[c] < box.z));
+            }
+            // private mask of the faces that pass this pixel's border test
+            unsigned long long M = valid ? (select8(cx, lx) & select8(ry, ly)) : 0ull;
+            while (M) {
+                const int j = __builtin_ctzll(M);
+                M &= M - 1;
+                const FaceRec& r = s_rec[j];
+                const float* vc = s_vcol + j * 9;
+                if ((r.flags & FLAG_SAFE) && p.consts_safe)
+                    forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
+                else
+                    forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
+            }
         }
+        fill = 0;
+        __syncthreads();                        // readers are done with s_rec before it is refilled
     }
 
     if (!valid) return;
@@ -274,14 +304,14 @@ __global__ __launch_bounds__(64) void k_softras_forward(
 template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
-    const int grid = ((ntiles + 7) / 8) * 8;
+    const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
     const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
     if (p.K <= 16)
         k_softras_forward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_count, ws.bin_base, ws.pool, aggrs, rgba, ids);
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, aggrs, rgba, ids);
     else
         k_softras_forward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_count, ws.bin_base, ws.pool, aggrs, rgba, ids);
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, aggrs, rgba, ids);
 }
 
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
