@@ -5,19 +5,23 @@
 // pixel-face pair) and issues 9+3T float atomics per pair.  Here one wavefront owns an 8x8 tile:
 //
 //   * every lane (= pixel) loads its K buffered ids and sorts them in registers;
-//   * the tile's bin list (ascending ids) is walked 64 entries at a time; each lane binary-
-//     searches ITS ids in the chunk (LDS) and builds a private 64-bit mask of chunk positions;
-//     the OR of the masks tells which faces anyone needs, and only those records are staged
-//     from the packed geometry array into LDS;
-//   * lanes map to pixels so that every DPP row (16 lanes) owns one 4x4 block; each row walks the
-//     faces ITS block needs (four faces in flight per wavefront, record read by per-row LDS address):
-//     the lanes that hold the face run the per-pair arithmetic, the 12 gradient components are reduced
-//     with a row-local butterfly transpose-reduction (row_mirror / row_half_mirror / quad_perm, payload
-//     halving every step) that leaves component k in lane k, and ONE atomic instruction per row covers
-//     all components of the face (instead of one atomic per pixel and component).
+//   * the tile's bin list (ascending ids) is walked 64 entries at a time; each lane binary-searches ITS
+//     ids in the chunk (LDS) and builds a private mask of chunk positions; the OR of the masks tells
+//     which faces anyone needs; only those records are staged, compacted across list chunks into a
+//     batch of 64 LDS slots (a tile needs ~40 distinct faces on the headline workload: one batch);
+//   * the batch is cut into WORK ITEMS = (face, up to 16 of the pixels that hold it): the pixel x slot
+//     bit matrix is transposed with ballots, a prefix sum numbers the items, and every 16-lane DPP row
+//     takes one item per trip.  The lanes of the row pick "their" pixel (n-th set bit of the face's
+//     holder mask) and GATHER that pixel's state with ds_bpermute — lanes are no longer tied to pixels,
+//     so a row is full unless the face has fewer than 16 holders left (lane utilisation 45 % -> 74 %);
+//   * the 12 gradient components are reduced with a row-local butterfly transpose-reduction
+//     (row_mirror / row_half_mirror / quad_perm, payload halving every step) that leaves component k
+//     in lane k, and ONE atomic instruction per row covers all components of the item (instead of one
+//     atomic per pixel and component).
 //
 // (Measured on MI355X, tools/: LDS float atomics — ds_add_f32 — retire about one lane per clock, so a
-// per-lane scatter into LDS accumulators is 2x slower; a whole-wavefront reduction per face 1.5x slower.)
+// per-lane scatter into LDS accumulators is 2x slower; a whole-wavefront reduction per face 1.5x slower;
+// rows tied to fixed 4x4 pixel blocks leave 55 % of the lanes idle.)
 #include "jr_kernels.h"
 
 namespace jr {
@@ -55,6 +59,30 @@ __device__ inline float row_transpose_reduce(const float (&v)[16], int li) {
 #pragma unroll
     for (int j = 0; j < 2; j++) c[j] = (h2 ? b[j + 2] : b[j]) + dpp_f<0x1B>(h2 ? b[j] : b[j + 2]);
     return (h1 ? c[1] : c[0]) + dpp_f<0xB1>(h1 ? c[0] : c[1]);
+}
+
+// position of the n-th (0-based) set bit of m; n < popcount(m)
+__device__ inline int select_bit(unsigned long long m, int n) {
+    const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+    const int cl = __builtin_popcount(lo);
+    const bool up64 = n >= cl;
+    unsigned w = up64 ? hi : lo;
+    int base = up64 ? 32 : 0;
+    n = up64 ? n - cl : n;
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        const int c = __builtin_popcount(w & ((1u << s) - 1u));
+        const bool up = n >= c;
+        n = up ? n - c : n;
+        base += up ? s : 0;
+        w = up ? (w >> s) : w;
+    }
+    return base;
+}
+
+// value of v in lane src (all lanes active)
+__device__ inline float gather(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v)));
 }
 
 template <int N>
@@ -205,6 +233,8 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
     __shared__ int s_ids[CHUNK];
     __shared__ unsigned long long s_need;
+    __shared__ unsigned long long s_has[CHUNK];      // slot -> pixels (lanes) that hold the face
+    __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
 
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
     const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
@@ -219,10 +249,8 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
     if (col0 >= p.IS || row0 >= p.IS) return;
 
-    // lane -> pixel: every DPP row (16 lanes) owns one 4x4 block of the 8x8 tile, so that the four
-    // rows of the wavefront can work on four different faces at once and reduce with row-local DPP
     const int lane = threadIdx.x, li = lane & 15, blk = lane >> 4;
-    const int col = col0 + (blk & 1) * 4 + (li & 3), row = row0 + (blk >> 1) * 4 + (li >> 2);
+    const int col = col0 + (lane & 7), row = row0 + (lane >> 3);
     const bool valid = col < p.IS && row < p.IS;
     const size_t pp = (size_t)p.IS * p.IS;
     const size_t pn = valid ? (size_t)row * p.IS + col : 0;
@@ -268,82 +296,129 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     float* gtbase = grad_textures + (size_t)b * p.NF * p.T * 3;
     const int ntex = p.tex == 1 ? 9 : (p.T == 1 ? 3 : 0);   // colour-gradient components shared by all pixels
 
-    for (int s0 = 0; s0 < n; s0 += CHUNK) {
-        if (!ballot(cur != BIG)) break;             // every pixel has consumed its buffer
-        const int cn = min(CHUNK, n - s0);
-        const int idx = s0 + lane;
-        const unsigned long long e = idx < n ? seg[idx] : 0ull;
-        const int fn_f = idx < n ? (int)(e >> 32) : BIG;
-        if (!ballot((e >> sub) & 1ull)) continue;   // no face of this chunk touches this tile
-        __syncthreads();
-        s_ids[lane] = fn_f;
-        if (lane == 0) s_need = 0ull;
-        __syncthreads();
-        const int hi_id = s_ids[cn - 1];
-
-        // ---- membership: positions (in this chunk) of my buffered faces ----
-        unsigned long long M = 0ull;
-        while (cur <= hi_id) {                       // BIG never satisfies this (ids < 2^31-1)
-            int lo = 0, hi = cn;
+    // Batch state: the faces somebody needs are compacted into the 64 LDS slots across list chunks;
+    // Ms = this pixel's faces as a mask over SLOTS.
+    unsigned long long Ms = 0ull;
+    int s0 = 0, fill = 0, cnt = 0, fn_f = 0;
+    unsigned long long M = 0ull, need = 0ull;        // of the chunk that waits for a free batch
+    bool pending = false;
+    for (;;) {
+        // ---- membership + stage: walk the list until the batch is full or the list / the buffers end ----
+        while (pending || (s0 < n && ballot(cur != BIG))) {
+            if (!pending) {
+                const int cn = min(CHUNK, n - s0);
+                const int idx = s0 + lane;
+                s0 += CHUNK;
+                const unsigned long long e = idx < n ? seg[idx] : 0ull;
+                fn_f = idx < n ? (int)(e >> 32) : BIG;
+                if (!ballot((e >> sub) & 1ull)) continue;   // no face of this chunk touches this tile
+                __syncthreads();
+                s_ids[lane] = fn_f;
+                if (lane == 0) s_need = 0ull;
+                __syncthreads();
+                const int hi_id = s_ids[cn - 1];
+                // positions (in this chunk) of my buffered faces
+                M = 0ull;
+                while (cur <= hi_id) {                       // BIG never satisfies this (ids < 2^31-1)
+                    int lo = 0, hi = cn;
 #pragma unroll
-            for (int it = 0; it < 7; it++) {         // lower_bound over <= 64 sorted ids
-                const int mid = (lo + hi) >> 1;
-                const bool less = mid < hi && s_ids[mid] < cur;
-                lo = less ? mid + 1 : lo;
-                hi = less ? hi : mid;
+                    for (int it = 0; it < 7; it++) {         // lower_bound over <= 64 sorted ids
+                        const int mid = (lo + hi) >> 1;
+                        const bool less = mid < hi && s_ids[mid] < cur;
+                        lo = less ? mid + 1 : lo;
+                        hi = less ? hi : mid;
+                    }
+                    if (lo < cn && s_ids[lo] == cur) M |= 1ull << lo;
+#pragma unroll
+                    for (int k = 0; k + 1 < KCAP; k++) mine[k] = mine[k + 1];
+                    mine[KCAP - 1] = BIG;
+                    cur = mine[0];
+                }
+                if (M) atomicOr(&s_need, M);
+                __syncthreads();
+                need = s_need;
+                if (!need) continue;
+                cnt = __builtin_popcountll(need);
             }
-            if (lo < cn && s_ids[lo] == cur) M |= 1ull << lo;
+            if (fill + cnt > CHUNK) { pending = true; break; }
+            pending = false;
+            // needed records -> slots fill .. fill+cnt-1 (ascending), chunk positions -> slot bits
+            if ((need >> lane) & 1ull) {
+                const int slot = fill + __builtin_popcountll(need & ((1ull << lane) - 1ull));
+                const FaceGeo* gp = gbase + fn_f;
+                const float4* src = reinterpret_cast<const float4*>(gp);
+                float4* dst = reinterpret_cast<float4*>(&s_rec[slot]);
 #pragma unroll
-            for (int k = 0; k + 1 < KCAP; k++) mine[k] = mine[k + 1];
-            mine[KCAP - 1] = BIG;
-            cur = mine[0];
-        }
-        if (M) atomicOr(&s_need, M);
-        __syncthreads();
-        unsigned long long need = s_need;
-        if (!need) continue;
-
-        // ---- stage the needed records (lane = face) ----
-        if ((need >> lane) & 1ull) {
-            const FaceGeo* gp = gbase + fn_f;
-            const float4* src = reinterpret_cast<const float4*>(gp);
-            float4* dst = reinterpret_cast<float4*>(&s_rec[lane]);
+                for (int k = 0; k < 11; k++) dst[k] = src[k];
+                if (p.tex == 1) {
+                    const float* tx_ = tbase + (size_t)fn_f * p.T * 3;
 #pragma unroll
-            for (int k = 0; k < 11; k++) dst[k] = src[k];
-            if (p.tex == 1) {
-                const float* tx_ = tbase + (size_t)fn_f * p.T * 3;
-#pragma unroll
-                for (int k = 0; k < 9; k++) s_vcol[lane * 9 + k] = tx_[k];
+                    for (int k = 0; k < 9; k++) s_vcol[slot * 9 + k] = tx_[k];
+                }
             }
+            while (M) {
+                const int j = __builtin_ctzll(M);
+                M &= M - 1;
+                Ms |= 1ull << (fill + __builtin_popcountll(need & ((1ull << j) - 1ull)));
+            }
+            fill += cnt;
         }
+        if (fill == 0) break;
+
+        // ---- work items: (face slot, group of <= 16 of the pixels that hold it) ----
+        // transpose the pixel x slot bit matrix: lane j learns which pixels hold slot j
+        unsigned long long has = 0ull;
+        for (int j = 0; j < fill; j++) {
+            const unsigned long long hj = ballot((Ms >> j) & 1ull);
+            if (lane == j) has = hj;
+        }
+        const int items = (__builtin_popcountll(has) + 15) >> 4;
+        int incl = items;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const int nitems = __builtin_amdgcn_readlane(incl, 63);
+        s_has[lane] = has;
+        s_ioff[lane] = incl - items;
+        if (lane == 0) s_ioff[64] = nitems;
         __syncthreads();
 
-        // ---- each 16-lane row walks the faces ITS 4x4 block needs (four faces in flight per
-        //      wavefront); pairs -> row-local transpose-reduction -> lane k of the row holds
-        //      component k -> ONE atomic instruction per row and face ----
-        unsigned long long nr = row_or(M);
-        while (ballot(nr != 0ull)) {
-            const bool act = nr != 0ull;                         // uniform within a row
-            const int f = act ? __builtin_ctzll(nr) : 0;
-            nr &= nr - 1;
-            const FaceRec& fr = s_rec[f];
-            const bool has = act && ((M >> f) & 1ull);
+        // ---- each 16-lane DPP row takes one item per trip (four faces in flight per wavefront): gather
+        //      the pixels' state, pair arithmetic, row-local transpose-reduction -> lane k of the row
+        //      holds component k -> ONE atomic instruction per row and item ----
+        int j = 0;
+        for (int i0 = 0; i0 < nitems; i0 += 4) {
+            const int item = i0 + blk;
+            const bool ract = item < nitems;                     // uniform within a row
+            if (ract) while (s_ioff[j + 1] <= item) j++;
+            const unsigned long long hs = ract ? s_has[j] : 0ull;
+            const int nth = ract ? (item - s_ioff[j]) * 16 + li : 64;
+            const bool act = nth < __builtin_popcountll(hs);
+            const int src = act ? select_bit(hs, nth) : lane;    // the pixel (lane) this pair belongs to
+            PixelGrad q;
+            q.g0 = gather(px.g0, src); q.g1 = gather(px.g1, src); q.g2 = gather(px.g2, src); q.g3 = gather(px.g3, src);
+            q.o0 = gather(px.o0, src); q.o1 = gather(px.o1, src); q.o2 = gather(px.o2, src); q.o3 = gather(px.o3, src);
+            q.ssum = gather(px.ssum, src); q.smax = gather(px.smax, src); q.r_ssum = gather(px.r_ssum, src);
+            const float qx = gather(xp, src), qy = gather(yp, src);
+            const FaceRec& fr = s_rec[j];
             float v[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float gt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             // check_border is repeated by the reference's backward (SRK:1244)
-            if (has && !(xp > fr.xhi || xp < fr.xlo || yp > fr.yhi || yp < fr.ylo)) {
+            if (act && !(qx > fr.xhi || qx < fr.xlo || qy > fr.yhi || qy < fr.ylo)) {
                 float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // x0 y0 z0 x1 y1 z1 x2 y2 z2
                 float tgs;
                 bool tex_on;
-                const float* vc = s_vcol + f * 9;
+                const float* vc = s_vcol + j * 9;
                 const int texel = ((fr.flags & FLAG_SAFE) && p.consts_safe)
-                    ? backward_pair<DIST, RGB, true>(p, fr, vc, px, xp, yp, tbase, gv, gt, tgs, tex_on)
-                    : backward_pair<DIST, RGB, false>(p, fr, vc, px, xp, yp, tbase, gv, gt, tgs, tex_on);
+                    ? backward_pair<DIST, RGB, true>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on)
+                    : backward_pair<DIST, RGB, false>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on);
                 if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: straight to global
                     float* gtx = gtbase + ((size_t)fr.id * p.T + texel) * 3;
-                    atomicAdd(gtx + 0, tgs * px.g0);
-                    atomicAdd(gtx + 1, tgs * px.g1);
-                    atomicAdd(gtx + 2, tgs * px.g2);
+                    atomicAdd(gtx + 0, tgs * q.g0);
+                    atomicAdd(gtx + 1, tgs * q.g1);
+                    atomicAdd(gtx + 2, tgs * q.g2);
                 }
 #pragma unroll
                 for (int k = 0; k < 9; k++) v[k] = gv[k];
@@ -351,7 +426,7 @@ __global__ __launch_bounds__(64) void k_softras_backward(
             }
             const int fn = fr.id;
             const float s = row_transpose_reduce(v, li);         // lane li: component li summed over the row
-            if (act && s != 0.f) {                               // SRK:1349-1358 does one atomic per pixel
+            if (ract && s != 0.f) {                              // SRK:1349-1358 does one atomic per pixel
                 if (li < 9) atomicAdd(gfbase + (size_t)fn * 9 + li, s);
                 else if (li < 9 + (ntex == 3 ? 3 : 0)) atomicAdd(gtbase + (size_t)fn * p.T * 3 + (li - 9), s);
             }
@@ -360,9 +435,12 @@ __global__ __launch_bounds__(64) void k_softras_backward(
 #pragma unroll
                 for (int k = 0; k < 9; k++) u[k] = gt[k];
                 const float st = row_transpose_reduce(u, li);
-                if (act && li < 9 && st != 0.f) atomicAdd(gtbase + (size_t)fn * p.T * 3 + li, st);
+                if (ract && li < 9 && st != 0.f) atomicAdd(gtbase + (size_t)fn * p.T * 3 + li, st);
             }
         }
+        fill = 0;
+        Ms = 0ull;
+        __syncthreads();                        // the batch's records and tables are free again
     }
 }
 
