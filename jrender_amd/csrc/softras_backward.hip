@@ -405,8 +405,11 @@ __global__ __launch_bounds__(64) void k_softras_backward(
             const FaceRec& fr = s_rec[j];
             float v[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float gt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            // check_border is repeated by the reference's backward (SRK:1244)
-            if (act && !(qx > fr.xhi || qx < fr.xlo || qy > fr.yhi || qy < fr.ylo)) {
+            // check_border is repeated by the reference's backward (SRK:1244); one predicate, no
+            // short-circuit ladder (every rung would re-materialise the zeroed outputs)
+            const float4 box = *reinterpret_cast<const float4*>(&fr);       // xlo xhi ylo yhi
+            const bool inb = !(qx > box.y) & !(qx < box.x) & !(qy > box.w) & !(qy < box.z);
+            if (act & inb) {
                 float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // x0 y0 z0 x1 y1 z1 x2 y2 z2
                 float tgs;
                 bool tex_on;

@@ -35,9 +35,11 @@ struct KBuffer {
     float max_z;
     int max_slot;
 
-    __device__ inline void init() {
+    // Slots >= K are never written; their depth is -inf so that the rescan (which starts from -1) can
+    // run over all KCAP registers without a per-slot "k < K" predicate (16 SGPR pairs otherwise).
+    __device__ inline void init(int K) {
 #pragma unroll
-        for (int k = 0; k < KCAP; k++) { id[k] = -1; z[k] = 0.f; }
+        for (int k = 0; k < KCAP; k++) { id[k] = -1; z[k] = k < K ? 0.f : -__builtin_inff(); }
         size = 0; max_z = -1.f; max_slot = -1;
     }
     // K-nearest insert with the reference's slot semantics (SRK:369-385): append while not
@@ -61,7 +63,7 @@ struct KBuffer {
             int ms = max_slot;
 #pragma unroll
             for (int k = 0; k < KCAP; k++) {
-                const bool gt = (k < K) && (z[k] > m);
+                const bool gt = z[k] > m;
                 m = gt ? z[k] : m;
                 ms = gt ? k : ms;
             }
@@ -169,18 +171,17 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
     const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
     if (col0 >= p.IS || row0 >= p.IS) return;            // tile lies outside the image
+    const int n = bin_count[bin];
 
     const int lane = threadIdx.x, lx = lane & 7, ly = lane >> 3;
     const int col = col0 + lx, row = row0 + ly;
     const bool valid = col < p.IS && row < p.IS;
     const float xp = pixel_centre(col, p.IS);
     const float yp = pixel_centre(p.IS - 1 - row, p.IS);                      // SRK:280-283
-    float xc[8], yc[8];                                                       // wave-uniform centres
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        xc[c] = pixel_centre(col0 + c, p.IS);
-        yc[c] = pixel_centre(p.IS - 1 - (row0 + c), p.IS);
-    }
+    // the tile's 8 column / 8 row centres are the xp of lanes 0..7 and the yp of lanes 0,8,..,56:
+    // read them with v_readlane where they are used instead of pinning 16 SGPRs over the raster loop
+    auto xc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xp), c)); };
+    auto yc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yp), 8 * c)); };
 
     PixelState<KCAP> s;
     s.c0 = 1.f; s.c1 = 1.f; s.c2 = 1.f;
@@ -190,9 +191,8 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     else if (RGB == 1) { s.c0 = p.bg[0] * s.ssum; s.c1 = p.bg[1] * s.ssum; s.c2 = p.bg[2] * s.ssum; }
     s.depth_min = 10000000.f;
     s.face_min = -1;
-    s.q.init();
+    s.q.init(p.K);
 
-    const int n = bin_count[bin];
     const unsigned long long* seg = pool + bin_base[bin];
     const FaceGeo* gbase = geo + (size_t)b * p.NF;
     const float* tbase = textures + (size_t)b * p.NF * p.T * 3;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void k_softras_forward(
                 if (need) box = *reinterpret_cast<const float4*>(gp);         // xlo xhi ylo yhi
                 // conservative tile test with check_border's own compare form (SRK:28-34: NaN passes);
                 // column centres ascend with c, row centres descend
-                keep = need && !(xc[0] > box.y) && !(xc[7] < box.x) && !(yc[7] > box.w) && !(yc[0] < box.z);
+                keep = need && !(xc(0) > box.y) && !(xc(7) < box.x) && !(yc(7) > box.w) && !(yc(0) < box.z);
                 const unsigned long long surv = ballot(keep);
                 if (!surv) continue;
                 cnt = __builtin_popcountll(surv);
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(64) void k_softras_forward(
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 // check_border (SRK:28-34, :316): a pixel is culled when strictly outside the grown box
-                cx[c] = ballot(have && !(xc[c] > box.y) && !(xc[c] < box.x));
-                ry[c] = ballot(have && !(yc[c] > box.w) && !(yc[c] < box.z));
+                cx[c] = ballot(have && !(xc(c) > box.y) && !(xc(c) < box.x));
+                ry[c] = ballot(have && !(yc(c) > box.w) && !(yc(c) < box.z));
             }
             // private mask of the faces that pass this pixel's border test
             unsigned long long M = valid ? (select8(cx, lx) & select8(ry, ly)) : 0ull;
