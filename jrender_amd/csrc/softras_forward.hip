@@ -59,13 +59,25 @@ struct KBuffer {
             if (zp > max_z) { max_z = zp; max_slot = size; }
             size++;
         } else {
-            float m = -1.f;
-            int ms = max_slot;
+            // largest depth by a v_max3 tree, then the FIRST slot that holds it (descending selects, so
+            // the smallest k is written last); equals the reference's strict '>' scan from -1 (SRK:379-385),
+            // NaN depths are skipped by both.  No serial compare-select chain.
+            float t[KCAP];
 #pragma unroll
-            for (int k = 0; k < KCAP; k++) {
-                const bool gt = z[k] > m;
-                m = gt ? z[k] : m;
-                ms = gt ? k : ms;
+            for (int k = 0; k < KCAP; k++) t[k] = z[k];
+#pragma unroll
+            for (int w = KCAP; w > 1; w = (w + 2) / 3) {
+#pragma unroll
+                for (int i = 0; i * 3 < w; i++) {
+                    const float a = t[3 * i], b = 3 * i + 1 < w ? t[3 * i + 1] : a, c = 3 * i + 2 < w ? t[3 * i + 2] : a;
+                    t[i] = fmaxf(fmaxf(a, b), c);
+                }
+            }
+            const float m = fmaxf(t[0], -1.f);
+            int ms = max_slot;
+            if (m > -1.f) {
+#pragma unroll
+                for (int k = KCAP - 1; k >= 0; k--) ms = z[k] == m ? k : ms;
             }
             max_z = m; max_slot = ms;
         }
