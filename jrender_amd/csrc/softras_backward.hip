@@ -5,10 +5,11 @@
 // pixel-face pair) and issues 9+3T float atomics per pair.  Here one wavefront owns an 8x8 tile:
 //
 //   * every lane (= pixel) loads its K buffered ids and sorts them in registers;
-//   * the tile's bin list (ascending ids) is walked 64 entries at a time; each lane binary-searches ITS
-//     ids in the chunk (LDS) and builds a private mask of chunk positions; the OR of the masks tells
-//     which faces anyone needs; only those records are staged, compacted across list chunks into a
-//     batch of 64 LDS slots (a tile needs ~40 distinct faces on the headline workload: one batch);
+//   * the faces the tile needs are the UNION of those ids: the wavefront repeatedly extracts the
+//     smallest pending id (DPP min), the ballot of the lanes whose head equals it is that face's holder
+//     mask, those lanes advance.  Up to 64 distinct faces form a batch (a tile of the headline workload
+//     needs ~40), their packed records are staged into LDS (lane = slot).  The bin lists are only used
+//     for the launch order and the empty-bin exit;
 //   * the batch is cut into WORK ITEMS = (face, up to 16 of the pixels that hold it): the pixel x slot
 //     bit matrix is transposed with ballots, a prefix sum numbers the items, and every 16-lane DPP row
 //     takes one item per trip.  The lanes of the row pick "their" pixel (n-th set bit of the face's
@@ -36,16 +37,6 @@ __device__ inline unsigned dpp_u(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// OR of a 64-bit mask over the 16 lanes of each row, result in every lane (row_ror 1,2,4,8)
-__device__ inline unsigned long long row_or(unsigned long long m) {
-    unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
-    lo |= dpp_u<0x121>(lo); hi |= dpp_u<0x121>(hi);
-    lo |= dpp_u<0x122>(lo); hi |= dpp_u<0x122>(hi);
-    lo |= dpp_u<0x124>(lo); hi |= dpp_u<0x124>(hi);
-    lo |= dpp_u<0x128>(lo); hi |= dpp_u<0x128>(hi);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // Sum of 16 per-lane values over the 16 lanes of a row, "transposed": lane i of the row ends up
 // with the row total of v[i].  Butterfly with halving payload (8+4+2+1 exchanges instead of
 // 16 x 4): partners are row_mirror, row_half_mirror, quad_perm[3,2,1,0], quad_perm[1,0,3,2].
@@ -59,6 +50,16 @@ __device__ inline float row_transpose_reduce(const float (&v)[16], int li) {
 #pragma unroll
     for (int j = 0; j < 2; j++) c[j] = (h2 ? b[j + 2] : b[j]) + dpp_f<0x1B>(h2 ? b[j] : b[j + 2]);
     return (h1 ? c[1] : c[0]) + dpp_f<0xB1>(h1 ? c[0] : c[1]);
+}
+
+// smallest value over the wavefront, uniform (all lanes active)
+__device__ inline int wave_min(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // position of the n-th (0-based) set bit of m; n < popcount(m)
@@ -224,15 +225,12 @@ template <int DIST, int RGB, int KCAP>
 __global__ __launch_bounds__(64) void k_softras_backward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
-    const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
     const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
     float* __restrict__ grad_faces, float* __restrict__ grad_textures) {
     extern __shared__ float4 s_dyn[];
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
     float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
-    __shared__ int s_ids[CHUNK];
-    __shared__ unsigned long long s_need;
     __shared__ unsigned long long s_has[CHUNK];      // slot -> pixels (lanes) that hold the face
     __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
 
@@ -261,17 +259,21 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     constexpr int BIG = 0x7fffffff;
     int mine[KCAP];
     {
+        // plane 0 decides whether the tile has anything to do; the other planes are then fetched at
+        // once (independent loads) and the reference's early stop is applied in registers
         const int32_t* ip = ids + (size_t)b * p.K * pp + pn;
-        bool live = valid;
+        int raw[KCAP];
+        raw[0] = valid ? ip[0] : -1;
+        if (!ballot(raw[0] >= 0)) return;           // nothing buffered anywhere in this tile
+#pragma unroll
+        for (int k = 1; k < KCAP; k++) raw[k] = (valid && k < p.K) ? ip[(size_t)k * pp] : -1;
+        bool live = true;
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
-            int v = -1;
-            if (live && k < p.K) v = ip[(size_t)k * pp];
-            live = live && v != -1;
-            mine[k] = live ? v : BIG;
+            live = live && raw[k] >= 0 && raw[k] < p.NF;   // -1 ends the list (ids outside [0, NF) too)
+            mine[k] = live ? raw[k] : BIG;
         }
     }
-    if (!ballot(mine[0] != BIG)) return;            // nothing buffered anywhere in this tile
     sort_ascending(mine);
     int cur = mine[0];
 
@@ -289,89 +291,51 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     }
     px.r_ssum = __builtin_amdgcn_rcpf(px.ssum);
 
-    const unsigned long long* seg = pool + bin_base[bin];
     const FaceGeo* gbase = geo + (size_t)b * p.NF;
     const float* tbase = textures + (size_t)b * p.NF * p.T * 3;
     float* gfbase = grad_faces + (size_t)b * p.NF * 9;
     float* gtbase = grad_textures + (size_t)b * p.NF * p.T * 3;
     const int ntex = p.tex == 1 ? 9 : (p.T == 1 ? 3 : 0);   // colour-gradient components shared by all pixels
 
-    // Batch state: the faces somebody needs are compacted into the 64 LDS slots across list chunks;
-    // Ms = this pixel's faces as a mask over SLOTS.
-    unsigned long long Ms = 0ull;
-    int s0 = 0, fill = 0, cnt = 0, fn_f = 0;
-    unsigned long long M = 0ull, need = 0ull;        // of the chunk that waits for a free batch
-    bool pending = false;
+    // The faces this tile needs are the UNION of its pixels' buffered ids — the bin lists are not needed
+    // to find them.  Every lane holds its ids sorted; the wavefront repeatedly extracts the smallest id
+    // that is still pending anywhere (DPP min), the ballot of the lanes whose head equals it IS the
+    // face's holder mask, and those lanes advance.  Up to 64 distinct faces form a batch (a tile of the
+    // headline workload needs ~40): slot = extraction order = ascending id, lane j keeps slot j's id and
+    // holder mask.  No list walk, no binary search, no bit-matrix transpose.
     for (;;) {
-        // ---- membership + stage: walk the list until the batch is full or the list / the buffers end ----
-        while (pending || (s0 < n && ballot(cur != BIG))) {
-            if (!pending) {
-                const int cn = min(CHUNK, n - s0);
-                const int idx = s0 + lane;
-                s0 += CHUNK;
-                const unsigned long long e = idx < n ? seg[idx] : 0ull;
-                fn_f = idx < n ? (int)(e >> 32) : BIG;
-                if (!ballot((e >> sub) & 1ull)) continue;   // no face of this chunk touches this tile
-                __syncthreads();
-                s_ids[lane] = fn_f;
-                if (lane == 0) s_need = 0ull;
-                __syncthreads();
-                const int hi_id = s_ids[cn - 1];
-                // positions (in this chunk) of my buffered faces
-                M = 0ull;
-                while (cur <= hi_id) {                       // BIG never satisfies this (ids < 2^31-1)
-                    int lo = 0, hi = cn;
+        int fill = 0, myid = 0;
+        unsigned long long has = 0ull;
+        while (fill < CHUNK) {
+            const int m = wave_min(cur);
+            if (m == BIG) break;
+            const bool hit = cur == m;
+            const unsigned long long h = ballot(hit);
+            if (lane == fill) { myid = m; has = h; }
+            if (hit) {
 #pragma unroll
-                    for (int it = 0; it < 7; it++) {         // lower_bound over <= 64 sorted ids
-                        const int mid = (lo + hi) >> 1;
-                        const bool less = mid < hi && s_ids[mid] < cur;
-                        lo = less ? mid + 1 : lo;
-                        hi = less ? hi : mid;
-                    }
-                    if (lo < cn && s_ids[lo] == cur) M |= 1ull << lo;
-#pragma unroll
-                    for (int k = 0; k + 1 < KCAP; k++) mine[k] = mine[k + 1];
-                    mine[KCAP - 1] = BIG;
-                    cur = mine[0];
-                }
-                if (M) atomicOr(&s_need, M);
-                __syncthreads();
-                need = s_need;
-                if (!need) continue;
-                cnt = __builtin_popcountll(need);
+                for (int k = 0; k + 1 < KCAP; k++) mine[k] = mine[k + 1];
+                mine[KCAP - 1] = BIG;
+                cur = mine[0];
             }
-            if (fill + cnt > CHUNK) { pending = true; break; }
-            pending = false;
-            // needed records -> slots fill .. fill+cnt-1 (ascending), chunk positions -> slot bits
-            if ((need >> lane) & 1ull) {
-                const int slot = fill + __builtin_popcountll(need & ((1ull << lane) - 1ull));
-                const FaceGeo* gp = gbase + fn_f;
-                const float4* src = reinterpret_cast<const float4*>(gp);
-                float4* dst = reinterpret_cast<float4*>(&s_rec[slot]);
-#pragma unroll
-                for (int k = 0; k < 11; k++) dst[k] = src[k];
-                if (p.tex == 1) {
-                    const float* tx_ = tbase + (size_t)fn_f * p.T * 3;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) s_vcol[slot * 9 + k] = tx_[k];
-                }
-            }
-            while (M) {
-                const int j = __builtin_ctzll(M);
-                M &= M - 1;
-                Ms |= 1ull << (fill + __builtin_popcountll(need & ((1ull << j) - 1ull)));
-            }
-            fill += cnt;
+            fill++;
         }
         if (fill == 0) break;
 
-        // ---- work items: (face slot, group of <= 16 of the pixels that hold it) ----
-        // transpose the pixel x slot bit matrix: lane j learns which pixels hold slot j
-        unsigned long long has = 0ull;
-        for (int j = 0; j < fill; j++) {
-            const unsigned long long hj = ballot((Ms >> j) & 1ull);
-            if (lane == j) has = hj;
+        // ---- stage the batch's records (lane = slot) ----
+        if (lane < fill) {
+            const float4* src = reinterpret_cast<const float4*>(gbase + myid);
+            float4* dst = reinterpret_cast<float4*>(&s_rec[lane]);
+#pragma unroll
+            for (int k = 0; k < 11; k++) dst[k] = src[k];
+            if (p.tex == 1) {
+                const float* tx_ = tbase + (size_t)myid * p.T * 3;
+#pragma unroll
+                for (int k = 0; k < 9; k++) s_vcol[lane * 9 + k] = tx_[k];
+            }
         }
+
+        // ---- work items: (face slot, group of <= 16 of the pixels that hold it) ----
         const int items = (__builtin_popcountll(has) + 15) >> 4;
         int incl = items;
 #pragma unroll
@@ -441,8 +405,6 @@ __global__ __launch_bounds__(64) void k_softras_backward(
                 if (ract && li < 9 && st != 0.f) atomicAdd(gtbase + (size_t)fn * p.T * 3 + li, st);
             }
         }
-        fill = 0;
-        Ms = 0ull;
         __syncthreads();                        // the batch's records and tables are free again
     }
 }
@@ -455,11 +417,11 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
     const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
     if (p.K <= 16)
         k_softras_backward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, rgba, aggrs, ids, grad_rgba,
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures);
     else
         k_softras_backward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, rgba, aggrs, ids, grad_rgba,
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures);
 }
 
