@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void k_bin_alloc(int nbins_total, const int* _
 __global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4* __restrict__ face_rect,
                                                   const int* __restrict__ bin_base,
                                                   int* __restrict__ bin_cursor,
-                                                  unsigned long long* __restrict__ pool) {
+                                                  unsigned long long* __restrict__ pool,
+                                                  const unsigned long long* __restrict__ counters,
+                                                  unsigned long long cap) {
+    if (counters[0] > cap) return;          // pool too small: the host regrows it and launches again
     const int total = p.B * p.NF;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int ic = min(i, total - 1);
@@ -198,8 +201,11 @@ constexpr int BITMAP_MAX_FACES = 262144;     // 2 x NF/32 words of LDS <= 64 KB
 __global__ __launch_bounds__(256) void k_bin_order(int NF, const int* __restrict__ bin_count,
                                                    const int* __restrict__ bin_base,
                                                    const unsigned long long* __restrict__ src,
-                                                   unsigned long long* __restrict__ dst) {
+                                                   unsigned long long* __restrict__ dst,
+                                                   const unsigned long long* __restrict__ counters,
+                                                   unsigned long long cap) {
     extern __shared__ unsigned s_dyn[];
+    if (counters[0] > cap) return;
     __shared__ int s_wsum[4];
     const int t = blockIdx.x;
     const int n = bin_count[t];
@@ -261,9 +267,10 @@ __global__ __launch_bounds__(1024) void k_bin_schedule(int nbins_total, const in
     __syncthreads();
     for (int t = threadIdx.x; t < nbins_total; t += 1024) atomicAdd(&s_hist[bucket(bin_count[t])], 1);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 256) {                // first rank of bucket b = number of bins in heavier buckets
         int run = 0;
-        for (int b = 255; b >= 0; b--) { s_start[b] = run; run += s_hist[b]; }
+        for (int b = 255; b > (int)threadIdx.x; b--) run += s_hist[b];
+        s_start[threadIdx.x] = run;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < nbins_total; t += 1024)
@@ -276,8 +283,11 @@ constexpr int SORT_LDS = 4096;   // 64-bit entries sortable in LDS by one workgr
 __global__ __launch_bounds__(256) void k_bin_sort(const int* __restrict__ bin_count,
                                                   const int* __restrict__ bin_base,
                                                   unsigned long long* __restrict__ pool,
-                                                  unsigned long long* __restrict__ scratch) {
+                                                  unsigned long long* __restrict__ scratch,
+                                                  const unsigned long long* __restrict__ counters,
+                                                  unsigned long long cap) {
     __shared__ unsigned long long s[SORT_LDS];
+    if (counters[0] > cap) return;
     const int t = blockIdx.x;
     const int n = bin_count[t];
     if (n <= 1) return;
@@ -331,19 +341,24 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, c
     (void)hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * 4, st);
     k_face_setup<<<(nfaces + 255) / 256, 256, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_count);
     k_bin_alloc<<<(nbins + 255) / 256, 256, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.counters);
+    k_bin_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_order);
 }
 
-void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws, size_t pairs) {
+// Every kernel here is guarded by "total pairs <= pool capacity" read from device memory, so that the
+// host can enqueue them BEFORE it knows the total (no pipeline bubble); see build_bins in jr_api.cpp.
+void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws) {
     const int nfaces = p.B * p.NF;
     const int nbins = p.B * p.bins_x * p.bins_y;
-    k_bin_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_order);
-    k_bin_fill<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.bin_base, ws.bin_cursor, ws.pool_scratch);
+    const unsigned long long cap = ws.pool_cap;
+    (void)hipMemsetAsync(ws.bin_cursor, 0, sizeof(int) * (size_t)nbins, st);
+    k_bin_fill<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.bin_base, ws.bin_cursor, ws.pool_scratch,
+                                                     ws.counters, cap);
     if (p.NF <= BITMAP_MAX_FACES) {
         const size_t lds = sizeof(unsigned) * 2 * (size_t)((p.NF + 31) >> 5);
-        k_bin_order<<<nbins, 256, lds, st>>>(p.NF, ws.bin_count, ws.bin_base, ws.pool_scratch, ws.pool);
+        k_bin_order<<<nbins, 256, lds, st>>>(p.NF, ws.bin_count, ws.bin_base, ws.pool_scratch, ws.pool, ws.counters, cap);
     } else {
-        k_bin_sort<<<nbins, 256, 0, st>>>(ws.bin_count, ws.bin_base, ws.pool_scratch, ws.pool);
-        (void)hipMemcpyAsync(ws.pool, ws.pool_scratch, sizeof(unsigned long long) * pairs, hipMemcpyDeviceToDevice, st);
+        k_bin_sort<<<nbins, 256, 0, st>>>(ws.bin_count, ws.bin_base, ws.pool_scratch, ws.pool, ws.counters, cap);
+        (void)hipMemcpyAsync(ws.pool, ws.pool_scratch, sizeof(unsigned long long) * ws.pool_cap, hipMemcpyDeviceToDevice, st);
     }
 }
 

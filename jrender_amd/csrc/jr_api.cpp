@@ -40,6 +40,7 @@ struct jr_ctx {
     hipStream_t stream = nullptr;
     jr::BinWorkspace ws;
     unsigned long long* h_counters = nullptr;   // pinned, 4 entries
+    hipEvent_t ev_counters = nullptr;           // marks the read-back of the pair total
     // identity of the bin lists currently held in ws (reused by the backward)
     const void* bins_faces = nullptr;
     const void* bins_tex = nullptr;
@@ -141,9 +142,9 @@ jr::RasterParams make_params(int B, int NF, int T, int IS, int K, float near_, f
     return p;
 }
 
-// Build (or rebuild) the per-bin ascending face lists for this geometry.
-int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
-               float* faces_info) {
+// Per-face records, bin counts and launch order for this geometry (all the backward needs).
+int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
+                float* faces_info) {
     const size_t nfaces = (size_t)p.B * p.NF, nbins = (size_t)p.B * p.bins_x * p.bins_y;
     jr::BinWorkspace& ws = ctx->ws;
     if (nfaces > ws.faces_cap || !ws.geo) {
@@ -164,27 +165,51 @@ int build_bins(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const
         ProfScope ps(ctx, JR_PHASE_BIN_COUNT);
         jr::launch_binning(ctx->stream, p, faces, textures, faces_info, ws);
     }
+    ctx->bins_faces = faces; ctx->bins_B = p.B; ctx->bins_NF = p.NF; ctx->bins_IS = p.IS;
+    ctx->bins_rad = p.rad; ctx->bins_tex = textures; ctx->bins_T = p.T; ctx->bins_valid = true;
+    return 0;
+}
+
+// Forward = setup + per-bin ascending lists + raster.  The pool that holds the lists must fit the total
+// number of (bin, face) pairs, which only the device knows after k_bin_alloc.  Waiting for that number
+// before enqueueing the rest costs a host round trip with an idle GPU on every call, so the rest is
+// enqueued SPECULATIVELY against the pool we already have (every kernel re-checks "pairs <= capacity" in
+// device memory and does nothing otherwise); the host then waits for the 32-byte read-back only, and in
+// the rare case that the pool was too small (first call, bigger scene) grows it and enqueues again.
+int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
+                     float* faces_info, float* aggrs_info, float* soft_colors, int32_t* faces_id_buffer) {
+    jr::BinWorkspace& ws = ctx->ws;
+    if (setup_faces(ctx, p, faces, textures, faces_info)) return 1;
     JR_HIP(hipMemcpyAsync(ctx->h_counters, ws.counters, sizeof(unsigned long long) * 4,
                           hipMemcpyDeviceToHost, ctx->stream));
-    JR_HIP(hipStreamSynchronize(ctx->stream));
+    JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));
+    auto enqueue = [&]() {
+        {
+            ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
+            jr::launch_bin_fill_sort(ctx->stream, p, ws);
+        }
+        ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
+        jr::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
+    };
+    const bool speculative = ws.pool != nullptr && ws.pool_cap > 0;
+    if (speculative) enqueue();
+    JR_HIP(hipEventSynchronize(ctx->ev_counters));
     const size_t pairs = (size_t)ctx->h_counters[0];
     ctx->stats[0] = (int64_t)pairs;
     ctx->stats[1] = (int64_t)ctx->h_counters[1];
     ctx->stats[2] = (int64_t)ctx->h_counters[2];
     ctx->stats[3] = (int64_t)p.bins_x * p.bins_y;
-    if (pairs > ws.pool_cap || !ws.pool) {
-        size_t c0 = ws.pool_cap, c1 = ws.pool_cap;
-        if (grow(ws.pool, c0, pairs, 1.25)) return 1;
-        if (grow(ws.pool_scratch, c1, pairs, 1.25)) return 1;
-        ws.pool_cap = c0;
-    }
-    {
-        ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
-        jr::launch_bin_fill_sort(ctx->stream, p, ws, pairs);
+    if (!speculative || pairs > ws.pool_cap) {
+        if (pairs > ws.pool_cap || !ws.pool) {
+            JR_HIP(hipStreamSynchronize(ctx->stream));      // nobody may still read the old pool
+            size_t c0 = ws.pool_cap, c1 = ws.pool_cap;
+            if (grow(ws.pool, c0, pairs > 0 ? pairs : 1, 1.25)) return 1;
+            if (grow(ws.pool_scratch, c1, pairs > 0 ? pairs : 1, 1.25)) return 1;
+            ws.pool_cap = c0;
+        }
+        enqueue();
     }
     JR_HIP(hipGetLastError());
-    ctx->bins_faces = faces; ctx->bins_B = p.B; ctx->bins_NF = p.NF; ctx->bins_IS = p.IS;
-    ctx->bins_rad = p.rad; ctx->bins_tex = textures; ctx->bins_T = p.T; ctx->bins_valid = true;
     return 0;
 }
 
@@ -212,6 +237,7 @@ int jr_ctx_create(int device, jr_ctx** out) {
     JR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     JR_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * 4, hipHostMallocDefault));
     JR_HIP(hipMalloc((void**)&c->ws.counters, sizeof(unsigned long long) * 4));
+    JR_HIP(hipEventCreateWithFlags(&c->ev_counters, hipEventDisableTiming));
     *out = c;
     return 0;
 }
@@ -229,6 +255,7 @@ int jr_ctx_destroy(jr_ctx* ctx) {
     (void)hipFree(ws.counters); (void)hipFree(ws.pool); (void)hipFree(ws.pool_scratch);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipHostFree(ctx->h_counters);
+    if (ctx->ev_counters) (void)hipEventDestroy(ctx->ev_counters);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -355,14 +382,8 @@ int jr_softras_forward(jr_ctx* ctx, const float* face_vertices, const float* tex
     const jr::RasterParams p = make_params(B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
                                            dist_eps, gamma_val, func_id_rgb, func_id_alpha,
                                            texture_sample_type, double_side, background_rgb);
-    if (build_bins(ctx, p, face_vertices, textures, faces_info)) return 1;
-    {
-        ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
-        jr::launch_softras_forward(ctx->stream, p, textures, ctx->ws, aggrs_info,
-                                   soft_colors, faces_id_buffer);
-    }
-    JR_HIP(hipGetLastError());
-    return 0;
+    return forward_pipeline(ctx, p, face_vertices, textures, faces_info, aggrs_info, soft_colors,
+                            faces_id_buffer);
 }
 
 int jr_softras_backward(jr_ctx* ctx, const float* face_vertices, const float* textures,
@@ -382,11 +403,12 @@ int jr_softras_backward(jr_ctx* ctx, const float* face_vertices, const float* te
     const jr::RasterParams p = make_params(B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
                                            dist_eps, gamma_val, func_id_rgb, func_id_alpha,
                                            texture_sample_type, double_side, nullptr);
-    // Tile lists of the matching forward are reused; anything else rebuilds them (no faces_info write).
+    // Face records / launch order of the matching forward are reused; anything else rebuilds them (no
+    // faces_info write, no lists: the backward finds its faces through the id buffer).
     const bool reuse = ctx->bins_valid && ctx->bins_faces == face_vertices && ctx->bins_B == B &&
                        ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad &&
                        ctx->bins_tex == textures && ctx->bins_T == T;
-    if (!reuse && build_bins(ctx, p, face_vertices, textures, nullptr)) return 1;
+    if (!reuse && setup_faces(ctx, p, face_vertices, textures, nullptr)) return 1;
     {
         ProfScope ps(ctx, JR_PHASE_BWD_RASTER);
         jr::launch_softras_backward(ctx->stream, p, textures, soft_colors, aggrs_info, faces_id_buffer,

@@ -166,8 +166,10 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
+    const unsigned long long* __restrict__ counters, unsigned long long pool_cap,
     float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     extern __shared__ float4 s_dyn[];
+    if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
     float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
 
@@ -320,10 +322,10 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
     const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
     if (p.K <= 16)
         k_softras_forward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, aggrs, rgba, ids);
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
     else
         k_softras_forward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, aggrs, rgba, ids);
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
 }
 
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
