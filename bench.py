@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="sphere", choices=["sphere", "soup"],
+                    help="sphere: 39k-face UV sphere turntable (BASELINE configs[2], the headline); "
+                         "soup: random triangles over the whole screen (north_star's 'random-triangle batches')")
     ap.add_argument("--faces", type=int, default=39000)
     ap.add_argument("--image-size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8, help="views per GPU")
@@ -143,7 +146,10 @@ def main():
     ctx = _ffi.Context(local_rank)
     B, NF, IS, K, T = args.batch, args.faces, args.image_size, args.K, 1
     # every rank gets its own 8 cameras of the turntable (different azimuth offset per rank)
-    fv_h, tex_h = syn.sphere_views(NF, B, azimuth0=360.0 * rank / max(world, 1) / B)
+    if args.scene == "sphere":
+        fv_h, tex_h = syn.sphere_views(NF, B, azimuth0=360.0 * rank / max(world, 1) / B)
+    else:
+        fv_h, tex_h = syn.triangle_soup(NF, B, seed=100 + rank)
     fv, tex = ctx.array(fv_h), ctx.array(tex_h)
     grad = ctx.array(np.random.default_rng(7 + rank).uniform(-1, 1, (B, 4, IS, IS)).astype(np.float32))
     fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
@@ -199,8 +205,9 @@ def main():
             "ms_per_image_fwd_bwd": ms_step / B,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UV-sphere %d faces x %d views/GPU, %dx%d, SoftRas fwd+bwd, K=%d, "
-                                   "sigma=1e-5 gamma=1e-4 euclidean/softmax/prod" % (NF, B, IS, IS, K),
+            "config": {"workload": "%s %d faces x %d views/GPU, %dx%d, SoftRas fwd+bwd, K=%d, "
+                                   "sigma=1e-5 gamma=1e-4 euclidean/softmax/prod"
+                                   % ("UV-sphere" if args.scene == "sphere" else "random-triangle soup", NF, B, IS, IS, K),
                        "faces": NF, "image_size": IS, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_softras_%s" % ("forward" if dom == "fwd_raster" else "backward"),

@@ -328,6 +328,89 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_depth(
         for (int l = 0; l < 2; l++) atomicAdd(&gf[3 * k + l], -gd * tmp[l] * w[k] * depth2 * is / 2);
 }
 
+// backward_textures + backward_depth_map with ONE WAVEFRONT PER FACE instead of one thread per pixel with
+// float atomics on the face's 9 + 3*TS^3 accumulators (every pixel of a face hits the same addresses: the
+// per-pixel kernels above spend their time serialising in L2).  The wavefront walks the face's bounding box
+// (the same box the z-buffer pass rasterised, so it contains every pixel the face owns), keeps the depth
+// gradient in registers and the texel gradients in LDS, and writes each face's results once, without
+// atomics and without a prior memset of grad_textures.  grad_faces already holds the pixel-map part
+// (k_n3mr_backward_pixel_map ran before on the same stream) and is updated in place by its only owner.
+constexpr int N3_TEX_LDS = 1536;            // floats of texel gradient per wavefront (TS <= 8)
+__global__ __launch_bounds__(256) void k_n3mr_backward_face(
+    N3Params p, const float* __restrict__ faces, const int32_t* __restrict__ face_index_map,
+    const float* __restrict__ depth_map, const float* __restrict__ face_inv_map,
+    const float* __restrict__ weight_map, const float* __restrict__ sampling_weight_map,
+    const int32_t* __restrict__ sampling_index_map, const float* __restrict__ grad_rgb_map,
+    const float* __restrict__ grad_depth_map, float* __restrict__ grad_faces, float* __restrict__ grad_textures) {
+    __shared__ float s_tex[4][N3_TEX_LDS];
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+    if (wave >= p.B * p.NF) return;
+    const int bn = wave / p.NF, fn = wave - bn * p.NF;
+    const int is = p.IS, ts = p.TS, ntex = p.return_rgb ? ts * ts * ts * 3 : 0;
+    float* acc = s_tex[wl];
+    for (int k = lane; k < ntex; k += 64) acc[k] = 0.f;
+    const float* f = faces + (size_t)wave * 9;
+    float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool front = !((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]));   // N3K:63
+    if (front) {
+        float x_min = is, y_min = is, x_max = 0, y_max = 0;                               // N3K:89-99
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float px = 0.5f * (f[3 * k] * is + is - 1), py = 0.5f * (f[3 * k + 1] * is + is - 1);
+            if (px < x_min) x_min = px;
+            if (px > x_max) x_max = px;
+            if (py < y_min) y_min = py;
+            if (py > y_max) y_max = py;
+        }
+        const int ix0 = max(0, (int)x_min), ix1 = min(is - 1, (int)x_max);
+        const int iy0 = max(0, (int)y_min), iy1 = min(is - 1, (int)y_max);
+        const int wid = ix1 - ix0 + 1;
+        const long npix = (ix1 < ix0 || iy1 < iy0) ? 0 : (long)wid * (iy1 - iy0 + 1);
+        const size_t mbase = (size_t)bn * is * is;
+        for (long idx = lane; idx < npix; idx += 64) {
+            const int yi = iy0 + (int)(idx / wid), xi = ix0 + (int)(idx % wid);           // lanes along rows
+            const size_t i = mbase + (size_t)yi * is + xi;
+            if (face_index_map[i] != fn) continue;
+            if (p.return_depth) {                                                          // N3K:768-779
+                const float depth = depth_map[i], depth2 = depth * depth, gd = grad_depth_map[i];
+                const float* finv = face_inv_map + 9 * i;
+                const float* w = weight_map + 3 * i;
+                for (int k = 0; k < 3; k++) {
+                    const float zk = f[3 * k + 2];
+                    g[3 * k + 2] += gd * w[k] * depth2 / (zk * zk);
+                }
+                float tmp[3] = {0.f, 0.f, 0.f};
+                for (int k = 0; k < 3; k++)
+                    for (int l = 0; l < 3; l++) tmp[k] += -finv[3 * l + k] / f[3 * l + 2];
+                for (int k = 0; k < 3; k++)
+                    for (int l = 0; l < 2; l++) g[3 * k + l] += -gd * tmp[l] * w[k] * depth2 * is / 2;
+            }
+            if (p.return_rgb) {                                                            // N3K:685-692
+                const float g0 = grad_rgb_map[3 * i], g1 = grad_rgb_map[3 * i + 1], g2 = grad_rgb_map[3 * i + 2];
+#pragma unroll
+                for (int pn = 0; pn < 8; pn++) {
+                    const float w = sampling_weight_map[8 * i + pn];
+                    float* t = acc + sampling_index_map[8 * i + pn] * 3;
+                    atomicAdd(t, w * g0); atomicAdd(t + 1, w * g1); atomicAdd(t + 2, w * g2);
+                }
+            }
+        }
+    }
+    if (p.return_depth) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float v = g[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && v != 0.f) grad_faces[(size_t)wave * 9 + k] += v;
+        }
+    }
+    if (ntex) {
+        __builtin_amdgcn_s_waitcnt(0);      // this wavefront's LDS atomics have landed (single-wave ownership)
+        float* gt = grad_textures + (size_t)wave * ntex;
+        for (int k = lane; k < ntex; k += 64) gt[k] = acc[k];
+    }
+}
+
 static N3Params make_n3(int B, int NF, int TS, int IS, float near_, float far_, float eps, const float* bg,
                         int rrgb, int ralpha, int rdepth) {
     N3Params p;
@@ -365,11 +448,17 @@ void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* fac
     if (rrgb || ralpha)
         k_n3mr_backward_pixel_map<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(
             p, faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces);
-    if (rrgb) {
-        (void)hipMemsetAsync(grad_textures, 0, sizeof(float) * (size_t)B * NF * TS * TS * TS * 3, st);
-        k_n3mr_backward_textures<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(
-            p, face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures);
+    if (!rrgb && !rdepth) return;
+    if (!rrgb || (size_t)TS * TS * TS * 3 <= (size_t)N3_TEX_LDS) {
+        k_n3mr_backward_face<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(
+            p, faces, face_index_map, depth_map, face_inv_map, weight_map, sampling_weight_map, sampling_index_map,
+            grad_rgb_map, grad_depth_map, grad_faces, grad_textures);
+        return;
     }
+    // texture cubes too large for the per-wavefront LDS accumulators: per-pixel kernels with global atomics
+    (void)hipMemsetAsync(grad_textures, 0, sizeof(float) * (size_t)B * NF * TS * TS * TS * 3, st);
+    k_n3mr_backward_textures<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(
+        p, face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures);
     if (rdepth)
         k_n3mr_backward_depth<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(
             p, faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces);

@@ -54,7 +54,8 @@ def test_n3mr_golden(path):
            (z["grad_faces"].reshape(z["faces"].shape[0], -1, 3, 3), z["grad_textures"]))
 
 
-@pytest.mark.parametrize("nf,IS,ts", [(280, 64, 2), (3300, 128, 3), (3300, 256, 2)])
+@pytest.mark.parametrize("nf,IS,ts", [(280, 64, 2), (3300, 128, 3), (3300, 256, 2),
+                                       (280, 48, 9)])   # ts=9: texel gradients beyond the LDS accumulators
 def test_n3mr_vs_reference_build(nf, IS, ts):
     from oracle import N3mrOracle
     try:
