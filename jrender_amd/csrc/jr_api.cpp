@@ -51,6 +51,8 @@ struct jr_ctx {
     int64_t stats[4] = {0, 0, 0, 0};
     unsigned long long* zkey = nullptr;     // n3mr z-buffer keys [B*IS*IS]
     size_t zkey_cap = 0;
+    unsigned char* n3_scratch = nullptr;    // n3mr backward: packed per-pixel planes in both orientations
+    size_t n3_scratch_cap = 0;
     // optional per-phase HIP-event timing (jr_profile_*): pairs of events bracketing each phase
     bool prof_on = false;
     std::vector<hipEvent_t> prof_events;     // pool, reused after every collect
@@ -250,7 +252,7 @@ int jr_ctx_destroy(jr_ctx* ctx) {
         for (void* p : kv.second) (void)hipFree(p);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     jr::BinWorkspace& ws = ctx->ws;
-    (void)hipFree(ctx->zkey);
+    (void)hipFree(ctx->zkey); (void)hipFree(ctx->n3_scratch);
     (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor); (void)hipFree(ws.bin_order);
     (void)hipFree(ws.counters); (void)hipFree(ws.pool); (void)hipFree(ws.pool_scratch);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
@@ -495,9 +497,13 @@ int jr_n3mr_backward(jr_ctx* ctx, const float* faces, const int32_t* face_index_
     if (return_depth && (!depth_map || !face_inv_map || !weight_map || !grad_depth_map))
         return fail("jr_n3mr_backward: return_depth needs depth / face_inv / weight maps and grad_depth_map");
     JR_HIP(hipSetDevice(ctx->device));
+    if (return_rgb || return_alpha) {
+        const size_t need = jr::n3mr_backward_scratch_bytes(B, IS);
+        if (need > ctx->n3_scratch_cap && grow(ctx->n3_scratch, ctx->n3_scratch_cap, need, 1.0)) return 1;
+    }
     jr::launch_n3mr_backward(ctx->stream, faces, face_index_map, weight_map, depth_map, face_inv_map, rgb_map,
                              alpha_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_alpha_map,
-                             grad_depth_map, grad_faces, grad_textures, B, NF, TS, IS, eps, return_rgb,
+                             grad_depth_map, grad_faces, grad_textures, ctx->n3_scratch, B, NF, TS, IS, eps, return_rgb,
                              return_alpha, return_depth);
     JR_HIP(hipGetLastError());
     return 0;

@@ -48,8 +48,9 @@ void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* fac
                           const float* weight_map, const float* depth_map, const float* face_inv_map,
                           const float* rgb_map, const float* alpha_map, const float* sampling_weight_map,
                           const int32_t* sampling_index_map, const float* grad_rgb_map, const float* grad_alpha_map,
-                          const float* grad_depth_map, float* grad_faces, float* grad_textures, int B, int NF,
-                          int TS, int IS, float eps, int rrgb, int ralpha, int rdepth);
+                          const float* grad_depth_map, float* grad_faces, float* grad_textures, void* scratch,
+                          int B, int NF, int TS, int IS, float eps, int rrgb, int ralpha, int rdepth);
+size_t n3mr_backward_scratch_bytes(int B, int IS);
 void launch_selftest_rcp(hipStream_t st, unsigned long long* mismatches);
 void launch_selftest_div(hipStream_t st, unsigned long long n, uint32_t seed, unsigned long long* mismatches);
 

@@ -174,103 +174,184 @@ __global__ __launch_bounds__(256) void k_n3mr_resolve(
     for (int k = 0; k < 8; k++) { sampling_index_map[8 * i + k] = sidx[k]; sampling_weight_map[8 * i + k] = swt[k]; }
 }
 
-// NMR's approximate image gradient (N3K:352-610): one wavefront per face.  The scan positions d0
-// crossed by an edge are few, but each one walks up to image_size pixels towards the image border
-// (N3K:450-507) — so the wavefront takes the d0 one after the other and spreads the PIXEL WALK over
-// its 64 lanes (coalesced along rows for axis 1).  Per-lane partial gradients are summed at the end
-// and stored once per face (no atomics, like the reference).
+// ---- NMR's approximate image gradient (N3K:352-610) ---------------------------------------------------
+// For every edge of a face and both image axes the reference walks the scan positions d0 the edge crosses;
+// at each one it compares the pixel just inside the edge with (a) every pixel from the outside neighbour to
+// the image border ("out" walk, only when the inside pixel shows this face) and (b) every pixel of this face
+// from the inside pixel to the opposite edge ("in" walk), and accumulates -max(diff, 0)/(dist +- eps) into the
+// two vertices of the edge, where diff = sum_k (map_k[m] - ref_k) * grad_k[m] over alpha, r, g, b.
+//
+// Organisation here (one wavefront per face):
+//   * a per-pixel PACK pass writes S[m] = sum_k map_k[m]*grad_k[m] and the four gradients as one float4 + one
+//     float, in row-major AND column-major order, so that diff = S[m] - sum_k ref_k*grad_k[m] costs two loads
+//     per visited pixel and every walk is contiguous in memory whichever axis it runs along (the column walks
+//     of the reference touch one cache line per pixel);
+//   * lanes = scan positions for the set-up (cross points, inside/outside pixels, divisions) and for the short
+//     "in" walks (each lane walks its own scan line);
+//   * the long "out" walks take the scan lines one after the other and spread the PIXEL walk over the 64 lanes;
+//   * gradient-only arithmetic in float with v_rcp_f32 (the reference promotes dist to double and divides);
+//     per-lane partial sums are reduced once per face and stored without atomics, like the reference.
+struct N3Planes {
+    const float4* sg;        // (S, g_alpha, g_r, g_g)
+    const float* gb;         // g_b
+    const int32_t* fidx;
+};
+
+__global__ __launch_bounds__(256) void k_n3mr_pack(
+    N3Params p, const int32_t* __restrict__ face_index_map, const float* __restrict__ rgb_map,
+    const float* __restrict__ alpha_map, const float* __restrict__ grad_rgb_map,
+    const float* __restrict__ grad_alpha_map, float4* __restrict__ sg, float* __restrict__ gb,
+    float4* __restrict__ sg_t, float* __restrict__ gb_t, int32_t* __restrict__ fidx_t) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long pp = (long)p.IS * p.IS;
+    if (i >= p.B * pp) return;
+    float S = 0.f, ga = 0.f, g[3] = {0.f, 0.f, 0.f};
+    if (p.return_alpha) { ga = grad_alpha_map[i]; S += alpha_map[i] * ga; }
+    if (p.return_rgb)
+        for (int k = 0; k < 3; k++) { g[k] = grad_rgb_map[3 * i + k]; S += rgb_map[3 * i + k] * g[k]; }
+    const float4 v = make_float4(S, ga, g[0], g[1]);
+    sg[i] = v; gb[i] = g[2];
+    const long bn = i / pp, r = i - bn * pp;
+    const int y = (int)(r / p.IS), x = (int)(r - (long)y * p.IS);
+    const long it = bn * pp + (long)x * p.IS + y;
+    sg_t[it] = v; gb_t[it] = g[2]; fidx_t[it] = face_index_map[i];
+}
+
+struct N3Ref { float a, c0, c1, c2; };       // the reference pixel of a walk (alpha, r, g, b)
+
+__device__ inline float n3_diff(const float4 v, float gbv, const N3Ref& r) {
+    return v.x - (((r.a * v.y + r.c0 * v.z) + r.c1 * v.w) + r.c2 * gbv);
+}
+
+// -= diff / (dist +- eps) for the two vertices of the edge (N3K:496-505, :583-592)
+__device__ inline void n3_push(float diff, int d1, float cross, float ta, float tb, bool ha, bool hb,
+                               float two_over_is, float eps, float& acc_a, float& acc_b) {
+    const float dd = (float)d1 - cross;
+    if (ha) {
+        float dist = ta * dd * two_over_is;
+        dist = (0 < dist) ? dist + eps : dist - eps;
+        acc_a -= diff * __builtin_amdgcn_rcpf(dist);
+    }
+    if (hb) {
+        float dist = tb * dd * two_over_is;
+        dist = (0 < dist) ? dist + eps : dist - eps;
+        acc_b -= diff * __builtin_amdgcn_rcpf(dist);
+    }
+}
+
+__device__ inline float n3_bcast(float v, int s) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s));
+}
+
+// One (edge, axis) of one face.  q = the edge's two vertices and the opposite one in pixel coordinates with
+// the walking axis second; `in` = planes in which consecutive scan positions are contiguous (lane = scan
+// line), `out` = planes in which consecutive walk positions are contiguous (lane = walk position).
+__device__ inline void n3_edge_axis(const N3Params& p, int axis, const float (&q)[3][2], int fn, size_t mbase,
+                                    const int32_t* __restrict__ face_index_map,
+                                    const float* __restrict__ rgb_map, const float* __restrict__ alpha_map,
+                                    const N3Planes& in, const N3Planes& out, int lane, float& acc_a, float& acc_b) {
+    const int is = p.IS;
+    const float q00 = q[0][0], q01 = q[0][1], q10 = q[1][0], q11 = q[1][1], q20 = q[2][0], q21 = q[2][1];
+    const int direction = axis == 0 ? (q00 < q10 ? -1 : 1) : (q00 < q10 ? 1 : -1);         // N3K:407-411
+    const int d0_from = (int)fmax((double)ceilf(fminf(q00, q10)), 0.);
+    const int d0_to = (int)fmin((double)fmaxf(q00, q10), is - 1.);
+    const float e10 = q10 - q00;
+    const float slope = (q11 - q01) / e10;
+    const float s20 = (q21 - q01) / (q20 - q00), s12 = (q11 - q21) / (q10 - q20);
+    const float two_over_is = 2.f / is;
+    const bool use_rgb = p.return_rgb, use_a = p.return_alpha;
+    for (int c0 = d0_from; c0 <= d0_to; c0 += 64) {
+        // ---- lane = scan position ----
+        const int d0 = c0 + lane;
+        const float d1_cross = slope * (d0 - q00) + q01;
+        const int d1_in = 0 < direction ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+        const int d1_out = d1_in + direction;
+        const bool ok = d0 <= d0_to && !(d1_in < 0 || is <= d1_in) && !(d1_out < 0 || is <= d1_out);
+        const bool ha = q10 != d0, hb = q00 != d0;
+        const float ta = e10 / (q10 - d0), tb = e10 / (d0 - q00);
+        N3Ref rin = {0.f, 0.f, 0.f, 0.f}, rout = {0.f, 0.f, 0.f, 0.f};
+        int fin = -1, from = 1, to = 0;
+        if (ok) {
+            const size_t idx_in = mbase + (axis == 0 ? (size_t)d1_in * is + d0 : (size_t)d0 * is + d1_in);
+            const size_t idx_out = mbase + (axis == 0 ? (size_t)d1_out * is + d0 : (size_t)d0 * is + d1_out);
+            fin = face_index_map[idx_in];
+            if (use_a) { rin.a = alpha_map[idx_in]; rout.a = alpha_map[idx_out]; }
+            if (use_rgb) {
+                rin.c0 = rgb_map[idx_in * 3]; rin.c1 = rgb_map[idx_in * 3 + 1]; rin.c2 = rgb_map[idx_in * 3 + 2];
+                rout.c0 = rgb_map[idx_out * 3]; rout.c1 = rgb_map[idx_out * 3 + 1]; rout.c2 = rgb_map[idx_out * 3 + 2];
+            }
+            const float cross2 = ((d0 - q00) * (d0 - q20) < 0) ? s20 * (d0 - q00) + q01 : s12 * (d0 - q20) + q21;
+            const int d1_limit = 0 < direction ? (int)ceilf(cross2) : (int)floorf(cross2);    // N3K:520-528
+            from = max(min(d1_in, d1_limit), 0);
+            to = min(max(d1_in, d1_limit), is - 1);
+        }
+        // ---- "in" walk: every lane walks its own scan line (contiguous across lanes in the `in` planes) ----
+        for (int k = 0; ballot(from + k <= to) != 0ull; k++) {
+            const int d1 = from + k;
+            if (d1 > to) continue;
+            const size_t m = mbase + (size_t)d1 * is + d0;
+            if (in.fidx[m] != fn) continue;
+            const float diff = n3_diff(in.sg[m], in.gb[m], rout);
+            if (diff <= 0) continue;
+            n3_push(diff, d1, d1_cross, ta, tb, ha, hb, two_over_is, p.eps, acc_a, acc_b);
+        }
+        // ---- "out" walks: scan lines one after the other, the pixel walk spread over the lanes ----
+        unsigned long long vis = ballot(ok && fin == fn);
+        while (vis) {
+            const int s = __builtin_ctzll(vis);
+            vis &= vis - 1;
+            const int bd0 = c0 + s;
+            const int b_out = __builtin_amdgcn_readlane(d1_out, s);
+            const float b_cross = n3_bcast(d1_cross, s), b_ta = n3_bcast(ta, s), b_tb = n3_bcast(tb, s);
+            const bool b_ha = q10 != bd0, b_hb = q00 != bd0;
+            const N3Ref r = {n3_bcast(rin.a, s), n3_bcast(rin.c0, s), n3_bcast(rin.c1, s), n3_bcast(rin.c2, s)};
+            const int d1_limit = 0 < direction ? is - 1 : 0;
+            const int wf = max(min(b_out, d1_limit), 0), wt = min(max(b_out, d1_limit), is - 1);
+            for (int d1 = wf + lane; d1 <= wt; d1 += 64) {
+                const size_t m = mbase + (size_t)bd0 * is + d1;
+                const float diff = n3_diff(out.sg[m], out.gb[m], r);
+                if (diff <= 0) continue;
+                n3_push(diff, d1, b_cross, b_ta, b_tb, b_ha, b_hb, two_over_is, p.eps, acc_a, acc_b);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_n3mr_backward_pixel_map(
     N3Params p, const float* __restrict__ faces, const int32_t* __restrict__ face_index_map,
     const float* __restrict__ rgb_map, const float* __restrict__ alpha_map,
-    const float* __restrict__ grad_rgb_map, const float* __restrict__ grad_alpha_map,
-    float* __restrict__ grad_faces) {
+    N3Planes rowmajor, N3Planes colmajor, float* __restrict__ grad_faces) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= p.B * p.NF) return;
     const int bn = wave / p.NF, fn = wave - bn * p.NF;
     const int is = p.IS;
     const float* face = faces + (size_t)wave * 9;
     if ((face[7] - face[1]) * (face[3] - face[0]) < (face[4] - face[1]) * (face[6] - face[0])) return;
-    const bool use_rgb = p.return_rgb, use_a = p.return_alpha;
     const size_t mbase = (size_t)bn * is * is;
     float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
+#pragma unroll
     for (int edge = 0; edge < 3; edge++) {
         const int pi0 = edge % 3, pi1 = (edge + 1) % 3, pi2 = (edge + 2) % 3;
         const int pis[3] = {pi0, pi1, pi2};
         float pp_[3][2];
+#pragma unroll
         for (int n = 0; n < 3; n++)
+#pragma unroll
             for (int d = 0; d < 2; d++) pp_[n][d] = 0.5f * (face[3 * pis[n] + d] * is + is - 1);
+#pragma unroll
         for (int axis = 0; axis < 2; axis++) {
             float q[3][2];
+#pragma unroll
             for (int n = 0; n < 3; n++)
+#pragma unroll
                 for (int d = 0; d < 2; d++) q[n][d] = pp_[n][(d + axis) % 2];
-            int direction;
-            if (axis == 0) direction = q[0][0] < q[1][0] ? -1 : 1;
-            else direction = q[0][0] < q[1][0] ? 1 : -1;
-            const int d0_from = (int)fmax((double)ceilf(fminf(q[0][0], q[1][0])), 0.);
-            const int d0_to = (int)fmin((double)fmaxf(q[0][0], q[1][0]), is - 1.);
-            for (int d0 = d0_from; d0 <= d0_to; d0++) {          // wave-uniform
-                const float d1_cross = (q[1][1] - q[0][1]) / (q[1][0] - q[0][0]) * (d0 - q[0][0]) + q[0][1];
-                const int d1_in = 0 < direction ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
-                const int d1_out = d1_in + direction;
-                if (d1_in < 0 || is <= d1_in) continue;
-                if (d1_out < 0 || is <= d1_out) continue;
-                size_t idx_in, idx_out;
-                if (axis == 0) { idx_in = mbase + (size_t)d1_in * is + d0; idx_out = mbase + (size_t)d1_out * is + d0; }
-                else { idx_in = mbase + (size_t)d0 * is + d1_in; idx_out = mbase + (size_t)d0 * is + d1_out; }
-                float a_in = 0.f, a_out = 0.f, c_in[3] = {0.f, 0.f, 0.f}, c_out[3] = {0.f, 0.f, 0.f};
-                if (use_a) { a_in = alpha_map[idx_in]; a_out = alpha_map[idx_out]; }
-                if (use_rgb)
-                    for (int k = 0; k < 3; k++) { c_in[k] = rgb_map[idx_in * 3 + k]; c_out[k] = rgb_map[idx_out * 3 + k]; }
-                const float e10 = q[1][0] - q[0][0];
-                // accumulate -diff/dist into the two vertices of the edge (N3K:496-505, :583-592)
-                auto push = [&](float diff_grad, int d1) {
-                    if (q[1][0] != d0) {
-                        float dist = (float)((double)(e10 / (q[1][0] - d0) * (d1 - d1_cross)) * 2. / is);
-                        dist = (0 < dist) ? dist + p.eps : dist - p.eps;
-                        g[pi0 * 3 + (1 - axis)] -= diff_grad / dist;
-                    }
-                    if (q[0][0] != d0) {
-                        float dist = (float)((double)(e10 / (d0 - q[0][0]) * (d1 - d1_cross)) * 2. / is);
-                        dist = (0 < dist) ? dist + p.eps : dist - p.eps;
-                        g[pi1 * 3 + (1 - axis)] -= diff_grad / dist;
-                    }
-                };
-                // ---- out: from the out-pixel to the image border (N3K:450-507) ----
-                if (face_index_map[idx_in] == fn) {
-                    const int d1_limit = 0 < direction ? is - 1 : 0;
-                    const int d1_from = max(min(d1_out, d1_limit), 0), d1_to = min(max(d1_out, d1_limit), is - 1);
-                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += 64) {
-                        const size_t m = axis == 0 ? mbase + (size_t)d1 * is + d0 : mbase + (size_t)d0 * is + d1;
-                        float diff = 0;
-                        if (use_a) diff += (alpha_map[m] - a_in) * grad_alpha_map[m];
-                        if (use_rgb)
-                            for (int k = 0; k < 3; k++) diff += (rgb_map[m * 3 + k] - c_in[k]) * grad_rgb_map[m * 3 + k];
-                        if (diff <= 0) continue;
-                        push(diff, d1);
-                    }
-                }
-                // ---- in: from the in-pixel to the opposite edge (N3K:510-594) ----
-                {
-                    float cross2;
-                    if ((d0 - q[0][0]) * (d0 - q[2][0]) < 0)
-                        cross2 = (q[2][1] - q[0][1]) / (q[2][0] - q[0][0]) * (d0 - q[0][0]) + q[0][1];
-                    else
-                        cross2 = (q[1][1] - q[2][1]) / (q[1][0] - q[2][0]) * (d0 - q[2][0]) + q[2][1];
-                    const int d1_limit = 0 < direction ? (int)ceilf(cross2) : (int)floorf(cross2);
-                    const int d1_from = max(min(d1_in, d1_limit), 0), d1_to = min(max(d1_in, d1_limit), is - 1);
-                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += 64) {
-                        const size_t m = axis == 0 ? mbase + (size_t)d1 * is + d0 : mbase + (size_t)d0 * is + d1;
-                        if (face_index_map[m] != fn) continue;
-                        float diff = 0;
-                        if (use_a) diff += (alpha_map[m] - a_out) * grad_alpha_map[m];
-                        if (use_rgb)
-                            for (int k = 0; k < 3; k++) diff += (rgb_map[m * 3 + k] - c_out[k]) * grad_rgb_map[m * 3 + k];
-                        if (diff <= 0) continue;
-                        push(diff, d1);
-                    }
-                }
-            }
+            float acc_a = 0.f, acc_b = 0.f;
+            // axis 0: scan positions are columns, walks run along rows  -> in = row-major, out = column-major
+            // axis 1: scan positions are rows, walks run along columns  -> in = column-major, out = row-major
+            n3_edge_axis(p, axis, q, fn, mbase, face_index_map, rgb_map, alpha_map, axis == 0 ? rowmajor : colmajor,
+                         axis == 0 ? colmajor : rowmajor, lane, acc_a, acc_b);
+            g[pi0 * 3 + (1 - axis)] += acc_a;
+            g[pi1 * 3 + (1 - axis)] += acc_b;
         }
     }
 #pragma unroll
@@ -436,18 +517,30 @@ void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textur
                                                                sampling_index_map, sampling_weight_map);
 }
 
+size_t n3mr_backward_scratch_bytes(int B, int IS) { return (size_t)B * IS * IS * (2 * 16 + 2 * 4 + 4); }
+
 void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* face_index_map,
                           const float* weight_map, const float* depth_map, const float* face_inv_map,
                           const float* rgb_map, const float* alpha_map, const float* sampling_weight_map,
                           const int32_t* sampling_index_map, const float* grad_rgb_map, const float* grad_alpha_map,
-                          const float* grad_depth_map, float* grad_faces, float* grad_textures, int B, int NF,
-                          int TS, int IS, float eps, int rrgb, int ralpha, int rdepth) {
+                          const float* grad_depth_map, float* grad_faces, float* grad_textures, void* scratch,
+                          int B, int NF, int TS, int IS, float eps, int rrgb, int ralpha, int rdepth) {
     const N3Params p = make_n3(B, NF, TS, IS, 0.f, 0.f, eps, nullptr, rrgb, ralpha, rdepth);
     const long P = (long)B * IS * IS, waves = (long)B * NF;
     (void)hipMemsetAsync(grad_faces, 0, sizeof(float) * (size_t)B * NF * 9, st);
-    if (rrgb || ralpha)
+    if (rrgb || ralpha) {
+        // scratch (n3mr_backward_scratch_bytes): [sg | sg_t] float4, [gb | gb_t] float, fidx_t int32
+        float4* sg = static_cast<float4*>(scratch);
+        float4* sg_t = sg + P;
+        float* gb = reinterpret_cast<float*>(sg_t + P);
+        float* gb_t = gb + P;
+        int32_t* fidx_t = reinterpret_cast<int32_t*>(gb_t + P);
+        k_n3mr_pack<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(p, face_index_map, rgb_map, alpha_map, grad_rgb_map,
+                                                                grad_alpha_map, sg, gb, sg_t, gb_t, fidx_t);
+        const N3Planes rowmajor = {sg, gb, face_index_map}, colmajor = {sg_t, gb_t, fidx_t};
         k_n3mr_backward_pixel_map<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(
-            p, faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces);
+            p, faces, face_index_map, rgb_map, alpha_map, rowmajor, colmajor, grad_faces);
+    }
     if (!rrgb && !rdepth) return;
     if (!rrgb || (size_t)TS * TS * TS * 3 <= (size_t)N3_TEX_LDS) {
         k_n3mr_backward_face<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(

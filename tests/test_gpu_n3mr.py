@@ -55,7 +55,8 @@ def test_n3mr_golden(path):
 
 
 @pytest.mark.parametrize("nf,IS,ts", [(280, 64, 2), (3300, 128, 3), (3300, 256, 2),
-                                       (280, 48, 9)])   # ts=9: texel gradients beyond the LDS accumulators
+                                       (280, 48, 9),     # ts=9: texel gradients beyond the LDS accumulators
+                                       (39000, 512, 2)]) # the bench mesh (78 000 faces with fill_back), walks of 500 px
 def test_n3mr_vs_reference_build(nf, IS, ts):
     from oracle import N3mrOracle
     try:
