@@ -85,6 +85,25 @@ def test_fast_division_identity(ctx):
     assert ctx.selftest_reciprocal() == 0
 
 
+def test_pool_growth_and_standalone_backward(port):
+    """Fresh context: the first forward has no pair pool (non-speculative path), the second scene needs a
+    bigger one than the first left behind (speculative launch is refused on the device, the host regrows
+    and launches again), the third fits (speculative launch is the real one).  Then a backward on a context
+    whose face records belong to another scene (rebuilds them without the lists)."""
+    ctx = _ffi.Context(0)
+    small = syn.sphere_views(280, 1)
+    big = syn.triangle_soup(3000, 2, seed=11, scale=3.0)
+    for fv, tex, size in ((small[0], small[1], 48), (big[0], big[1], 96), (small[0], small[1], 48)):
+        ref, fn = run_case(ctx, port, fv, tex, image_size=size)
+    # fn belongs to the small scene; render the big one in between, then differentiate the small one again
+    other = SoftRasterizeFunction(image_size=96, ctx=ctx)
+    other(big[0], big[1])
+    g = np.random.default_rng(3).uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
+    gf, gt = fn.grad(g)
+    gfo, gto = port.backward(ref, g)
+    assert grad_err(gf.numpy().reshape(gfo.shape), gfo) <= 1e-4 and grad_err(gt.numpy(), gto) <= 1e-4
+
+
 def test_default_sphere(ctx, port):
     run_case(ctx, port, *syn.sphere_views(280, 2), image_size=64)
 
