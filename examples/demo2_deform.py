@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Mesh deformation from silhouettes — the workload of the reference's demo2-deform.py (BASELINE.json
+configs[3]) on the HIP SoftRas path, with the backward chain written out (no autograd framework):
+
+    displace, center --(sigmoid/tanh parametrisation, demo2-deform.py:35-41)--> vertices
+      --look_at + perspective--> face_vertices --SoftRas (HIP)--> silhouettes --neg-IoU loss
+      + 0.03 Laplacian + 0.0003 flatten regularisers;   Adam(0.01, betas=(0.5, 0.99))
+
+    python examples/demo2_deform.py [--iters 200] [--batch-size 64] [-i source.npy -c camera.npy]
+    python -m torch.distributed.run --nproc-per-node 8 examples/demo2_deform.py   # views sharded over GPUs
+
+Without -i/-c (the reference's data files are not shipped here) the target is synthetic: silhouettes of a
+squashed, shifted ellipsoid seen from a ring of cameras.  With several ranks every rank renders its slice of
+the views; the vertex gradient (the mesh is shared by all views) is summed with one all-reduce.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import jrender_amd as jr                                                     # noqa: E402
+from jrender_amd.parallel import BatchShards                                 # noqa: E402
+
+
+class Model:
+    """demo2-deform.py:17-47 with an explicit backward."""
+
+    def __init__(self, vertices, faces):
+        self.vertices = (np.asarray(vertices, np.float32) * 0.5)[None]      # [1,nv,3], |v| < 1
+        self.faces = np.asarray(faces, np.int32)[None]
+        self.displace = np.zeros_like(self.vertices)
+        self.center = np.zeros((1, 1, 3), np.float32)
+        self.laplacian_loss = jr.LaplacianLoss(self.vertices[0], self.faces[0])
+        self.flatten_loss = jr.FlattenLoss(self.faces[0])
+
+    def parameters(self):
+        return [self.displace, self.center]
+
+    def forward(self):
+        a = np.abs(self.vertices)
+        with np.errstate(divide="ignore"):
+            base = np.log(a / (1 - a))
+        self._c = np.tanh(self.center)
+        self._s = 1.0 / (1.0 + np.exp(-(base + self.displace)))
+        self._sign = np.sign(self.vertices)
+        u = self._s * self._sign
+        self._u = u
+        v = np.maximum(u, 0) * (1 - self._c) - np.maximum(-u, 0) * (self._c + 1) + self._c
+        return v.astype(np.float32)
+
+    def backward(self, g):
+        """g = d(loss)/d(vertices) [1,nv,3] -> (d/d displace, d/d center)."""
+        u, c = self._u, self._c
+        g_c = (g * (1 - np.maximum(u, 0) - np.maximum(-u, 0))).sum(1, keepdims=True)
+        g_u = g * ((u > 0) * (1 - c) + (u < 0) * (c + 1))
+        g_disp = g_u * self._sign * self._s * (1 - self._s)
+        return g_disp.astype(np.float32), (g_c * (1 - c * c)).astype(np.float32)
+
+
+def synthetic_target(renderer, template_v, faces, n_views):
+    """Silhouettes of an ellipsoid (semi-axes 0.45, 0.2, 0.3, shifted) from a ring of cameras."""
+    dist = np.full(n_views, 2.732, np.float32)
+    elev = np.where(np.arange(n_views) % 2 == 0, 30.0, -20.0).astype(np.float32)
+    azim = (np.arange(n_views, dtype=np.float32) * 360.0 / n_views)
+    cameras = np.stack([dist, elev, azim], 1)
+    v = template_v * np.asarray([0.45, 0.2, 0.3], np.float32) + np.asarray([0.1, 0.05, 0.0], np.float32)
+    renderer.transform.set_eyes_from_angles(dist, elev, azim)
+    mesh = jr.Mesh(np.broadcast_to(v[None], (n_views,) + v.shape).copy(), np.broadcast_to(faces[None], (n_views,) + faces.shape).copy())
+    sil = renderer.render_mesh(mesh, mode='silhouettes').numpy()
+    return sil.reshape(n_views, sil.shape[-2], sil.shape[-1]), cameras
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('-i', '--filename-input', default=None, help="reference-format source.npy [N,4,64,64] uint8")
+    ap.add_argument('-c', '--camera-input', default=None, help="reference-format camera.npy [N,3] (distance, elevation, azimuth)")
+    ap.add_argument('-b', '--batch-size', type=int, default=64)
+    ap.add_argument('--iters', type=int, default=200)
+    ap.add_argument('--image-size', type=int, default=64)
+    ap.add_argument('-o', '--output', default=None, help="write the optimised mesh to this .obj")
+    ap.add_argument('--quiet', action='store_true')
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    shards = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.device_count() >= world:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+        shards = BatchShards()
+
+    tv, tf = jr.synthetic.uv_sphere(52, 27)                                   # 1 352-vertex class template (sphere_1352)
+    model = Model(tv, tf)
+    renderer = jr.Renderer(image_size=args.image_size, sigma_val=1e-4, aggr_func_rgb='hard', camera_mode='look_at',
+                           viewing_angle=15, dr_type='softras', bin_size=16, max_elems_per_bin=2700,
+                           max_faces_per_pixel_for_grad=16)
+    if args.filename_input and args.camera_input:
+        images = np.load(args.filename_input).astype(np.float32) / 255.
+        cameras = np.load(args.camera_input).astype(np.float32)
+        target = images[:args.batch_size, 3]
+        cameras = cameras[:args.batch_size]
+    else:
+        target, cameras = synthetic_target(renderer, tv, tf, args.batch_size)
+    B = target.shape[0]
+    lo, hi = (0, B) if shards is None else shards.bounds(B)[shards.rank]
+    renderer.transform.set_eyes_from_angles(cameras[lo:hi, 0], cameras[lo:hi, 1], cameras[lo:hi, 2])
+    optimizer = jr.Adam(model.parameters(), 0.01, betas=(0.5, 0.99))
+
+    t0 = time.time()
+    history = []
+    for it in range(args.iters):
+        vertices = model.forward()                                            # [1,nv,3]
+        nb = hi - lo
+        mesh = jr.Mesh(np.repeat(vertices, nb, 0), np.repeat(model.faces, nb, 0))
+        pred = renderer.render_mesh(mesh, mode='silhouettes').numpy().reshape(nb, args.image_size, args.image_size)
+        # neg-IoU over ALL views: per-view IoUs are independent, so the local part is (1/B) * sum over local views
+        inter = (pred * target[lo:hi]).sum((1, 2))
+        union = (pred + target[lo:hi] - pred * target[lo:hi]).sum((1, 2)) + 1e-6
+        iou_sum = float((inter / union).sum())
+        g_sil = jr.neg_iou_loss_backward(pred, target[lo:hi]) * (nb / B)      # that helper averages over its own batch
+        g_v = renderer.grad_vertices(grad_silhouettes=g_sil.reshape(nb, 1, args.image_size, args.image_size)).sum(0, keepdims=True)
+        if shards is not None:
+            g_v = shards.all_reduce_sum(g_v)
+            iou_sum = float(shards.all_reduce_sum(np.asarray([iou_sum], np.float32))[0])
+        lap = float(np.mean(model.laplacian_loss(vertices)))
+        flat = float(np.mean(model.flatten_loss(vertices)))
+        loss = (1.0 - iou_sum / B) + 0.03 * lap + 0.0003 * flat
+        g_v = g_v + 0.03 * model.laplacian_loss.backward(vertices) + 0.0003 * model.flatten_loss.backward(vertices)
+        optimizer.step(model.backward(g_v))
+        history.append(loss)
+        if rank == 0 and not args.quiet and (it % 20 == 0 or it == args.iters - 1):
+            print("iter %4d  loss %.4f  (1-IoU %.4f, laplacian %.4f, flatten %.4f)" % (it, loss, 1.0 - iou_sum / B, lap, flat), flush=True)
+    if rank == 0 and not args.quiet:
+        print("%d iterations, %d views on %d rank(s): %.2f s" % (args.iters, B, world, time.time() - t0))
+    if rank == 0 and args.output:
+        jr.save_obj(args.output, model.forward()[0], model.faces[0])
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return history
+
+
+if __name__ == '__main__':
+    main()

@@ -8,6 +8,7 @@ from .structures import *          # noqa: F401,F403
 from .renderer import *            # noqa: F401,F403
 from .loss import *                # noqa: F401,F403
 from .io import *                  # noqa: F401,F403
+from .optim import Adam            # noqa: F401
 from . import synthetic            # noqa: F401
 
 __version__ = "0.1"

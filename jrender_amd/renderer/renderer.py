@@ -4,7 +4,10 @@ Same constructor keywords and defaults, ``render_mesh(mesh, mode)``, ``execute(v
 textures, ...)``, ``set_sigma / set_gamma / set_texture_mode``.  ``dr_type='softras'`` drives the
 HIP SoftRas kernels, ``dr_type='n3mr'`` the HIP NMR kernels (with NMR's own near/far/eps, REN:46).
 """
+import numpy as np
+
 from ..structures import Mesh
+from ..structures.mesh import face_vertices_backward
 from .dr import N3mrRasterizer, SoftRasterizer
 from .lighting import Lighting
 from .transform import Transform
@@ -52,9 +55,26 @@ class Renderer:
 
     def render_mesh(self, mesh, mode='rgb'):
         self.set_texture_mode(mesh.texture_type)
-        mesh = self.lighting(mesh, self.transform.eyes)
+        if mode != 'silhouettes':           # lighting only rewrites the textures (REN:57): no effect on alpha
+            mesh = self.lighting(mesh, self.transform.eyes)
+        self._world_vertices, self._faces = np.array(mesh.vertices, np.float32), mesh.faces
         mesh = self.transform(mesh)
         return self.rasterizer(mesh, mode)
+
+    def grad_vertices(self, grad_silhouettes=None, grad_rgb=None):
+        """d(loss)/d(world-space vertices) [B,nv,3] of the last ``render_mesh`` (softras, look_at camera)
+        for upstream image gradients: rasteriser backward (HIP) -> scatter of the face-vertex gradients to
+        the vertices -> camera transform VJP.  The reference gets this chain from Jittor autograd."""
+        if self.dr_type != 'softras' or not hasattr(self.transform.transformer, 'backward'):
+            raise NotImplementedError("grad_vertices: softras rasteriser with a look_at camera only")
+        gfv, _ = self.rasterizer.backward(grad_silhouettes=grad_silhouettes, grad_rgb=grad_rgb)
+        v = self._world_vertices
+        nf = np.asarray(self._faces).shape[-2]
+        gfv = gfv.numpy().reshape(v.shape[0], -1, 3, 3)
+        if gfv.shape[1] == 2 * nf:          # fill_back doubled the faces: (f, f reversed) -> fold back
+            gfv = gfv[:, :nf] + gfv[:, nf:, ::-1]
+        gndc = face_vertices_backward(gfv, self._faces, v.shape[1])
+        return self.transform.transformer.backward(gndc, v)
 
     def execute(self, vertices, faces, textures=None, mode='rgb', texture_type='surface',
                 metallic_textures=None, roughness_textures=None):

@@ -24,8 +24,7 @@ def face_vertices(vertices, faces):
     assert vertices.shape[0] == faces.shape[0]
     assert faces.shape[2] == 3
     idx = faces.astype(np.int64)
-    return np.take_along_axis(vertices[:, :, None, :], idx.reshape(idx.shape[0], -1, 1, 1), axis=1) \
-        .reshape(idx.shape[0], idx.shape[1], 3, vertices.shape[2])
+    return vertices[np.arange(idx.shape[0])[:, None, None], idx]           # [B,NF,3,C]
 
 
 def face_vertices_backward(grad_fv, faces, num_vertices):
@@ -33,10 +32,11 @@ def face_vertices_backward(grad_fv, faces, num_vertices):
     grad_fv = np.asarray(grad_fv, F32)
     faces = np.asarray(faces).astype(np.int64)
     B, NF = faces.shape[:2]
-    out = np.zeros((B, num_vertices, grad_fv.shape[-1]), np.float64)
-    for b in range(B):
-        np.add.at(out[b], faces[b].reshape(-1), grad_fv[b].reshape(NF * 3, -1))
-    return out.astype(F32)
+    C = grad_fv.shape[-1]
+    flat = (faces + (np.arange(B, dtype=np.int64) * num_vertices)[:, None, None]).reshape(-1)
+    g = grad_fv.reshape(B * NF * 3, C)
+    out = np.stack([np.bincount(flat, weights=g[:, c], minlength=B * num_vertices) for c in range(C)], -1)
+    return out.reshape(B, num_vertices, C).astype(F32)
 
 
 def _normalize(v, eps, axis):

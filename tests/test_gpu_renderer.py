@@ -85,3 +85,17 @@ def test_demo2_style_silhouette_fitting_reduces_loss():
         gscale = (gworld * v[None]).sum((0, 2))
         scale = scale - 0.5 * gscale / (np.abs(gscale).max() + 1e-12) * 0.05
     assert losses[-1] < losses[0] * 0.7, losses
+
+
+def test_demo2_deform_example_reduces_loss():
+    """examples/demo2_deform.py (reference demo2-deform.py: sigmoid/tanh vertex parametrisation, neg-IoU +
+    Laplacian + flatten, Adam) on a synthetic target: the loss must fall and the mesh stay finite."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "demo2_deform.py")
+    spec = importlib.util.spec_from_file_location("demo2_deform", path)
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    hist = demo.main(["--iters", "60", "--batch-size", "8", "--quiet"])
+    assert np.isfinite(hist).all()
+    assert hist[-1] < 0.8 * hist[0], (hist[0], hist[-1])

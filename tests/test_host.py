@@ -132,3 +132,55 @@ def test_validation_without_gpu():
     with pytest.raises(ValueError):
         jr.Renderer(dr_type="raytrace")
     assert jr.SoftRenderer is jr.Renderer
+
+
+def _load_demo2():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "demo2_deform.py")
+    spec = importlib.util.spec_from_file_location("demo2_deform", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_adam_matches_closed_form_first_steps_and_converges():
+    import jrender_amd as jr
+    p = np.array([3.0, -2.0], np.float32)
+    opt = jr.Adam([p], lr=0.1, betas=(0.5, 0.99))
+    opt.step([2 * p.copy()])
+    # first Adam step moves every coordinate by lr * sign(g) (bias-corrected m/sqrt(v) = g/|g|)
+    assert np.allclose(p, [2.9, -1.9], atol=1e-6)
+    for _ in range(300):
+        opt.step([2 * p.copy()])
+    assert np.abs(p).max() < 0.05
+    with pytest.raises(TypeError):
+        jr.Adam([np.zeros(2)])                      # float64 is not accepted (updated in place as float32)
+    with pytest.raises(ValueError):
+        opt.step([p, p])
+
+
+def test_deform_model_backward_matches_finite_differences():
+    import jrender_amd as jr
+    demo = _load_demo2()
+    v, f = jr.synthetic.uv_sphere(8, 6)
+    m = demo.Model(v, f)
+    rng = np.random.default_rng(0)
+    m.displace[:] = rng.normal(0, 0.3, m.displace.shape)
+    m.center[:] = rng.normal(0, 0.2, m.center.shape)
+    w = rng.normal(0, 1, (1,) + v.shape).astype(np.float32)
+
+    def loss():
+        return float((m.forward().astype(np.float64) * w).sum())
+    loss()
+    gd, gc = m.backward(w)
+    h = 1e-3
+    for arr, g, picks in ((m.displace, gd, [(0, 3, 1), (0, 10, 2), (0, 20, 0)]), (m.center, gc, [(0, 0, 0), (0, 0, 2)])):
+        for idx in picks:
+            old = arr[idx]
+            arr[idx] = old + h
+            lp = loss()
+            arr[idx] = old - h
+            lm = loss()
+            arr[idx] = old
+            assert abs((lp - lm) / (2 * h) - g[idx]) <= 2e-3 * max(1.0, abs(g[idx]))
