@@ -99,3 +99,26 @@ def test_demo2_deform_example_reduces_loss():
     hist = demo.main(["--iters", "60", "--batch-size", "8", "--quiet"])
     assert np.isfinite(hist).all()
     assert hist[-1] < 0.8 * hist[0], (hist[0], hist[-1])
+
+
+def test_gbuffer_rasterizer_matches_oracle_modes():
+    """render2's caller of the operator: vertex attributes, barycentric distance, hard aggregation (+MSAA)."""
+    from oracle import Oracle
+    port = Oracle("port", nthreads=0)
+    fv, _ = jr.synthetic.sphere_views(280, 1)
+    attr = np.random.default_rng(5).uniform(0, 1, fv.shape[1:]).astype(np.float32)      # [NF,3,3] per-vertex attribute
+    gb = jr.GBufferRasterizer(image_size=48, near=1, far=100, fill_back=True)
+    img = gb.Rasterize(fv[0], attr)
+    ref = port.forward(fv, attr[None], image_size=48, near=1, far=100, texture_type="vertex",
+                       dist_func="barycentric", aggr_func_rgb="hard")
+    assert img.shape == (48, 48, 3)
+    assert np.allclose(img, ref["soft_colors"][0, :3].transpose(1, 2, 0), rtol=1e-4, atol=1e-6)
+    img2 = gb.Rasterize(fv[0], attr, MSAA=True)
+    ref2 = port.forward(fv, attr[None], image_size=96, near=1, far=100, texture_type="vertex",
+                        dist_func="barycentric", aggr_func_rgb="hard")["soft_colors"][0, :3]
+    pooled = ref2.reshape(3, 48, 2, 48, 2).mean((2, 4)).transpose(1, 2, 0)
+    assert np.allclose(img2, pooled, rtol=1e-4, atol=1e-6)
+    depth = gb.Rasterize_depth(fv[0])
+    refd = port.forward(fv, np.ones_like(fv[0])[None], image_size=48, near=1, far=100, texture_type="vertex",
+                        dist_func="hard", aggr_func_rgb="hard")["aggrs_info"][0, 0]
+    assert np.allclose(depth, refd, rtol=1e-6)
