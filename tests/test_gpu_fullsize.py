@@ -118,3 +118,33 @@ def test_mesh_above_bitmap_capacity(image_size, npix):
     assert bits_equal(ids, sub["ids"])
     assert rel_err(rgba, sub["rgba"], RGBA_ATOL) <= 1.0
     assert (ids[:, 0] >= 0).mean() > 0.2
+
+
+def test_soup_scene_random_pixels_and_masked_backward():
+    """north_star's random-triangle batch at full size (39 000 triangles over the whole 1024^2 screen):
+    forward at random pixels and the masked-gradient backward against the oracle."""
+    ctx = _ffi.Context.default()
+    b2 = 2
+    fv, tex = syn.triangle_soup(NF, b2, seed=100)
+    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+    fn(fv, tex)
+    saved = [x.numpy() for x in fn.save_vars]
+    port = Oracle("port", nthreads=0)
+    pix = np.unique(np.random.default_rng(9).choice(b2 * IS * IS, 3000, replace=False))
+    sub = port.forward_subset(fv, tex, pix, image_size=IS, max_faces_per_pixel_for_grad=K)
+    b, r = np.divmod(pix, IS * IS)
+    ids = saved[5].reshape(b2, K, -1)[b, :, r]
+    rgba = saved[2].reshape(b2, 4, -1)[b, :, r]
+    assert bits_equal(saved[3], sub["faces_info"])
+    assert bits_equal(ids, sub["ids"])
+    assert rel_err(rgba, sub["rgba"], RGBA_ATOL) <= 1.0
+    assert 0.5 < (ids[:, 0] >= 0).mean() and (ids[:, 3] >= 0).mean() > 0.2
+    g = np.zeros((b2, 4, IS, IS), np.float32)
+    g.reshape(b2, 4, -1)[b, :, r] = np.random.default_rng(2).uniform(-1, 1, (len(pix), 4))
+    gf, gt = fn.grad(g)
+    s = dict(face_vertices=saved[0].reshape(b2, NF, 9), textures=saved[1], soft_colors=saved[2],
+             faces_info=saved[3], aggrs_info=saved[4], faces_id_buffer=saved[5],
+             params=dict(image_size=IS, max_faces_per_pixel_for_grad=K))
+    gfo, gto = port.backward_subset(s, g, pix)
+    assert grad_err(gf.numpy().reshape(gfo.shape), gfo) <= 1e-4
+    assert grad_err(gt.numpy(), gto) <= 1e-4
