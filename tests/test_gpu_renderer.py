@@ -122,3 +122,29 @@ def test_gbuffer_rasterizer_matches_oracle_modes():
     refd = port.forward(fv, np.ones_like(fv[0])[None], image_size=48, near=1, far=100, texture_type="vertex",
                         dist_func="hard", aggr_func_rgb="hard")["aggrs_info"][0, 0]
     assert np.allclose(depth, refd, rtol=1e-6)
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's contract fields, the roofline and the CPU baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--faces", "280",
+                          "--image-size", "64", "--batch", "2"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "images/s" and c["sample"]
+    assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
