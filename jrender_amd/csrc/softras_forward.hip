@@ -1,20 +1,24 @@
 // SoftRas forward rasteriser for gfx950 (MI355X).
 //
 // Replaces forward_soft_rasterize_cuda_kernel (SRK:243-456).  The reference runs one thread per
-// pixel over ALL faces.  Here ONE WAVEFRONT owns an 8x8-pixel tile (lane = pixel) and walks its
-// 32x32 bin's ascending face list 64 faces at a time with the roles of the lanes switched:
+// pixel over ALL faces.  Here ONE WAVEFRONT owns an 8x8-pixel tile and walks its 32x32 bin's ascending
+// face list with the roles of the lanes switched between phases:
 //
-//   cull  (lane = face)   each lane takes one list entry, drops it unless the entry's tile mask
-//                         has this tile's bit, loads the face's border box and evaluates the
-//                         reference's border test (SRK:28-34) against the tile's 8 column and 8 row
-//                         pixel centres.  Every compare is a v_cmp whose 64-bit result IS the
-//                         wavefront ballot over the 64 faces: 32 compares cull 64 faces x 64 pixels.
-//   stage (lane = face)   surviving faces copy their packed record into LDS.
-//   raster(lane = pixel)  each pixel ANDs its column ballot with its row ballot: a private bitmask
-//                         of the faces that pass ITS border test.  It then pops its own bits in
-//                         ascending face order and runs the per-(pixel,face) arithmetic on the LDS
-//                         record of ITS face — lanes stay busy although neighbouring pixels see
-//                         different face subsets (lane compaction by bitmask).
+//   cull   (lane = list entry)  64 entries at a time: drop an entry unless its tile mask has this tile's
+//                         bit and its border box can touch the tile; survivors copy their packed record
+//                         into LDS, COMPACTED across list chunks (ascending order kept) until 64 slots are
+//                         full — the raster loop's trip count is the maximum over the pixels, and max/mean
+//                         shrinks with the batch.
+//   ballot (lane = slot)  the reference's border test (SRK:28-34) against the tile's 8 column and 8 row
+//                         pixel centres.  Every compare is a v_cmp whose 64-bit result IS the wavefront
+//                         ballot over the 64 slots: 32 compares decide 64 faces x 64 pixels.
+//   raster (lane = pixel) each pixel ANDs its column ballot with its row ballot: a private bitmask of the
+//                         faces that pass ITS border test.  It pops its own bits in ascending face order
+//                         and runs the per-(pixel,face) arithmetic on the LDS record of ITS face — lanes
+//                         stay busy although neighbouring pixels see different face subsets.
+//
+// Tiles are visited heaviest bin first (k_bin_schedule), bins dealt round-robin to the XCDs: the list
+// length varies from 1 to >1000 faces and the launch would otherwise end with a long tail.
 //
 // The per-pixel state machine (alpha, online softmax over depth, K-nearest buffer) lives in VGPRs;
 // it is sequential in face order, which is why the lists are sorted.  No MFMA: no dense contraction.
