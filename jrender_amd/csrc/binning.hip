@@ -346,11 +346,12 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, c
 
 // Every kernel here is guarded by "total pairs <= pool capacity" read from device memory, so that the
 // host can enqueue them BEFORE it knows the total (no pipeline bubble); see build_bins in jr_api.cpp.
-void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws) {
+void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws, bool reset_cursors) {
     const int nfaces = p.B * p.NF;
     const int nbins = p.B * p.bins_x * p.bins_y;
     const unsigned long long cap = ws.pool_cap;
-    (void)hipMemsetAsync(ws.bin_cursor, 0, sizeof(int) * (size_t)nbins, st);
+    // k_bin_alloc left the cursors at zero; only a second attempt (after the pool grew) has to clear them
+    if (reset_cursors) (void)hipMemsetAsync(ws.bin_cursor, 0, sizeof(int) * (size_t)nbins, st);
     k_bin_fill<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.bin_base, ws.bin_cursor, ws.pool_scratch,
                                                      ws.counters, cap);
     if (p.NF <= BITMAP_MAX_FACES) {

@@ -185,16 +185,16 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     JR_HIP(hipMemcpyAsync(ctx->h_counters, ws.counters, sizeof(unsigned long long) * 4,
                           hipMemcpyDeviceToHost, ctx->stream));
     JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));
-    auto enqueue = [&]() {
+    auto enqueue = [&](bool again) {
         {
             ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
-            jr::launch_bin_fill_sort(ctx->stream, p, ws);
+            jr::launch_bin_fill_sort(ctx->stream, p, ws, again);
         }
         ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
         jr::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
     };
     const bool speculative = ws.pool != nullptr && ws.pool_cap > 0;
-    if (speculative) enqueue();
+    if (speculative) enqueue(false);
     JR_HIP(hipEventSynchronize(ctx->ev_counters));
     const size_t pairs = (size_t)ctx->h_counters[0];
     ctx->stats[0] = (int64_t)pairs;
@@ -209,7 +209,7 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
             if (grow(ws.pool_scratch, c1, pairs > 0 ? pairs : 1, 1.25)) return 1;
             ws.pool_cap = c0;
         }
-        enqueue();
+        enqueue(speculative);
     }
     JR_HIP(hipGetLastError());
     return 0;

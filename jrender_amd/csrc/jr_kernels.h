@@ -23,7 +23,7 @@ struct BinWorkspace {
 
 void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, const float* textures,
                     float* faces_info, BinWorkspace& ws);
-void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws);
+void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& ws, bool reset_cursors);
 
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
                             const BinWorkspace& ws, float* aggrs_info, float* soft_colors,
