@@ -55,3 +55,31 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)
                 assert "softras_oracle" not in src and "libsoftras_ref" not in src, os.path.join(d, f)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/jrender_hip.h must be consumable by a C99 compiler (cgo / JNI / any FFI generator) and a C
+    program must link against the library and call it (no GPU needed for jr_version / jr_last_error)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "jrender_amd", "csrc")
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "jrender_hip.h"\n'
+                   'int main(void) {\n'
+                   '    jr_ctx* c = 0;\n'
+                   '    if (strstr(jr_version(), "gfx950") == 0) return 2;\n'
+                   '    /* invalid arguments are rejected with a message, without touching a device */\n'
+                   '    if (jr_softras_forward(c, 0, 0, 0, 0, 0, 0, 1, 1, 1, 8, 1, 1.f, 100.f, 1e-3f, 1e-5f, 2, 9.2f, 1e-4f, 1, 2, 0, 1, 0) == 0) return 3;\n'
+                   '    if (strlen(jr_last_error()) == 0) return 4;\n'
+                   '    printf("%s\\n", jr_version());\n'
+                   '    return 0;\n}\n')
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                    str(src), "-o", str(exe), "-L", lib_dir, "-ljrender_hip", "-Wl,-rpath," + lib_dir],
+                   check=True, capture_output=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert "gfx950" in out.stdout
