@@ -382,10 +382,23 @@ __global__ __launch_bounds__(64) void k_softras_backward(
                     ? backward_pair<DIST, RGB, true>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on)
                     : backward_pair<DIST, RGB, false>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on);
                 if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: straight to global
-                    float* gtx = gtbase + ((size_t)fr.id * p.T + texel) * 3;
-                    atomicAdd(gtx + 0, tgs * q.g0);
-                    atomicAdd(gtx + 1, tgs * q.g1);
-                    atomicAdd(gtx + 2, tgs * q.g2);
+                    float* gtf = gtbase + (size_t)fr.id * p.T * 3;
+                    const float c0 = tgs * q.g0, c1 = tgs * q.g1, c2 = tgs * q.g2;
+                    atomicAdd(gtf + texel * 3 + 0, c0);
+                    atomicAdd(gtf + texel * 3 + 1, c1);
+                    atomicAdd(gtf + texel * 3 + 2, c2);
+                    // The reference adds (texel j sampled ? 1 : 0) * c to EVERY texel j of the face
+                    // (SRK:1317-1320): an overflowed weight (inf, NaN) therefore poisons all of them with
+                    // 0 * inf = NaN.  Reproduced so that the non-finite pattern of the gradients matches.
+                    if (!(isfinite(c0) && isfinite(c1) && isfinite(c2))) {
+                        const float qnan = __builtin_nanf("");
+                        for (int jt = 0; jt < p.T; jt++) {
+                            if (jt == texel) continue;
+                            if (!isfinite(c0)) atomicAdd(gtf + jt * 3 + 0, qnan);
+                            if (!isfinite(c1)) atomicAdd(gtf + jt * 3 + 1, qnan);
+                            if (!isfinite(c2)) atomicAdd(gtf + jt * 3 + 2, qnan);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 9; k++) v[k] = gv[k];

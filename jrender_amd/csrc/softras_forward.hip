@@ -118,22 +118,32 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
                                     const float* __restrict__ tbase, float xp, float yp,
                                     PixelState<KCAP>& s) {
     const Bary w = barycentric(r, xp, yp);
-    float D;
+    float D, neg_num = -1.f;            // neg_num = the sigmoid's numerator, -sign*dis (any negative value for 'hard')
     if (DIST == 0) {                                                           // SRK:331-333
         if (!pixel_inside(w)) return;
         D = 1.f;
     } else if (DIST == 1) {                                                    // SRK:335-338
         const float dis = barycentric_dist(w);
         if (-dis >= p.thr) return;
-        D = coverage_fast(-dis, p);
+        neg_num = -dis;
+        D = coverage_fast(neg_num, p);
     } else {                                                                   // SRK:340-344
         const Dist dd = euclidean_p2f<FAST>(r, w, xp, yp);
         const float dis = dd.dx * dd.dx + dd.dy * dd.dy;
         if (dd.sign < 0 && dis >= p.thr) return;
-        D = coverage_fast(-dd.sign * dis, p);
+        neg_num = -dd.sign * dis;
+        D = coverage_fast(neg_num, p);
     }
     // alpha aggregation happens before the depth cull (SRK:350-358)
-    if (p.alpha == 0) { if (D > 0.5f) s.alpha = 1.f; }
+    if (p.alpha == 0) {
+        // 'hard' alpha is a DECISION (D > 0.5), so it must not ride on the approximate sigmoid.  With the
+        // reference's arithmetic, D = (float)(1/(1 + (double)expf(x))), x = neg_num/sigma (float division),
+        // D > 0.5 holds exactly when x < -1.5 * 2^-24 (monotone; checked float by float around the boundary).
+        const float x = (DIST == 0) ? -1.f
+                      : ((neg_num == 0.f || in_fast_range(neg_num)) ? div_known<FAST>(neg_num, p.sigma, p.r_sigma)
+                                                                     : neg_num / p.sigma);
+        if (x < -8.940696716308594e-08f) s.alpha = 1.f;
+    }
     else if (p.alpha == 1) s.alpha += D;
     else s.alpha = (float)((double)s.alpha * (1. - (double)D));
 

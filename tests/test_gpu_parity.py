@@ -23,7 +23,7 @@ from tests.util import RGBA_ATOL, bits_equal, grad_err, grad_err_elementwise, re
 pytestmark = pytest.mark.gpu
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith("n3mr_"))
+                if not os.path.basename(p).startswith(("n3mr_", "regress_")))
 GRAD_TOL = 1e-4
 
 
@@ -102,6 +102,17 @@ def test_pool_growth_and_standalone_backward(port):
     gf, gt = fn.grad(g)
     gfo, gto = port.backward(ref, g)
     assert grad_err(gf.numpy().reshape(gfo.shape), gfo) <= 1e-4 and grad_err(gt.numpy(), gto) <= 1e-4
+
+
+REGRESS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "regress_*.npz")))
+
+
+@pytest.mark.parametrize("path", REGRESS, ids=[os.path.basename(p)[:-4] for p in REGRESS])
+def test_fuzz_regressions(ctx, port, path):
+    """Inputs found by tests/fuzz_parity.py.  regress_hard_alpha_*: pixels within 1e-7 sigma of an edge, where
+    'hard' alpha (D > 0.5) used to be decided on the approximate sigmoid."""
+    z = np.load(path)
+    run_case(ctx, port, z["fv"], z["tex"], **eval(str(z["kw"])))
 
 
 def test_default_sphere(ctx, port):
