@@ -61,7 +61,7 @@ def check_against(ref, fn, g, ref_grads):
     return status
 
 
-def draw_case(rng):
+def draw_case(rng, big=False):
     kind = rng.choice(["soup", "sphere", "big_faces", "far_soup"])
     B = int(rng.choice([1, 1, 2, 3]))
     texture_type = str(rng.choice(["surface", "surface", "vertex"]))
@@ -71,12 +71,12 @@ def draw_case(rng):
         fv, tex = syn.sphere_views(nf, B, texels=texels, seed=int(rng.integers(1 << 30)), azimuth0=float(rng.uniform(0, 360)),
                                    elevation=float(rng.uniform(-60, 60)))
     else:
-        nf = int(rng.integers(1, 2500))
+        nf = int(rng.integers(1, 12000 if big else 2500))
         scale = {"soup": float(rng.uniform(0.8, 4.0)), "big_faces": float(rng.uniform(8, 30)), "far_soup": float(rng.uniform(1, 3))}[kind]
         fv, tex = syn.triangle_soup(nf, B, seed=int(rng.integers(1 << 30)), texels=texels, scale=scale)
         if kind == "far_soup":
             fv[..., :2] *= float(rng.uniform(1.2, 2.5))            # many faces partly / fully off-screen
-    kw = dict(image_size=int(rng.integers(9, 140)),
+    kw = dict(image_size=int(rng.integers(9, 330 if big else 140)),
               dist_func=str(rng.choice(["euclidean", "euclidean", "barycentric", "hard"])),
               aggr_func_rgb=str(rng.choice(["softmax", "softmax", "hard"])),
               aggr_func_alpha=str(rng.choice(["prod", "sum", "hard"])),
@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-failures", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="up to 12 000 faces and 330^2 pixels (seconds per case in the oracle)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = _ffi.Context.default()
@@ -101,7 +102,7 @@ def main():
     done = skipped = failed = overflowed = illcond = 0
     t0 = time.time()
     for i in range(args.cases):
-        kind, fv, tex, kw = draw_case(rng)
+        kind, fv, tex, kw = draw_case(rng, args.big)
         ref = port.forward(fv, tex, **kw)
         if port.ub_events():
             skipped += 1
