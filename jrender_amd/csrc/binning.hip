@@ -78,7 +78,8 @@ __device__ inline int wave_bin_add(int* __restrict__ arr, int tb) {
     return pos;
 }
 
-__global__ __launch_bounds__(256) void k_face_setup(RasterParams p, const float* __restrict__ faces,
+constexpr int SETUP_WG = 128;      // faces per workgroup of k_face_setup (22 KB of LDS: 7 workgroups per CU in flight)
+__global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const float* __restrict__ faces,
                                                     const float* __restrict__ textures,
                                                     float* __restrict__ faces_info,
                                                     FaceGeo* __restrict__ geo,
@@ -86,12 +87,12 @@ __global__ __launch_bounds__(256) void k_face_setup(RasterParams p, const float*
                                                     int* __restrict__ bin_count) {
     // records leave through LDS so that the global stores are contiguous 16-byte lanes (a thread
     // writing its own 108 B / 176 B record directly touches ~60 cache lines per store instruction)
-    __shared__ __align__(16) float s_out[256 * 44];
+    __shared__ __align__(16) float s_out[SETUP_WG * 44];
     const int total = p.B * p.NF;
-    const int i0 = blockIdx.x * 256;
+    const int i0 = blockIdx.x * SETUP_WG;
     const int i = i0 + threadIdx.x;
     const bool valid = i < total;
-    const int nvalid = min(256, total - i0);
+    const int nvalid = min(SETUP_WG, total - i0);
     const int ic = valid ? i : total - 1;
     const float* f = faces + (size_t)ic * 9;
     float info[27];
@@ -100,9 +101,9 @@ __global__ __launch_bounds__(256) void k_face_setup(RasterParams p, const float*
 #pragma unroll
         for (int k = 0; k < 27; k++) s_out[threadIdx.x * 27 + k] = info[k];
         __syncthreads();
-        float* out = faces_info + (size_t)i0 * 27;                  // 256*108 B per block: 16 B aligned
+        float* out = faces_info + (size_t)i0 * 27;                  // SETUP_WG*108 B per block: 16 B aligned
         const int nfl = nvalid * 27;
-        for (int q = threadIdx.x; q < (nfl >> 2); q += 256)
+        for (int q = threadIdx.x; q < (nfl >> 2); q += SETUP_WG)
             reinterpret_cast<float4*>(out)[q] = reinterpret_cast<const float4*>(s_out)[q];
         if (threadIdx.x < (nfl & 3)) out[(nfl & ~3) + threadIdx.x] = s_out[(nfl & ~3) + threadIdx.x];
         __syncthreads();
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void k_face_setup(RasterParams p, const float*
     __syncthreads();
     {
         float4* out = reinterpret_cast<float4*>(geo + i0);
-        for (int q = threadIdx.x; q < nvalid * 11; q += 256) out[q] = reinterpret_cast<const float4*>(s_out)[q];
+        for (int q = threadIdx.x; q < nvalid * 11; q += SETUP_WG) out[q] = reinterpret_cast<const float4*>(s_out)[q];
     }
 
     int px0, px1, py0, py1;
@@ -339,7 +340,7 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, c
     const int nbins = p.B * p.bins_x * p.bins_y;
     (void)hipMemsetAsync(ws.bin_count, 0, sizeof(int) * (size_t)nbins, st);
     (void)hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * 4, st);
-    k_face_setup<<<(nfaces + 255) / 256, 256, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_count);
+    k_face_setup<<<(nfaces + SETUP_WG - 1) / SETUP_WG, SETUP_WG, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_count);
     k_bin_alloc<<<(nbins + 255) / 256, 256, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.counters);
     k_bin_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_order);
 }
