@@ -191,7 +191,8 @@ def main():
         achieved = ab[dom] / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        profiled = (args.scene, NF, IS, B, K) == ("sphere", 39000, 1024, 8, 16)    # the configuration the PMC passes ran
+        if profiled and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(dom)
             except Exception:
