@@ -47,6 +47,22 @@ def make_port(force=False):
     return PORT_LIB
 
 
+N3MR_PORT_LIB = os.path.join(HERE, "libn3mr_oracle.so")
+
+
+def make_n3mr_port(force=False):
+    """gcc build of oracle/n3mr_oracle.c (the plain-C restatement of the NMR kernels)."""
+    src = os.path.join(HERE, "n3mr_oracle.c")
+    if (not force and os.path.exists(N3MR_PORT_LIB)
+            and os.path.getmtime(N3MR_PORT_LIB) >= os.path.getmtime(src)):
+        return N3MR_PORT_LIB
+    tmp = N3MR_PORT_LIB + ".tmp%d" % os.getpid()
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+                           src, "-o", tmp, "-lm"])
+    os.replace(tmp, N3MR_PORT_LIB)
+    return N3MR_PORT_LIB
+
+
 def make_ref(force=False):
     import importlib
     return importlib.import_module(__name__ + ".build_ref").build(force=force)
@@ -207,15 +223,25 @@ class Oracle:
 
 
 class N3mrOracle:
-    """The reference's NMR kernels compiled for the host (oracle/_ref/libn3mr_ref.so, serial).
+    """The reference's NMR kernels compiled for the host (oracle/_ref/libn3mr_ref.so, serial) or their
+    plain-C restatement (oracle/n3mr_oracle.c) behind the same entry points.
     Layouts are the reference's op-level ones (NHWC, bottom-up rows); background compositing and
     alpha are the host ops of n3mr.py:135-148, restated in NumPy."""
 
-    def __init__(self):
+    def __init__(self, kind=None):
+        """kind='reference': the reference's own kernels compiled for the host (oracle/_ref/libn3mr_ref.so; a
+        fixed list of image sizes is instantiated); kind='port': oracle/n3mr_oracle.c (any size, builds with
+        gcc alone); None: the reference build when it exists or can be built, else the port."""
         import importlib
-        path = importlib.import_module(__name__ + ".build_ref").build_n3mr()
+        path = None
+        if kind in (None, "reference"):
+            path = importlib.import_module(__name__ + ".build_ref").build_n3mr()
+            if (path is None or not os.path.exists(path)) and kind == "reference":
+                raise FileNotFoundError("oracle/_ref/libn3mr_ref.so not built and /root/reference not mounted")
+        self.kind = "reference"
         if path is None or not os.path.exists(path):
-            raise FileNotFoundError("oracle/_ref/libn3mr_ref.so not built and /root/reference not mounted")
+            path = make_n3mr_port()
+            self.kind = "port"
         self.lib = C.CDLL(path)
 
     def forward(self, faces, textures=None, image_size=256, near=0.1, far=100, eps=1e-3,
