@@ -123,7 +123,70 @@ class FlattenLoss:
         loss = ((cos + 1) ** 2).sum(tuple(range(cos.ndim))[1:])
         return (loss.sum() / vertices.shape[0] if self.average else loss).astype(F32)
 
-    def backward(self, vertices, eps=1e-6, h=1e-4):
+    @staticmethod
+    def _half_vjp(a, b, eps, dcb, dl):
+        """VJP of _half: upstream (dcb [.,3], dl [.]) -> (da, db).  Mirrors the forward expression by expression."""
+        al2 = (a * a).sum(-1)
+        bl2 = (b * b).sum(-1)
+        al1 = np.sqrt(al2 + eps)
+        bl1 = np.sqrt(bl2 + eps)
+        ab = (a * b).sum(-1)
+        den = al1 * bl1 + eps
+        cos = ab / den
+        sin = np.sqrt(1 - cos * cos + eps)
+        s = ab / (al2 + eps)
+        # l = bl1 * sin
+        dbl1 = sin * dl
+        dsin = bl1 * dl
+        dcos = dsin * (-cos / sin)
+        # cos = ab / (al1 * bl1 + eps)
+        dab = dcos / den
+        dal1 = -ab * bl1 / (den * den) * dcos
+        dbl1 = dbl1 + (-ab * al1 / (den * den) * dcos)
+        # cb = b - a * s,  s = ab / (al2 + eps)
+        db = dcb.copy()
+        da = -s[..., None] * dcb
+        ds = -(a * dcb).sum(-1)
+        dab = dab + ds / (al2 + eps)
+        dal2 = -ab / ((al2 + eps) ** 2) * ds
+        # norms and the dot product
+        dal2 = dal2 + dal1 / (2 * al1)
+        dbl2 = dbl1 / (2 * bl1)
+        da = da + 2 * a * dal2[..., None] + b * dab[..., None]
+        db = db + 2 * b * dbl2[..., None] + a * dab[..., None]
+        return da, db
+
+    def backward(self, vertices, eps=1e-6):
+        """d(sum over batch of the loss)/d(vertices) (divided by the batch size when average=True): reverse mode
+        through the per-edge expression, scattered to the four vertices of every edge pair."""
+        vertices = np.asarray(vertices, np.float64)
+        B, nv = vertices.shape[:2]
+        v0, v1 = vertices[:, self.v0s], vertices[:, self.v1s]
+        v2, v3 = vertices[:, self.v2s], vertices[:, self.v3s]
+        a, b1, b2 = v1 - v0, v2 - v0, v3 - v0
+        cb1, l1 = self._half(a, b1, eps)
+        cb2, l2 = self._half(a, b2, eps)
+        num = (cb1 * cb2).sum(-1)
+        den = l1 * l2 + eps
+        cos = num / den
+        g = 2 * (cos + 1)                                       # d(loss)/d(cos)
+        dcb1 = cb2 * (g / den)[..., None]
+        dcb2 = cb1 * (g / den)[..., None]
+        dl1 = -num * l2 / (den * den) * g
+        dl2 = -num * l1 / (den * den) * g
+        da1, db1 = self._half_vjp(a, b1, eps, dcb1, dl1)
+        da2, db2 = self._half_vjp(a, b2, eps, dcb2, dl2)
+        da = da1 + da2
+        out = np.zeros((B * nv, 3), np.float64)
+        offs = (np.arange(B, dtype=np.int64) * nv)[:, None]
+        for idx, contrib in ((self.v1s, da), (self.v2s, db1), (self.v3s, db2), (self.v0s, -(da + db1 + db2))):
+            flat = (idx[None, :] + offs).reshape(-1)
+            for d in range(3):
+                out[:, d] += np.bincount(flat, weights=contrib[..., d].reshape(-1), minlength=B * nv)
+        out = out.reshape(B, nv, 3)
+        return (out / B if self.average else out).astype(F32)
+
+    def backward_fd(self, vertices, eps=1e-6, h=1e-4):
         """Gradient by symmetric differences on the (small, smooth) per-edge expression — the loss is
         a regulariser weighted 3e-4 in the demo; analytic accuracy is not needed there."""
         vertices = np.asarray(vertices, np.float64)

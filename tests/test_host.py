@@ -184,3 +184,22 @@ def test_deform_model_backward_matches_finite_differences():
             lm = loss()
             arr[idx] = old
             assert abs((lp - lm) / (2 * h) - g[idx]) <= 2e-3 * max(1.0, abs(g[idx]))
+
+
+def test_flatten_loss_analytic_backward_matches_central_differences():
+    import jrender_amd as jr
+    v, f = jr.synthetic.uv_sphere(12, 7)
+    fl = jr.FlattenLoss(f)
+    rng = np.random.default_rng(1)
+    x = (v * 0.5)[None].astype(np.float64) + rng.normal(0, 0.03, (1,) + v.shape)
+
+    def total(y):
+        return ((fl._cos(y, 1e-6) + 1) ** 2).sum()
+    g = fl.backward(x).astype(np.float64)
+    for _ in range(25):
+        i, d, h = int(rng.integers(v.shape[0])), int(rng.integers(3)), 1e-6
+        xp, xm = x.copy(), x.copy()
+        xp[0, i, d] += h
+        xm[0, i, d] -= h
+        num = (total(xp) - total(xm)) / (2 * h)
+        assert abs(num - g[0, i, d]) <= 1e-5 * max(1.0, abs(num))
