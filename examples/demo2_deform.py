@@ -7,7 +7,7 @@ configs[3]) on the HIP SoftRas path, with the backward chain written out (no aut
       + 0.03 Laplacian + 0.0003 flatten regularisers;   Adam(0.01, betas=(0.5, 0.99))
 
     python examples/demo2_deform.py [--iters 200] [--batch-size 64] [-i source.npy -c camera.npy]
-    python -m torch.distributed.run --nproc-per-node 8 examples/demo2_deform.py   # views sharded over GPUs
+    python examples/demo2_deform.py --gpus 8                 # views sharded over 8 GPUs (one process each, RCCL)
 
 Without -i/-c (the reference's data files are not shipped here) the target is synthetic: silhouettes of a
 squashed, shifted ellipsoid seen from a ring of cameras.  With several ranks every rank renders its slice of
@@ -22,7 +22,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import jrender_amd as jr                                                     # noqa: E402
-from jrender_amd.parallel import BatchShards                                 # noqa: E402
+from jrender_amd import comm as jcomm                                        # noqa: E402
+from jrender_amd.parallel import shard_bounds                                # noqa: E402
 
 
 class Model:
@@ -82,21 +83,17 @@ def main(argv=None):
     ap.add_argument('--image-size', type=int, default=64)
     ap.add_argument('-o', '--output', default=None, help="write the optimised mesh to this .obj")
     ap.add_argument('--quiet', action='store_true')
+    ap.add_argument('--gpus', type=int, default=1, help="spawn this many ranks (one process per GPU)")
     args = ap.parse_args(argv)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    shards = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        if torch.cuda.device_count() >= world:
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group("gloo")
-        shards = BatchShards()
+    if args.batch_size < world:
+        raise SystemExit("demo2_deform: %d views cannot be sharded over %d ranks" % (args.batch_size, world))
+    # one process per GPU: the context follows LOCAL_RANK; RCCL when every rank owns a GPU, else host sockets
+    comm = jcomm.init_from_env(jr.Context.default()) if world > 1 else None
 
     tv, tf = jr.synthetic.uv_sphere(52, 27)                                   # 1 352-vertex class template (sphere_1352)
     model = Model(tv, tf)
@@ -111,7 +108,7 @@ def main(argv=None):
     else:
         target, cameras = synthetic_target(renderer, tv, tf, args.batch_size)
     B = target.shape[0]
-    lo, hi = (0, B) if shards is None else shards.bounds(B)[shards.rank]
+    lo, hi = (0, B) if comm is None else shard_bounds(B, world)[rank]
     renderer.transform.set_eyes_from_angles(cameras[lo:hi, 0], cameras[lo:hi, 1], cameras[lo:hi, 2])
     optimizer = jr.Adam(model.parameters(), 0.01, betas=(0.5, 0.99))
 
@@ -128,9 +125,9 @@ def main(argv=None):
         iou_sum = float((inter / union).sum())
         g_sil = jr.neg_iou_loss_backward(pred, target[lo:hi]) * (nb / B)      # that helper averages over its own batch
         g_v = renderer.grad_vertices(grad_silhouettes=g_sil.reshape(nb, 1, args.image_size, args.image_size)).sum(0, keepdims=True)
-        if shards is not None:
-            g_v = shards.all_reduce_sum(g_v)
-            iou_sum = float(shards.all_reduce_sum(np.asarray([iou_sum], np.float32))[0])
+        if comm is not None:
+            g_v = comm.all_reduce_sum_host(g_v)          # [1,nv,3]: the mesh is shared by all views
+            iou_sum = comm.all_reduce_scalar(iou_sum, "sum")
         lap = float(np.mean(model.laplacian_loss(vertices)))
         flat = float(np.mean(model.flatten_loss(vertices)))
         loss = (1.0 - iou_sum / B) + 0.03 * lap + 0.0003 * flat
@@ -143,10 +140,23 @@ def main(argv=None):
         print("%d iterations, %d views on %d rank(s): %.2f s" % (args.iters, B, world, time.time() - t0))
     if rank == 0 and args.output:
         jr.save_obj(args.output, model.forward()[0], model.faces[0])
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
     return history
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script (one process per GPU) with a private file rendezvous."""
+    import subprocess
+    import tempfile
+    rdzv = os.path.join(tempfile.mkdtemp(prefix="jrender_demo2_"), "rdzv")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                                       LOCAL_WORLD_SIZE=str(n), JRENDER_RDZV=rdzv))
+             for r in range(n)]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit("demo2_deform: rank exit codes %s" % rcs)
 
 
 if __name__ == '__main__':

@@ -100,6 +100,25 @@ int jr_softras_backward(jr_ctx* ctx, const float* face_vertices, const float* te
                         int func_id_rgb, int func_id_alpha, int texture_sample_type,
                         int double_side);
 
+/* The backward needs the per-face records and the launch order that the forward's set-up pass built.
+ * jr_softras_backward always REBUILDS them from face_vertices / textures as passed (0.06 ms on the
+ * headline workload).  A caller that runs the backward of the context's LATEST forward can skip that:
+ * jr_softras_forward_token() returns a non-zero generation token right after a successful forward, and
+ * jr_softras_backward_ex() reuses the forward's records iff that token is still the context's current
+ * generation (no other forward / backward set-up ran on the context in between) and the shapes match.
+ * The token says nothing about the CONTENT of face_vertices / textures: passing it asserts that the
+ * caller has not modified those buffers since the forward (the Python mirror clones them like the
+ * reference, soft_rasterize.py:59-60).  Token 0 = always rebuild.  Pointer identity is never used. */
+uint64_t jr_softras_forward_token(const jr_ctx* ctx);
+int jr_softras_backward_ex(jr_ctx* ctx, const float* face_vertices, const float* textures,
+                           const float* soft_colors, const float* faces_info,
+                           const float* aggrs_info, const int32_t* faces_id_buffer,
+                           const float* grad_soft_colors, float* grad_faces, float* grad_textures,
+                           int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
+                           float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                           int func_id_rgb, int func_id_alpha, int texture_sample_type,
+                           int double_side, uint64_t forward_token);
+
 /* ---- adjacent steps the reference ran as Jittor tensor ops -----------------------
  * face_vertices gather  vertices[B,NV,3] x faces[NF,3] (shared) -> [B,NF,9]
  *   (jrender/structures/utils/faces_vertices.py:4-19) and its scatter-add backward
@@ -111,9 +130,38 @@ int jr_face_vertices_forward(jr_ctx* ctx, const float* vertices, const int32_t* 
                              float* face_vertices, int B, int NV, int NF);
 int jr_face_vertices_backward(jr_ctx* ctx, const float* grad_face_vertices, const int32_t* faces,
                               float* grad_vertices, int B, int NV, int NF);
+/* views that share ONE vertex set (demo2-deform.py:45): sum of the per-view scatter-adds -> [NV,3] */
+int jr_face_vertices_backward_shared(jr_ctx* ctx, const float* grad_face_vertices,
+                                     const int32_t* faces, float* grad_vertices, int B, int NV,
+                                     int NF);
 int jr_avgpool2x2_forward(jr_ctx* ctx, const float* in, float* out, int planes, int H, int W);
 int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, int planes, int H,
                            int W);
+
+/* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU ------------------------------
+ * The reference has no distributed code.  A batch shards over ranks with no collective inside the
+ * op (every kernel indexes its view independently, SRK:278, :1216); what a caller exchanges
+ * afterwards is image / gradient shards (all-gather) and the gradient of vertices shared by all
+ * views (all-reduce; demo2-deform.py:45).  Rendezvous: rank 0 calls jr_comm_unique_id and ships
+ * the 128 bytes to the other ranks by any side channel (jrender_amd/comm.py: a file); every rank
+ * then calls jr_comm_create (collective).  All buffers are DEVICE pointers on the context's GPU,
+ * all collectives are enqueued on the context's stream, librccl.so is loaded on first use. */
+typedef struct jr_comm jr_comm;
+#define JR_COMM_ID_BYTES 128
+enum { JR_REDUCE_SUM = 0, JR_REDUCE_MAX = 1 };
+int jr_comm_unique_id(void* id_host /* JR_COMM_ID_BYTES */);
+int jr_comm_create(jr_ctx* ctx, const void* id_host, int nranks, int rank, jr_comm** out);
+int jr_comm_destroy(jr_comm* comm);
+int jr_comm_rank(const jr_comm* comm);
+int jr_comm_size(const jr_comm* comm);
+/* recv[nranks * bytes_per_rank]; in place when send == recv + rank * bytes_per_rank */
+int jr_comm_all_gather(jr_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
+/* uneven shards: bytes_of_rank is a HOST array [nranks]; recv is their concatenation */
+int jr_comm_all_gather_v(jr_comm* comm, const void* send, void* recv, const size_t* bytes_of_rank);
+int jr_comm_all_reduce_f32(jr_comm* comm, const float* send, float* recv, size_t count, int op);
+/* 1 or 2 HOST doubles reduced over the ranks (timing, loss values); blocks until done */
+int jr_comm_all_reduce_host_f64(jr_comm* comm, double* values_host, int count, int op);
+int jr_comm_barrier(jr_comm* comm); /* blocks: every rank's stream reached this point */
 
 /* ---- per-phase GPU timing with HIP events on the context stream (benchmarks) ---------
  * After jr_profile_enable(ctx, 1) every forward/backward brackets its phases with event pairs;

@@ -10,5 +10,6 @@ from .loss import *                # noqa: F401,F403
 from .io import *                  # noqa: F401,F403
 from .optim import Adam            # noqa: F401
 from . import synthetic            # noqa: F401
+from ._ffi import Context, DeviceArray   # noqa: F401
 
 __version__ = "0.1"

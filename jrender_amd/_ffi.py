@@ -45,8 +45,11 @@ SIGNATURES = {
     "jr_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "jr_softras_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + _SCALARS_FWD + [c_float_p]),
     "jr_softras_backward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + _SCALARS_FWD),
+    "jr_softras_backward_ex": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + _SCALARS_FWD + [C.c_uint64]),
+    "jr_softras_forward_token": (C.c_uint64, [C.c_void_p]),
     "jr_face_vertices_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3),
     "jr_face_vertices_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3),
+    "jr_face_vertices_backward_shared": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3),
     "jr_avgpool2x2_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_avgpool2x2_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_n3mr_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float] * 3 + [c_float_p] + [C.c_int] * 3),
@@ -56,6 +59,16 @@ SIGNATURES = {
     "jr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "jr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "jr_softras_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "jr_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "jr_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "jr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "jr_comm_rank": (C.c_int, [C.c_void_p]),
+    "jr_comm_size": (C.c_int, [C.c_void_p]),
+    "jr_comm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "jr_comm_all_gather_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "jr_comm_all_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "jr_comm_all_reduce_host_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    "jr_comm_barrier": (C.c_int, [C.c_void_p]),
 }
 
 
@@ -150,9 +163,18 @@ class DeviceArray:
         _check(load().jr_memset(self.ctx.handle, self.ptr, 0, self.nbytes))
         return self
 
+    def view(self, lo, hi):
+        """Rows [lo, hi) of the leading axis as a non-owning view."""
+        lo, hi = int(lo), int(hi)
+        if not (0 <= lo <= hi <= self.shape[0]):
+            raise IndexError("rows [%d, %d) of %s" % (lo, hi, self.shape))
+        row = self.nbytes // self.shape[0] if self.shape[0] else 0
+        return DeviceArray(self.ctx, (self.ptr or 0) + lo * row, (hi - lo,) + self.shape[1:], self.dtype,
+                           owner=self if self._owner is None else self._owner)
+
     @property
     def __cuda_array_interface__(self):
-        # zero-copy hand-off to anything that understands the protocol (used only by jrender_amd.parallel)
+        # zero-copy hand-off to anything that understands the protocol (tests, interop)
         return {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.ptr), False),
                 "version": 3, "strides": None}
 
@@ -170,7 +192,7 @@ class DeviceArray:
 
 class Context:
     """One GPU: HIP stream + scratch arena (jr_ctx).  ``Context.default()`` picks the GPU from
-    LOCAL_RANK (one process per GPU under torch.distributed.run) or GPU 0."""
+    LOCAL_RANK (one process per GPU; set by bench.py's own launcher or by torch.distributed.run) or GPU 0."""
 
     _default = None
 

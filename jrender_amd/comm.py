@@ -1,0 +1,280 @@
+"""Communicators for batch-sharded rendering: one process per GPU, no PyTorch.
+
+The reference has no distributed code.  What a sharded batch exchanges is
+described in ``include/jrender_hip.h`` (jr_comm_*): image / gradient shards (all-gather) and
+the gradient of vertices shared by all views (all-reduce).
+
+* ``RcclCommunicator`` — RCCL over xGMI through the C ABI (``jr_comm_*``), device buffers on
+  the context's stream, nothing touches the host.  Rendezvous on one node: rank 0 writes the
+  128-byte RCCL unique id to a file, the others poll for it.
+* ``HostCommunicator`` — the same interface over a local socket for HOST (NumPy) arrays, star
+  topology through rank 0.  Used where RCCL cannot run: CPU tests, and plumbing runs that put
+  several ranks on ONE GPU (RCCL refuses two ranks on the same device).  Device arrays are
+  bounced through the host there — a test vehicle, not a data path.
+* ``SingleCommunicator`` — world size 1, every collective is the identity.
+
+``init_from_env(ctx)`` picks one from RANK / WORLD_SIZE / LOCAL_RANK (set by ``bench.py --gpus N``'s
+own launcher or by ``torch.distributed.run``, whose environment variables are only READ here).
+"""
+import ctypes as C
+import os
+import tempfile
+import time
+from multiprocessing.connection import Client, Listener
+
+import numpy as np
+
+from . import _ffi
+
+__all__ = ["SingleCommunicator", "RcclCommunicator", "HostCommunicator", "init_from_env",
+           "rendezvous_path"]
+
+ID_BYTES = 128
+_AUTH = b"jrender_amd.comm"
+
+
+def rendezvous_path():
+    """File-system rendezvous prefix shared by the ranks of ONE launch on this node."""
+    p = os.environ.get("JRENDER_RDZV")
+    if p:
+        return p
+    # torch.distributed.run: every worker has the same parent (the agent) and the same MASTER_PORT
+    return os.path.join(tempfile.gettempdir(), "jrender_rdzv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+
+
+def _wait_for(path, timeout):
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise TimeoutError("rendezvous: %s did not appear within %.0f s" % (path, timeout))
+        time.sleep(0.01)
+
+
+def _publish(path, data):
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)            # atomic: readers never see a partial file
+
+
+class _Base:
+    rank, world = 0, 1
+
+    def bounds(self, batch):
+        from .parallel import shard_bounds
+        return shard_bounds(batch, self.world)
+
+    def all_reduce_max(self, value):
+        return self.all_reduce_scalar(value, "max")
+
+    def all_reduce_sum_host(self, x):
+        """Sum of a (small) HOST float32 array over ranks -> host array."""
+        return np.asarray(self.all_reduce_sum(np.ascontiguousarray(x, np.float32)))
+
+    def close(self):
+        pass
+
+
+class SingleCommunicator(_Base):
+    backend = "single"
+
+    def all_gather(self, local, batch):
+        return local
+
+    def all_reduce_sum(self, x):
+        return x
+
+    def all_reduce_scalar(self, value, op="sum"):
+        return float(value)
+
+    def barrier(self):
+        pass
+
+
+class RcclCommunicator(_Base):
+    """RCCL communicator of one (process, GPU).  All array arguments are ``DeviceArray``s of ``ctx``."""
+
+    backend = "rccl"
+
+    def __init__(self, ctx, rank, world, path=None, timeout=300.0):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        lib = _ffi.load()
+        idfile = (path or rendezvous_path()) + ".id"
+        buf = (C.c_char * ID_BYTES)()
+        if self.rank == 0:
+            _ffi._check(lib.jr_comm_unique_id(buf))
+            _publish(idfile, bytes(buf))
+        else:
+            _wait_for(idfile, timeout)
+            data = open(idfile, "rb").read()
+            if len(data) != ID_BYTES:
+                raise RuntimeError("rendezvous: %s holds %d bytes, expected %d" % (idfile, len(data), ID_BYTES))
+            C.memmove(buf, data, ID_BYTES)
+        h = C.c_void_p()
+        _ffi._check(lib.jr_comm_create(ctx.handle, buf, self.world, self.rank, C.byref(h)))   # collective
+        self.handle = h
+        if self.rank == 0:
+            # ncclCommInitRank returned => every rank has read the id
+            try:
+                os.unlink(idfile)
+            except OSError:
+                pass
+
+    def _dev(self, x):
+        if not isinstance(x, _ffi.DeviceArray):
+            raise TypeError("RcclCommunicator exchanges DeviceArrays (got %s); upload with ctx.array() first" % type(x).__name__)
+        if x.ctx is not self.ctx:
+            raise ValueError("array belongs to another context")
+        return x
+
+    def all_gather(self, local, batch):
+        """Every rank's ``local`` [b_r, ...] concatenated along axis 0 -> DeviceArray [batch, ...] on
+        every rank, device to device.  Even shards: one ncclAllGather; uneven: grouped broadcasts."""
+        local = self._dev(local)
+        bounds = self.bounds(batch)
+        lo, hi = bounds[self.rank]
+        if local.shape[0] != hi - lo:
+            raise ValueError("rank %d holds %d rows, its shard of %d is [%d, %d)" % (self.rank, local.shape[0], batch, lo, hi))
+        out = self.ctx.empty((int(batch),) + local.shape[1:], local.dtype)
+        row = local.dtype.itemsize * int(np.prod(local.shape[1:], dtype=np.int64))
+        sizes = [(h - l) * row for l, h in bounds]
+        lib = _ffi.load()
+        if len(set(sizes)) == 1:
+            _ffi._check(lib.jr_comm_all_gather(self.handle, local.ptr, out.ptr, sizes[0]))
+        else:
+            arr = (C.c_size_t * self.world)(*sizes)
+            _ffi._check(lib.jr_comm_all_gather_v(self.handle, local.ptr if local.nbytes else None, out.ptr, arr))
+        return out
+
+    def all_reduce_sum(self, x):
+        """In-place float32 sum over ranks on the device -> the same DeviceArray."""
+        x = self._dev(x)
+        if x.dtype != np.float32:
+            raise TypeError("all_reduce_sum: float32 only")
+        _ffi._check(_ffi.load().jr_comm_all_reduce_f32(self.handle, x.ptr, x.ptr, x.size, 0))
+        return x
+
+    def all_reduce_sum_host(self, x):
+        d = self.ctx.array(np.ascontiguousarray(x, np.float32))
+        return self.all_reduce_sum(d).numpy()
+
+    def all_reduce_scalar(self, value, op="sum"):
+        v = (C.c_double * 1)(float(value))
+        _ffi._check(_ffi.load().jr_comm_all_reduce_host_f64(self.handle, v, 1, 0 if op == "sum" else 1))
+        return float(v[0])
+
+    def barrier(self):
+        _ffi._check(_ffi.load().jr_comm_barrier(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _ffi.load().jr_comm_destroy(self.handle)
+            self.handle = None
+
+
+class HostCommunicator(_Base):
+    """Same interface for host arrays over a local socket (rank 0 = hub).  DeviceArrays are
+    accepted and bounced through the host: this is the CPU-test / shared-GPU plumbing vehicle."""
+
+    backend = "host"
+
+    def __init__(self, rank, world, path=None, ctx=None, timeout=120.0):
+        self.rank, self.world, self.ctx = int(rank), int(world), ctx
+        addr = (path or rendezvous_path()) + ".sock"
+        self._addr = addr
+        self._peers, self._hub, self._listener = [], None, None
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            if os.path.exists(addr):
+                os.unlink(addr)
+            self._listener = Listener(addr, family="AF_UNIX", authkey=_AUTH)
+            conns = {}
+            for _ in range(self.world - 1):
+                c = self._listener.accept()
+                conns[c.recv()] = c
+            self._peers = [conns[r] for r in range(1, self.world)]
+        else:
+            _wait_for(addr, timeout)
+            t0 = time.time()
+            while True:
+                try:
+                    self._hub = Client(addr, family="AF_UNIX", authkey=_AUTH)
+                    break
+                except (ConnectionRefusedError, FileNotFoundError):
+                    if time.time() - t0 > timeout:
+                        raise
+                    time.sleep(0.01)
+            self._hub.send(self.rank)
+
+    def _exchange(self, item, combine):
+        """rank 0 collects every rank's item, applies ``combine(list)`` and sends the result back."""
+        if self.world == 1:
+            return combine([item])
+        if self.rank == 0:
+            res = combine([item] + [c.recv() for c in self._peers])
+            for c in self._peers:
+                c.send(res)
+            return res
+        self._hub.send(item)
+        return self._hub.recv()
+
+    def _host(self, x):
+        return x.numpy() if isinstance(x, _ffi.DeviceArray) else np.ascontiguousarray(x)
+
+    def _like(self, res, x):
+        return x.ctx.array(res) if isinstance(x, _ffi.DeviceArray) else res
+
+    def all_gather(self, local, batch):
+        h = self._host(local)
+        lo, hi = self.bounds(batch)[self.rank]
+        if h.shape[0] != hi - lo:
+            raise ValueError("rank %d holds %d rows, its shard of %d is [%d, %d)" % (self.rank, h.shape[0], batch, lo, hi))
+        return self._like(self._exchange(h, lambda parts: np.concatenate(parts, axis=0)), local)
+
+    def all_reduce_sum(self, x):
+        h = self._host(x)
+        res = self._exchange(h, lambda parts: np.sum(np.stack(parts), axis=0, dtype=parts[0].dtype))
+        if isinstance(x, _ffi.DeviceArray):
+            return x.copy_from_host(res)
+        return res
+
+    def all_reduce_scalar(self, value, op="sum"):
+        return float(self._exchange(float(value), max if op == "max" else sum))
+
+    def barrier(self):
+        if self.ctx is not None:
+            self.ctx.synchronize()
+        self._exchange(0, lambda parts: 0)
+
+    def close(self):
+        for c in self._peers:
+            c.close()
+        if self._hub is not None:
+            self._hub.close()
+        if self._listener is not None:
+            self._listener.close()
+        self._peers, self._hub, self._listener = [], None, None
+
+
+def init_from_env(ctx=None, backend=None):
+    """Communicator of this process from RANK / WORLD_SIZE / LOCAL_RANK.
+
+    ``backend``: "rccl", "host" or None = RCCL when every rank of the node can own a GPU (and a
+    context is given), else the host communicator (ranks share GPUs: plumbing only)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return SingleCommunicator()
+    if backend is None:
+        backend = os.environ.get("JRENDER_COMM")
+    if backend is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        backend = "rccl" if (ctx is not None and _ffi.device_count() >= local_world) else "host"
+    if backend == "rccl":
+        if ctx is None:
+            raise ValueError("the RCCL communicator needs a Context")
+        return RcclCommunicator(ctx, rank, world)
+    if backend == "host":
+        return HostCommunicator(rank, world, ctx=ctx)
+    raise ValueError("unknown communicator backend %r" % (backend,))

@@ -35,6 +35,23 @@ __global__ __launch_bounds__(256) void k_face_vertices_bwd(const float* __restri
     atomicAdd(dst + 0, src[0]); atomicAdd(dst + 1, src[1]); atomicAdd(dst + 2, src[2]);
 }
 
+// All views share ONE vertex set (demo2-deform.py:45 repeats the vertices over the batch): the per-view
+// gradients collapse into [NV,3].  One thread per (face, corner) sums its B views in registers (coalesced
+// reads, 36 B apart per view), then one atomic per component.
+__global__ __launch_bounds__(256) void k_face_vertices_bwd_shared(const float* __restrict__ gfv,
+                                                                  const int32_t* __restrict__ faces,
+                                                                  float* __restrict__ gv, int B, int NF) {
+    const long fc = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (fc >= (long)NF * 3) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; b++) {
+        const float* src = gfv + ((long)b * NF * 3 + fc) * 3;
+        s0 += src[0]; s1 += src[1]; s2 += src[2];
+    }
+    float* dst = gv + (long)faces[fc] * 3;
+    atomicAdd(dst + 0, s0); atomicAdd(dst + 1, s1); atomicAdd(dst + 2, s2);
+}
+
 __global__ __launch_bounds__(256) void k_avgpool_fwd(const float* __restrict__ in, float* __restrict__ out,
                                                      long total, int Ho, int Wo) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,6 +90,13 @@ void launch_face_vertices_backward(hipStream_t st, const float* gfv, const int32
     (void)hipMemsetAsync(gv, 0, sizeof(float) * (size_t)B * NV * 3, st);
     const long total = (long)B * NF * 3;
     k_face_vertices_bwd<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(gfv, faces, gv, B, NV, NF);
+}
+void launch_face_vertices_backward_shared(hipStream_t st, const float* gfv, const int32_t* faces, float* gv,
+                                          int B, int NV, int NF) {
+    (void)hipMemsetAsync(gv, 0, sizeof(float) * (size_t)NV * 3, st);
+    if (B < 1) return;
+    const long total = (long)NF * 3;
+    k_face_vertices_bwd_shared<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(gfv, faces, gv, B, NF);
 }
 void launch_avgpool2x2_forward(hipStream_t st, const float* in, float* out, int planes, int H, int W) {
     const int Ho = H / 2, Wo = W / 2;

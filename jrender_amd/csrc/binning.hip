@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4*
 
 // One workgroup per bin: counting order through an LDS bitmap over the face ids (see the file header).
 // src = the unordered segments, dst = the same segments in ascending id order.
-constexpr int BITMAP_MAX_FACES = 262144;     // 2 x NF/32 words of LDS <= 64 KB
+constexpr int BITMAP_MAX_FACES = 258048;     // 2 x NF/32 words of dynamic LDS + the static tables stay below 64 KB
 __global__ __launch_bounds__(256) void k_bin_order(int NF, const int* __restrict__ bin_count,
                                                    const int* __restrict__ bin_base,
                                                    const unsigned long long* __restrict__ src,

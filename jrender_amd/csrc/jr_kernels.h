@@ -37,6 +37,8 @@ void launch_face_vertices_forward(hipStream_t st, const float* vertices, const i
                                   float* fv, int B, int NV, int NF);
 void launch_face_vertices_backward(hipStream_t st, const float* gfv, const int32_t* faces,
                                    float* gv, int B, int NV, int NF);
+void launch_face_vertices_backward_shared(hipStream_t st, const float* gfv, const int32_t* faces,
+                                          float* gv, int B, int NV, int NF);
 void launch_avgpool2x2_forward(hipStream_t st, const float* in, float* out, int planes, int H, int W);
 void launch_avgpool2x2_backward(hipStream_t st, const float* gout, float* gin, int planes, int H, int W);
 void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textures, float* faces_inv,

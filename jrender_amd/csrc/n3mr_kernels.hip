@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void k_n3mr_zbuffer(N3Params p, const float* _
         const int xi = ix0 + (int)(idx / hgt), yi = iy0 + (int)(idx % hgt);
         float w[3], zp;
         if (!n3_pixel(f, inv, xi, yi, p.IS, w, zp)) continue;
-        if (zp <= p.near_ || p.far_ <= zp) continue;                                   // N3K:136
+        // N3K:136 (zp <= near || far <= zp) AND N3K:147 (zp < depth_map, false for NaN): a zero-area face
+        // gives w_sum == 0 -> zp = NaN, which the reference never draws; reject unordered depths here
+        if (!(zp > p.near_ && zp < p.far_)) continue;
         const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned, zp) << 32) | (unsigned)fn;
         atomicMin(&zkey[(size_t)bn * p.IS * p.IS + (size_t)yi * p.IS + xi], key);
     }

@@ -7,15 +7,18 @@ collective inside the op.  What a caller may want afterwards is an exchange step
 
   * ``all_gather``   rendered images (or per-view gradients) of every rank, e.g. to write one
                      image grid or to evaluate a loss that couples views;
-  * ``all_reduce``   the gradient of vertices that are SHARED by all views (mesh deformation).
+  * ``all_reduce``   the gradient of vertices that are SHARED by all views (mesh deformation,
+                     demo2-deform.py:45 repeats one vertex set over the batch).
 
-``torch.distributed`` is used purely as the communicator: backend "nccl" (= RCCL over xGMI on
-ROCm) for device buffers, "gloo" for host arrays / CPU tests.  Device buffers are handed over
-zero-copy through ``__cuda_array_interface__``; nothing else of PyTorch is touched.
+The communicator is ``jrender_amd.comm``: RCCL over xGMI through the C ABI for device arrays
+(device to device, on the context's stream), a local-socket communicator for host arrays (CPU
+tests, several ranks on one GPU).  No PyTorch anywhere.
 """
+
 import numpy as np
 
 from . import _ffi
+from . import comm as _comm
 
 __all__ = ["shard_bounds", "BatchShards", "ShardedSoftRasterizer"]
 
@@ -31,68 +34,31 @@ def shard_bounds(batch, world_size):
     return out
 
 
-def _dist():
-    import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized():
-        return None
-    return dist
-
-
 class BatchShards:
-    """Collectives over the leading (batch) axis.  Works un-initialised as world_size 1."""
+    """Collectives over the leading (batch) axis.  Without a communicator: world size 1."""
 
-    def __init__(self, group=None):
-        d = _dist()
-        self.group = group
-        self.rank = d.get_rank(group) if d else 0
-        self.world = d.get_world_size(group) if d else 1
+    def __init__(self, comm=None):
+        self.comm = comm if comm is not None else _comm.SingleCommunicator()
+        self.rank, self.world = self.comm.rank, self.comm.world
 
     def bounds(self, batch):
         return shard_bounds(batch, self.world)
 
     def local(self, array, batch=None):
-        """This rank's slice of a full-batch host array."""
+        """This rank's slice of a full-batch array (host array or DeviceArray)."""
         lo, hi = self.bounds(array.shape[0] if batch is None else batch)[self.rank]
+        if isinstance(array, _ffi.DeviceArray):
+            return array.view(lo, hi)
         return array[lo:hi]
 
-    def _as_tensor(self, x):
-        import torch
-        if isinstance(x, _ffi.DeviceArray):
-            x.ctx.synchronize()                       # our stream -> torch's stream hand-off
-            return torch.as_tensor(x, device="cuda:%d" % x.ctx.device), True
-        return torch.from_numpy(np.ascontiguousarray(x)), False
-
     def all_gather(self, local, batch):
-        """Concatenate every rank's ``local`` [b_r, ...] along axis 0 -> NumPy [batch, ...] on all
-        ranks (shards may be uneven; they are padded to the largest for the collective)."""
-        if self.world == 1:
-            return np.asarray(local)
-        import torch
-        d = _dist()
-        bounds = self.bounds(batch)
-        width = max(hi - lo for lo, hi in bounds)
-        t, on_gpu = self._as_tensor(local)
-        item = tuple(t.shape[1:])
-        pad = torch.zeros((width,) + item, dtype=t.dtype, device=t.device)
-        pad[: t.shape[0]] = t
-        out = torch.empty((self.world * width,) + item, dtype=t.dtype, device=t.device)
-        d.all_gather_into_tensor(out, pad, group=self.group)
-        if on_gpu:
-            torch.cuda.synchronize()
-        out = out.cpu().numpy().reshape((self.world, width) + item)
-        return np.concatenate([out[r, : hi - lo] for r, (lo, hi) in enumerate(bounds)], axis=0)
+        """Every rank's ``local`` [b_r, ...] along axis 0 -> [batch, ...] on all ranks.  A
+        DeviceArray stays on the device (RCCL), a host array stays on the host."""
+        return self.comm.all_gather(local, batch)
 
     def all_reduce_sum(self, x):
-        """Sum a (small) host array over ranks — e.g. the gradient of vertices shared by all views."""
-        if self.world == 1:
-            return np.asarray(x)
-        import torch
-        d = _dist()
-        t = torch.from_numpy(np.ascontiguousarray(x).copy())
-        if d.get_backend(self.group) == "nccl":
-            t = t.cuda()
-        d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy()
+        """Sum over ranks (DeviceArray: in place on the device)."""
+        return self.comm.all_reduce_sum(x)
 
 
 class ShardedSoftRasterizer:
@@ -102,20 +68,23 @@ class ShardedSoftRasterizer:
     in a CPU function with the same ``execute`` / ``grad`` protocol.
     """
 
-    def __init__(self, make_function=None, group=None, **op_kwargs):
+    def __init__(self, make_function=None, comm=None, **op_kwargs):
         if make_function is None:
             from .renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
             make_function = lambda **kw: SoftRasterizeFunction(**kw)   # noqa: E731
-        self.shards = BatchShards(group)
+        self.shards = BatchShards(comm)
         self.fn = make_function(**op_kwargs)
         self._batch = None
 
+    def _slice(self, x, batch=None):
+        if isinstance(x, _ffi.DeviceArray):
+            return self.shards.local(x, batch)
+        return self.shards.local(np.asarray(x, np.float32), batch)
+
     def forward_local(self, face_vertices, textures):
-        """Full-batch host inputs -> this rank's images [b_r, 4, IS, IS] (device or host array)."""
+        """Full-batch inputs (host arrays or DeviceArrays) -> this rank's images [b_r, 4, IS, IS]."""
         self._batch = face_vertices.shape[0]
-        fv = self.shards.local(np.asarray(face_vertices, np.float32))
-        tex = self.shards.local(np.asarray(textures, np.float32))
-        return self.fn.execute(fv, tex)
+        return self.fn.execute(self._slice(face_vertices), self._slice(textures))
 
     def forward(self, face_vertices, textures):
         """-> images of the WHOLE batch on every rank (all-gather of the image shards)."""
@@ -124,8 +93,7 @@ class ShardedSoftRasterizer:
 
     def backward_local(self, grad_images_full):
         """Full-batch upstream gradient -> this rank's (grad_face_vertices, grad_textures)."""
-        g = self.shards.local(np.asarray(grad_images_full, np.float32), self._batch)
-        return self.fn.grad(g)
+        return self.fn.grad(self._slice(grad_images_full, self._batch))
 
     def backward(self, grad_images_full):
         """-> per-view gradients of the whole batch on every rank (all-gather of the shards)."""
@@ -134,13 +102,31 @@ class ShardedSoftRasterizer:
 
     def backward_shared_vertices(self, grad_images_full, faces, num_vertices):
         """Views share one vertex set: scatter per-face gradients to vertices locally, sum over the
-        rank's views, all-reduce over ranks -> [NV, 3] on every rank."""
-        from .structures.mesh import face_vertices_backward
+        rank's views, all-reduce over ranks -> [NV, 3] on every rank (DeviceArray on the HIP path:
+        scatter kernel + ncclAllReduce, nothing leaves the device)."""
         gf, _ = self.backward_local(grad_images_full)
-        gf = np.asarray(gf).reshape(-1, np.asarray(faces).shape[-2], 3, 3)
-        if gf.shape[0]:
-            fb = np.broadcast_to(np.asarray(faces).reshape(1, -1, 3), (gf.shape[0], gf.shape[1], 3))
-            gv = face_vertices_backward(gf, fb, num_vertices).sum(0)
-        else:
-            gv = np.zeros((num_vertices, 3), np.float32)
-        return self.shards.all_reduce_sum(gv)
+        return shared_vertex_gradient(gf, faces, num_vertices, self.shards.comm)
+
+
+def shared_vertex_gradient(grad_faces, faces, num_vertices, comm=None):
+    """Σ over local views of the face→vertex scatter-add of ``grad_faces`` [b, NF, 3, 3], then the
+    sum over ranks.  DeviceArray in -> DeviceArray [NV, 3] out (device scatter + RCCL all-reduce);
+    host array in -> host array out."""
+    comm = comm if comm is not None else _comm.SingleCommunicator()
+    if isinstance(grad_faces, _ffi.DeviceArray):
+        ctx = grad_faces.ctx
+        faces_d = faces if isinstance(faces, _ffi.DeviceArray) else ctx.array(np.asarray(faces, np.int32).reshape(-1, 3))
+        nf = faces_d.size // 3
+        gv = ctx.empty((int(num_vertices), 3), np.float32)
+        _ffi._check(_ffi.load().jr_face_vertices_backward_shared(
+            ctx.handle, grad_faces.ptr, faces_d.ptr, gv.ptr, int(grad_faces.shape[0]), int(num_vertices), int(nf)))
+        return comm.all_reduce_sum(gv)
+    from .structures.mesh import face_vertices_backward
+    faces = np.asarray(faces)
+    gf = np.asarray(grad_faces).reshape(-1, faces.shape[-2], 3, 3)
+    if gf.shape[0]:
+        fb = np.broadcast_to(faces.reshape(1, -1, 3), (gf.shape[0], gf.shape[1], 3))
+        gv = face_vertices_backward(gf, fb, num_vertices).sum(0)
+    else:
+        gv = np.zeros((num_vertices, 3), np.float32)
+    return comm.all_reduce_sum(gv.astype(np.float32))

@@ -86,6 +86,14 @@ class SoftRasterizeFunction:
         if fv.dtype != np.float32 or tex.dtype != np.float32:
             raise TypeError("face_vertices and textures must be float32")
         self.batch_size, self.num_faces = fv.shape[:2]
+        if self.batch_size == 0:
+            # an empty shard (global batch < number of ranks): nothing to launch, empty results
+            IS, K = int(self.image_size), int(self.max_faces_id)
+            self.texture_size = tex.shape[2] if tex.ndim >= 3 else 1
+            self._ctx, self._token = ctx, 0
+            self.save_vars = (fv, tex, ctx.empty((0, 4, IS, IS)), ctx.empty((0, self.num_faces, 27)),
+                              ctx.empty((0, 2, IS, IS)), ctx.empty((0, K, IS, IS), np.int32))
+            return self.save_vars[2]
         if fv.size != self.batch_size * self.num_faces * 9:
             raise ValueError("face_vertices must be [B, NF, 3, 3], got %s" % (fv.shape,))
         self.texture_size = tex.size // (self.batch_size * self.num_faces * 3)
@@ -102,6 +110,9 @@ class SoftRasterizeFunction:
         _ffi._check(lib.jr_softras_forward(ctx.handle, fv.ptr, tex.ptr, faces_info.ptr, aggrs_info.ptr,
                                            soft_colors.ptr, faces_id_buffer.ptr, *self._scalars(), bg))
         self._ctx = ctx
+        # generation token of the set-up pass: lets the backward reuse the forward's face records as long
+        # as no other forward ran on this context in between (the saved inputs are private clones)
+        self._token = int(lib.jr_softras_forward_token(ctx.handle))
         self.save_vars = fv, tex, soft_colors, faces_info, aggrs_info, faces_id_buffer   # SRW:101
         return soft_colors
 
@@ -118,9 +129,12 @@ class SoftRasterizeFunction:
             raise ValueError("grad_soft_colors must be %s, got %s" % (soft_colors.shape, g.shape))
         grad_faces = ctx.empty(fv.shape, np.float32)
         grad_textures = ctx.empty(tex.shape, np.float32)
-        _ffi._check(_ffi.load().jr_softras_backward(
+        if fv.shape[0] == 0:
+            return grad_faces, grad_textures
+        _ffi._check(_ffi.load().jr_softras_backward_ex(
             ctx.handle, fv.ptr, tex.ptr, soft_colors.ptr, faces_info.ptr, aggrs_info.ptr,
-            faces_id_buffer.ptr, g.ptr, grad_faces.ptr, grad_textures.ptr, *self._scalars()))
+            faces_id_buffer.ptr, g.ptr, grad_faces.ptr, grad_textures.ptr, *self._scalars(),
+            C.c_uint64(self._token)))
         return grad_faces, grad_textures
 
 

@@ -1,0 +1,169 @@
+"""Multi-GPU plumbing on the (1-GPU) box: the RCCL communicator through the C ABI at world size 1,
+two ranks on one GPU through the host communicator, bench.py's own rank launcher, the device-resident
+shared-vertex gradient, and the generation token that guards the backward's reuse of face records."""
+import ctypes as C
+import json
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from jrender_amd import _ffi, comm as jcomm, synthetic as syn
+from jrender_amd.parallel import ShardedSoftRasterizer, shared_vertex_gradient
+from jrender_amd.renderer.dr.softras import SoftRasterizeFunction
+from jrender_amd.structures.mesh import face_vertices_backward
+from oracle import Oracle
+from tests.util import bits_equal, grad_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return _ffi.Context.default()
+
+
+def test_rccl_world1_collectives(ctx, tmp_path):
+    """ncclGetUniqueId / ncclCommInitRank / all-gather / all-gather-v / all-reduce / barrier via jr_comm_*."""
+    cm = jcomm.RcclCommunicator(ctx, 0, 1, path=str(tmp_path / "rdzv"))
+    try:
+        x = np.random.default_rng(0).uniform(-1, 1, (3, 5, 7)).astype(np.float32)
+        d = ctx.array(x)
+        out = cm.all_gather(d, 3)
+        assert isinstance(out, _ffi.DeviceArray) and bits_equal(out.numpy(), x)
+        assert bits_equal(cm.all_reduce_sum(d).numpy(), x)
+        assert cm.all_reduce_max(2.5) == 2.5 and cm.all_reduce_scalar(1.25, "sum") == 1.25
+        cm.barrier()
+        # uneven path (grouped broadcasts) with a single rank
+        sizes = (C.c_size_t * 1)(d.nbytes)
+        out2 = ctx.empty(x.shape)
+        _ffi._check(_ffi.load().jr_comm_all_gather_v(cm.handle, d.ptr, out2.ptr, sizes))
+        assert bits_equal(out2.numpy(), x)
+        with pytest.raises(TypeError):
+            cm.all_gather(x, 3)                     # host arrays are not accepted by the RCCL path
+    finally:
+        cm.close()
+    assert not os.path.exists(str(tmp_path / "rdzv") + ".id")
+
+
+def test_shared_vertex_gradient_on_device(ctx):
+    verts, faces = syn.sphere_mesh(280)
+    gf = np.random.default_rng(1).uniform(-1, 1, (3, faces.shape[0], 3, 3)).astype(np.float32)
+    ref = face_vertices_backward(gf, np.broadcast_to(faces[None], (3,) + faces.shape), verts.shape[0]).sum(0)
+    out = shared_vertex_gradient(ctx.array(gf), faces, verts.shape[0])
+    assert isinstance(out, _ffi.DeviceArray) and out.shape == (verts.shape[0], 3)
+    assert np.allclose(out.numpy(), ref, rtol=1e-5, atol=1e-5)
+    empty = shared_vertex_gradient(ctx.empty((0, faces.shape[0], 3, 3)), faces, verts.shape[0])
+    assert not empty.numpy().any()
+
+
+def _rank(rank, world, B, out_dir):
+    sys.path.insert(0, ROOT)
+    from jrender_amd import _ffi as ffi, comm as jc, synthetic as s
+    from jrender_amd.parallel import ShardedSoftRasterizer as Sh
+    c = ffi.Context(0)                                          # both ranks on GPU 0
+    cm = jc.HostCommunicator(rank, world, path=os.path.join(out_dir, "rdzv"), ctx=c)
+    fv, tex = s.sphere_views(280, B)
+    sh = Sh(comm=cm, image_size=32, ctx=c)
+    images = sh.forward(c.array(fv), c.array(tex))              # device in, device out
+    g = np.random.default_rng(0).uniform(-1, 1, images.shape).astype(np.float32)
+    gf, gt = sh.backward(c.array(g))
+    verts, faces = s.sphere_mesh(280)
+    gv = sh.backward_shared_vertices(c.array(g), faces, verts.shape[0])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), images=images.numpy(), gf=gf.numpy(), gt=gt.numpy(), gv=gv.numpy())
+    cm.barrier()
+    cm.close()
+
+
+@pytest.mark.parametrize("B", [4, 3, 1])
+def test_two_ranks_one_gpu_match_single_process(ctx, tmp_path, B):
+    """The sharded code path with the HIP op, 2 processes on the one GPU (B=1: rank 1's shard is empty)."""
+    mctx = mp.get_context("spawn")
+    procs = [mctx.Process(target=_rank, args=(r, 2, B, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    fv, tex = syn.sphere_views(280, B)
+    one = ShardedSoftRasterizer(image_size=32, ctx=ctx)
+    ref = one.forward(fv, tex).numpy()
+    g = np.random.default_rng(0).uniform(-1, 1, ref.shape).astype(np.float32)
+    gf, gt = [x.numpy() for x in one.backward(g)]
+    verts, faces = syn.sphere_mesh(280)
+    gv = one.backward_shared_vertices(g, faces, verts.shape[0]).numpy()
+    for r in range(2):
+        d = np.load(tmp_path / ("rank%d.npz" % r))
+        assert bits_equal(d["images"], ref)
+        assert grad_err(d["gf"], gf) <= 1e-5 and grad_err(d["gt"], gt) <= 1e-5      # float atomics reorder sums
+        assert grad_err(d["gv"], gv) <= 1e-5
+
+
+def test_bench_launcher_spawns_ranks():
+    """`python bench.py --gpus 2` starts 2 ranks itself and reports n_gpus = 2 (on this 1-GPU box the ranks
+    share the GPU and talk through the host communicator; with >= 2 GPUs the same command uses RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--faces", "1280", "--image-size", "128", "--batch", "2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4
+    assert line["exchange"]["kind"] == "allreduce_vertex_grads"
+    assert line["value"] > 0 and line["step_ms"]["median"] > 0
+
+
+def _raw_forward(ctx, lib, fn_args, fv_d, tex_d, B, NF, IS, K):
+    info, aggr = ctx.empty((B, NF, 27)), ctx.empty((B, 2, IS, IS))
+    rgba, ids = ctx.empty((B, 4, IS, IS)), ctx.empty((B, K, IS, IS), np.int32)
+    _ffi._check(lib.jr_softras_forward(ctx.handle, fv_d.ptr, tex_d.ptr, info.ptr, aggr.ptr, rgba.ptr, ids.ptr, *fn_args, None))
+    return info, aggr, rgba, ids, int(lib.jr_softras_forward_token(ctx.handle))
+
+
+def test_backward_never_reuses_stale_face_records(ctx):
+    """reuse of the forward's face records was keyed on POINTER identity.  Here the
+    address of forward A's vertices is recycled for different geometry before A's... and a stale token is
+    presented: every variant must give the oracle's gradients for the data actually passed."""
+    lib = _ffi.load()
+    B, NF, IS, K = 1, 280, 48, 8
+    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+    fn.batch_size, fn.num_faces, fn.texture_size = B, NF, 1
+    fn.func_dist_type, fn.func_rgb_type, fn.func_alpha_type, fn.texture_type = 2, 1, 2, 0
+    args = fn._scalars()
+    fvA, tex = syn.sphere_views(NF, B)
+    fvB = syn.sphere_views(NF, B, azimuth0=77.0, elevation=-20.0)[0]
+    orc = Oracle("port")
+    g = np.random.default_rng(3).uniform(-1, 1, (B, 4, IS, IS)).astype(np.float32)
+    refs = {}
+    for name, fv in (("A", fvA), ("B", fvB)):
+        s = orc.forward(fv, tex, image_size=IS, max_faces_per_pixel_for_grad=K)
+        refs[name] = orc.backward(s, g)[0]
+    P, tex_d, g_d = ctx.array(fvA), ctx.array(tex), ctx.array(g)
+
+    def backward(saved, token):
+        info, aggr, rgba, ids = saved
+        gf, gt = ctx.empty((B, NF, 9)), ctx.empty((B, NF, 1, 3))
+        _ffi._check(lib.jr_softras_backward_ex(ctx.handle, P.ptr, tex_d.ptr, rgba.ptr, info.ptr, aggr.ptr, ids.ptr,
+                                               g_d.ptr, gf.ptr, gt.ptr, *args, C.c_uint64(token)))
+        return gf.numpy().reshape(refs["A"].shape)
+
+    *savedA, tokA = _raw_forward(ctx, lib, args, P, tex_d, B, NF, IS, K)
+    assert tokA != 0
+    assert grad_err(backward(savedA, tokA), refs["A"]) <= 1e-4            # the fast path itself is right
+    # 1) same address, new content written behind the library's back (what a recycling allocator does)
+    hip = C.CDLL("libamdhip64.so")
+    ctx.synchronize()
+    assert hip.hipMemcpy(C.c_void_p(P.ptr), fvB.ctypes.data_as(C.c_void_p), C.c_size_t(fvB.nbytes), 1) == 0
+    *savedB, tokB = _raw_forward(ctx, lib, args, P, tex_d, B, NF, IS, K)
+    assert tokB != tokA
+    # 2) A's stale token with B's data at the same pointer: must rebuild -> B's gradients
+    assert grad_err(backward(savedB, tokA), refs["B"]) <= 1e-4
+    # 3) token 0 (plain jr_softras_backward semantics) after yet another forward elsewhere on the context
+    other = ctx.array(fvA)
+    _raw_forward(ctx, lib, args, other, tex_d, B, NF, IS, K)
+    assert grad_err(backward(savedB, 0), refs["B"]) <= 1e-4
+    assert grad_err(backward(savedB, tokB), refs["B"]) <= 1e-4            # stale token: rebuilt, still right

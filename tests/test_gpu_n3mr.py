@@ -108,3 +108,39 @@ def test_n3mr_validation():
         RasterizeFunction(32, -1.0, 100, 1e-3, (0, 0, 0), True, True, True)(faces, tex)
     with pytest.raises(ValueError):
         RasterizeFunction(32, 0.1, 100, 1e-3, (0, 0, 0), True, False, False)(faces, None)
+
+
+def _degenerate_scene():
+    faces, tex = _scene(280, 1, 2, 9)
+    faces = faces.copy()
+    n = faces.shape[1]
+    faces[0, 5] = faces[0, 5, 0]                 # all three vertices coincide: zero area, w_sum = 0 -> zp = NaN
+    faces[0, 40, 1] = faces[0, 40, 0]            # two coincide: zero area, collinear
+    faces[0, n // 2 + 7, 2, 0] = np.nan          # NaN x in one vertex
+    faces[0, 90, :, 2] = np.nan                  # NaN depths
+    # a coincident-vertex face in front of everything, over an otherwise EMPTY corner of the image
+    faces[0, 11] = np.asarray([-0.9, -0.9, 1.5], np.float32)
+    return faces, tex
+
+
+def test_n3mr_degenerate_and_nan_faces():
+    """a zero-area face (zp = NaN) must not be drawn — the reference's `zp < depth_map` is false
+    for NaN (N3K:147).  Maps bit-exact vs the reference build incl. coincident-vertex and NaN faces."""
+    from oracle import N3mrOracle
+    o = N3mrOracle()
+    faces, tex = _degenerate_scene()
+    for IS in (64, 128):
+        try:
+            ref = o.forward(faces, tex, image_size=IS)
+        except RuntimeError:
+            continue
+        fn = RasterizeFunction(IS, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)
+        fn(faces, tex)
+        f, t, fim, wm, dm, rgb, alpha, fivm, sidx, swt = fn.save_vars
+        assert bits_equal(fim.numpy(), ref["face_index_map"]), "face_index_map"
+        assert not np.isin(fim.numpy(), [5, 11, 40]).any()          # the zero-area faces are never drawn
+        d, dr = dm.numpy(), ref["depth_map"]
+        assert np.array_equal(np.isnan(d), np.isnan(dr)) and bits_equal(np.nan_to_num(d), np.nan_to_num(dr))
+        assert bits_equal(alpha.numpy(), ref["alpha_map"])
+        w, wr = wm.numpy(), ref["weight_map"]
+        assert np.array_equal(np.isnan(w), np.isnan(wr)) and bits_equal(np.nan_to_num(w), np.nan_to_num(wr))

@@ -1,6 +1,12 @@
-"""N>1 path on CPU: world_size-2 `gloo` process group, the sharding/collective logic of
-jrender_amd.parallel driven with a CPU stand-in for the local op (the oracle — tests only)."""
+"""N>1 path on CPU, world size 2: the sharding / collective logic of jrender_amd.parallel driven with a
+CPU stand-in for the local op (the oracle — tests only), over
+  * jrender_amd.comm.HostCommunicator (the package's own local-socket communicator), and
+  * a `gloo` process group wrapped in the same communicator interface (torch is used by this TEST only;
+    the package itself never imports it — test_no_torch_in_product).
+The RCCL communicator itself needs GPUs: tests/test_gpu_comm.py."""
+import multiprocessing as mp
 import os
+import re
 import sys
 
 import numpy as np
@@ -20,6 +26,17 @@ def test_shard_bounds():
             assert b[0][0] == 0 and b[-1][1] == B and all(x[1] == y[0] for x, y in zip(b, b[1:]))
 
 
+def test_no_torch_in_product():
+    """north_star: no PyTorch in the product — package, bench and examples never import it."""
+    paths = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for top in ("jrender_amd", "examples"):
+        for d, _, files in os.walk(os.path.join(ROOT, top)):
+            paths += [os.path.join(d, f) for f in files if f.endswith(".py")]
+    for p in paths:
+        src = open(p).read()
+        assert not re.search(r"^\s*(from|import)\s+(torch|triton|jittor)\b", src, flags=re.M), p
+
+
 class _OracleFunction:
     """execute/grad protocol of SoftRasterizeFunction, computed by the CPU oracle."""
 
@@ -37,36 +54,81 @@ class _OracleFunction:
 
     def grad(self, g):
         if self.saved is None:
-            return np.zeros((0, 1, 3, 3), np.float32), np.zeros((0, 1, 1, 3), np.float32)
+            return np.zeros((0, 280, 3, 3), np.float32), np.zeros((0, 280, 1, 3), np.float32)
         return self.orc.backward(self.saved, g)
 
 
-def _worker(rank, world, port, B, out_dir):
+class _GlooCommunicator:
+    """jrender_amd.comm interface over a torch.distributed gloo group (host arrays)."""
+    backend = "gloo"
+
+    def __init__(self, rank, world, port):
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def bounds(self, batch):
+        from jrender_amd.parallel import shard_bounds
+        return shard_bounds(batch, self.world)
+
+    def all_gather(self, local, batch):
+        import torch
+        bounds = self.bounds(batch)
+        width = max(hi - lo for lo, hi in bounds)
+        t = torch.from_numpy(np.ascontiguousarray(local))
+        pad = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype)
+        pad[: t.shape[0]] = t
+        out = torch.empty((self.world * width,) + tuple(t.shape[1:]), dtype=t.dtype)
+        self.dist.all_gather_into_tensor(out, pad)
+        out = out.numpy().reshape((self.world, width) + tuple(t.shape[1:]))
+        return np.concatenate([out[r, : hi - lo] for r, (lo, hi) in enumerate(bounds)], axis=0)
+
+    def all_reduce_sum(self, x):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(x).copy())
+        self.dist.all_reduce(t)
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def _worker(rank, world, kind, token, B, out_dir):
     sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from jrender_amd import synthetic as syn
+    from jrender_amd import comm as jcomm, synthetic as syn
     from jrender_amd.parallel import ShardedSoftRasterizer
+    if kind == "host":
+        cm = jcomm.HostCommunicator(rank, world, path=os.path.join(out_dir, "rdzv"))
+    else:
+        cm = _GlooCommunicator(rank, world, token)
     fv, tex = syn.sphere_views(280, B)
     kw = dict(image_size=24)
-    sh = ShardedSoftRasterizer(make_function=lambda **k: _OracleFunction(**k), **kw)
+    sh = ShardedSoftRasterizer(make_function=lambda **k: _OracleFunction(**k), comm=cm, **kw)
     images = sh.forward(fv, tex)
     g = np.random.default_rng(0).uniform(-1, 1, images.shape).astype(np.float32)
     gf, gt = sh.backward(g)
     verts, faces = syn.sphere_mesh(280)
     gv = sh.backward_shared_vertices(g, faces, verts.shape[0])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), images=images, gf=gf, gt=gt, gv=gv)
-    dist.barrier()
-    dist.destroy_process_group()
+    cm.barrier()
+    cm.close()
 
 
-@pytest.mark.parametrize("B", [4, 3])
-def test_gloo_world2_matches_single_process(tmp_path, B):
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("kind,B", [("host", 4), ("host", 3), ("host", 1), ("gloo", 4), ("gloo", 3)])
+def test_world2_matches_single_process(tmp_path, kind, B):
     port = 29500 + (os.getpid() % 2000) + B
-    mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, kind, port, B, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, "rank exited with %r" % (p.exitcode,)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     from jrender_amd import synthetic as syn
     from jrender_amd.structures.mesh import face_vertices_backward
@@ -81,3 +143,22 @@ def test_gloo_world2_matches_single_process(tmp_path, B):
     verts, faces = syn.sphere_mesh(280)
     gv = face_vertices_backward(gf, np.broadcast_to(faces[None], (B,) + faces.shape), verts.shape[0]).sum(0)
     assert np.allclose(r0["gv"], gv, rtol=1e-5, atol=1e-6) and np.array_equal(r0["gv"], r1["gv"])
+
+
+def test_single_communicator_is_identity():
+    from jrender_amd import comm as jcomm
+    from jrender_amd.parallel import BatchShards
+    sh = BatchShards()
+    assert (sh.rank, sh.world) == (0, 1)
+    x = np.arange(6, dtype=np.float32).reshape(2, 3)
+    assert sh.all_gather(x, 2) is x and sh.all_reduce_sum(x) is x
+    assert jcomm.SingleCommunicator().all_reduce_max(3.5) == 3.5
+
+
+def test_rendezvous_path_from_env(monkeypatch):
+    from jrender_amd import comm as jcomm
+    monkeypatch.setenv("JRENDER_RDZV", "/tmp/abc")
+    assert jcomm.rendezvous_path() == "/tmp/abc"
+    monkeypatch.delenv("JRENDER_RDZV")
+    monkeypatch.setenv("MASTER_PORT", "1234")
+    assert "1234" in jcomm.rendezvous_path() and str(os.getppid()) in jcomm.rendezvous_path()
