@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libjrender_hip.so")
 SOURCES = ["jr_api.cpp", "jr_comm.cpp", "binning.hip", "softras_forward.hip", "softras_backward.hip", "aux_kernels.hip", "n3mr_kernels.hip"]
-HEADERS = ["jr_kernels.h", "softras_device.h", "../../include/jrender_hip.h"]
+HEADERS = ["jr_kernels.h", "softras_device.h", "jr_tuning.h", "../../include/jrender_hip.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -26,15 +26,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None, defines=()):
+    """variant/defines: an ablation build (tools/ablate): objects and the library get a suffix, the
+    product library is untouched.  Tuning switches are the JR_TUNE_* macros of csrc/jr_tuning.h."""
+    suffix = "" if not variant else "_" + variant
+    lib = os.path.join(CSRC, "libjrender_hip%s.so" % suffix)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        obj = os.path.join(CSRC, os.path.splitext(s)[0] + suffix + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-x", "hip", "-c", src, "-o", obj])
+        if force or variant or _stale(obj, [src] + hdrs):
+            jobs.append([HIPCC, *FLAGS, *["-D" + d for d in defines], "-x", "hip", "-c", src, "-o", obj])
     if jobs:
         def run(cmd):
             if verbose:
@@ -42,12 +46,19 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd, cwd=CSRC)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
-    if jobs or _stale(LIB, objs):
-        tmp = LIB + ".tmp%d" % os.getpid()
+    if jobs or _stale(lib, objs):
+        tmp = lib + ".tmp%d" % os.getpid()
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", tmp], cwd=CSRC)
-        os.replace(tmp, LIB)
-    return LIB
+        os.replace(tmp, lib)
+    if variant:
+        for o in objs:
+            os.unlink(o)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m jrender_amd._build [--force] [--variant NAME -DJR_TUNE_X=1 ...]
+    args = sys.argv[1:]
+    variant = args[args.index("--variant") + 1] if "--variant" in args else None
+    defines = [a[2:] for a in args if a.startswith("-D")]
+    print(build(force="--force" in args, verbose=True, variant=variant, defines=defines))

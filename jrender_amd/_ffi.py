@@ -13,7 +13,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libjrender_hip.so")
+# JRENDER_LIB: another build of the same library (tools/ablate/ builds variants next to the product .so)
+LIB_PATH = os.environ.get("JRENDER_LIB") or os.path.join(_HERE, "csrc", "libjrender_hip.so")
 
 _lib = None
 _lock = threading.Lock()

@@ -1,0 +1,34 @@
+// Tuning switches of the raster kernels.  The product is built with the defaults below; tools/ablate/
+// builds variants with -DJR_TUNE_<X>=0|1 (python -m jrender_amd._build --variant NAME -D...) to reproduce
+// the A/B tables of DESIGN.md on one GPU box.  Every switch selects between two EXACTNESS-EQUIVALENT
+// implementations (same face-index buffer bits, colours / gradients within tolerance).
+#pragma once
+
+#ifndef JR_TUNE_TV_DIVKNOWN      // edge-projection parameter: reciprocal-refinement quotient instead of IEEE '/'
+#define JR_TUNE_TV_DIVKNOWN 0
+#endif
+#ifndef JR_TUNE_FWD_DIS_ONLY     // forward: carry only (sign, dis) out of the distance machinery
+#define JR_TUNE_FWD_DIS_ONLY 0
+#endif
+#ifndef JR_TUNE_FWD_PREPASS      // forward: conservative half-plane pre-cull of (pixel, face) pairs, lane = face
+#define JR_TUNE_FWD_PREPASS 0
+#endif
+#ifndef JR_TUNE_FWD_IDS_LDS      // forward: K-buffer ids live in LDS (one ds_write per insert), depths stay in VGPRs
+#define JR_TUNE_FWD_IDS_LDS 0
+#endif
+#ifndef JR_TUNE_FWD_OCC4         // forward: ask the register allocator for 4 wavefronts per SIMD at K <= 16 (128 VGPRs)
+#define JR_TUNE_FWD_OCC4 1
+#endif
+#ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
+#define JR_TUNE_BWD_TV_RCP 0
+#endif
+
+namespace jr {
+namespace tune {
+constexpr bool tv_divknown = JR_TUNE_TV_DIVKNOWN != 0;
+constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
+constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
+constexpr bool fwd_ids_lds = JR_TUNE_FWD_IDS_LDS != 0;
+constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
+}  // namespace tune
+}  // namespace jr

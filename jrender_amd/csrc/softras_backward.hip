@@ -136,7 +136,8 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     if (DIST == 0) D = 1.f;                                               // SRK:1258-1270
     else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_fast(-dis, p); }
     else {
-        dd = euclidean_p2f<FAST>(r, w, xp, yp);
+        // nothing is decided from the projection parameter here (sign and region come from the exact w)
+        dd = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE)>(r, w, xp, yp);
         dis = dd.dx * dd.dx + dd.dy * dd.dy;
         D = coverage_fast(-dd.sign * dis, p);
     }
@@ -430,6 +431,10 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
     const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
     if (p.K <= 16)
         k_softras_backward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
+            grad_faces, grad_textures);
+    else if (p.K <= 32)
+        k_softras_backward<DIST, RGB, 32><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures);
     else

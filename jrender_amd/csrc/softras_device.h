@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "jr_tuning.h"
+
 namespace jr {
 
 constexpr int TILE = 8;          // pixels per side of a wavefront's tile (8x8 = 64 lanes)
@@ -231,15 +233,34 @@ struct Dist {
 // `r` refers to an LDS record: a per-lane edge index is an LDS address, not a select chain.
 struct EdgeCand { float u0, u1, u2, ex, ey, dd; };
 
-template <bool FAST>
+// TV selects how the quotient of SRK:81 / :132 is formed:
+//   TV_IEEE   plain IEEE division (~50 cycles)
+//   TV_EXACT  the same bits from the reciprocal-refinement quotient: the divisor's correctly rounded
+//             reciprocal comes from recip_exact (FLAG_SAFE faces have Dn in its proven range), the numerator
+//             — which can be a rounding crumb when the pixel projects exactly onto a vertex — is checked
+//             against the refinement's guarantee domain (0 or 2^-80 <= |a| <= 2^60) and takes the IEEE
+//             division otherwise
+//   TV_RCP    reciprocal multiply (<= 2 ulp off): only where nothing is decided from the result
+constexpr int TV_IEEE = 0, TV_EXACT = 1, TV_RCP = 2;
+
+__device__ inline bool in_refinement_domain(float a) {
+    const float m = fabsf(a);
+    return a == 0.f || (m >= 8.271806125530277e-25f && m <= 1.152921504606847e18f);
+}
+
+template <bool FAST, int TV = (tune::tv_divknown ? TV_EXACT : TV_IEEE)>
 __device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e, bool clamp) {
     const int e1 = e == 2 ? 0 : e + 1;
     const float a0 = r.A[3 * e], a1 = r.A[3 * e + 1], a2 = r.A[3 * e + 2];
     const float av1 = r.A[3 * e + e1];
     const float dn = r.Dn[e];
-    // the numerator can be a rounding crumb (pixel projecting exactly onto a vertex), which is
-    // outside the refinement-division guarantee: plain IEEE division here
-    const float tv = (((b.w0 * a0 + b.w1 * a1) + b.w2 * a2) - av1) / dn;                 // SRK:81 / :132
+    const float num = ((b.w0 * a0 + b.w1 * a1) + b.w2 * a2) - av1;                       // SRK:81 / :132
+    float tv;
+    if (FAST && TV == TV_RCP) tv = num * __builtin_amdgcn_rcpf(dn);
+    else if (FAST && TV == TV_EXACT) {
+        tv = div_known<true>(num, dn, recip_exact(dn));
+        if (__builtin_expect(!in_refinement_domain(num), 0)) tv = num / dn;
+    } else tv = num / dn;
     const float tn = 1 - tv;
     // t[e] = tv, t[e+1] = 1 - tv, t[e+2] = 0 (indices mod 3)
     float u0 = e == 0 ? tv : (e == 2 ? tn : 0.f);
@@ -254,15 +275,11 @@ __device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e
     return c;
 }
 
-// squared-distance machinery, euclidean mode (SRK:57-147).  The inside case (three edge
-// projections, keep the nearest) and the outside case (one edge chosen from the sign pattern of
-// w, clamped) share the first projection so that a wavefront with both kinds of pixels does not
-// execute two separate code paths; the two further projections run only if some lane is inside.
-template <bool FAST>
-__device__ inline Dist euclidean_p2f(const FaceGeo& r, const Bary& b, float xp, float yp) {
-    const bool inside = b.w0 > 0 && b.w1 > 0 && b.w2 > 0 && b.w0 < 1 && b.w1 < 1 && b.w2 < 1;
-    // SRK:107-121: two non-positive weights -> the vertex region `corner` (edge = corner, unless the
-    // vertex is the obtuse one and the pixel lies beyond it: then the previous edge); one -> that edge
+// region of an outside pixel (SRK:107-121): two non-positive weights -> the vertex region `corner` (edge =
+// corner, unless the vertex is the obtuse one and the pixel lies beyond it: then the previous edge); one ->
+// that edge.  Returns the edge index, or -1 where the reference indexes t[-1] (undefined behaviour: some
+// w >= 1 by rounding while none is <= 0).
+__device__ inline int outside_edge(const FaceGeo& r, const Bary& b, float xp, float yp) {
     const bool n0 = b.w0 <= 0, n1 = b.w1 <= 0, n2 = b.w2 <= 0;
     int v0 = -1, corner = -1;
     if (n1 && n2) corner = 0;
@@ -280,16 +297,31 @@ __device__ inline Dist euclidean_p2f(const FaceGeo& r, const Bary& b, float xp, 
             if ((xp - xc) * (xy[2 * other] - xc) + (yp - yc) * (xy[2 * other + 1] - yc) > 0) v0 = other;
         }
     }
+    return v0;
+}
+
+__device__ inline bool strictly_inside(const Bary& b) {
+    return b.w0 > 0 && b.w1 > 0 && b.w2 > 0 && b.w0 < 1 && b.w1 < 1 && b.w2 < 1;
+}
+
+// squared-distance machinery, euclidean mode (SRK:57-147).  The inside case (three edge
+// projections, keep the nearest) and the outside case (one edge chosen from the sign pattern of
+// w, clamped) share the first projection so that a wavefront with both kinds of pixels does not
+// execute two separate code paths; the two further projections run only if some lane is inside.
+template <bool FAST, int TV = (tune::tv_divknown ? TV_EXACT : TV_IEEE)>
+__device__ inline Dist euclidean_p2f(const FaceGeo& r, const Bary& b, float xp, float yp) {
+    const bool inside = strictly_inside(b);
+    const int v0 = outside_edge(r, b, xp, yp);
     Dist d;
-    const EdgeCand c = edge_candidate<FAST>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
+    const EdgeCand c = edge_candidate<FAST, TV>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
     if (inside) {
         // SRK:68-105: dis_min starts at 1e8, strict '<' keeps the first of equal candidates
         float best = 100000000.f;
         d.dx = 0.f; d.dy = 0.f; d.t0 = 0.f; d.t1 = 0.f; d.t2 = 0.f;
         if (c.dd < best) { best = c.dd; d.dx = c.ex; d.dy = c.ey; d.t0 = c.u0; d.t1 = c.u1; d.t2 = c.u2; }
-        const EdgeCand c1 = edge_candidate<FAST>(r, b, 1, false);
+        const EdgeCand c1 = edge_candidate<FAST, TV>(r, b, 1, false);
         if (c1.dd < best) { best = c1.dd; d.dx = c1.ex; d.dy = c1.ey; d.t0 = c1.u0; d.t1 = c1.u1; d.t2 = c1.u2; }
-        const EdgeCand c2 = edge_candidate<FAST>(r, b, 2, false);
+        const EdgeCand c2 = edge_candidate<FAST, TV>(r, b, 2, false);
         if (c2.dd < best) { best = c2.dd; d.dx = c2.ex; d.dy = c2.ey; d.t0 = c2.u0; d.t1 = c2.u1; d.t2 = c2.u2; }
         d.sign = 1.f;
     } else if (v0 < 0) {
@@ -300,6 +332,32 @@ __device__ inline Dist euclidean_p2f(const FaceGeo& r, const Bary& b, float xp, 
         d.sign = -1.f; d.dx = c.ex; d.dy = c.ey; d.t0 = c.u0; d.t1 = c.u1; d.t2 = c.u2;
     }
     return d;
+}
+
+// What the FORWARD needs of it: the sign and the squared distance dx*dx + dy*dy (SRK:341-342), which is
+// bit for bit the candidate's own dd = ex*ex + ey*ey; the nearest point and its barycentric offsets (six
+// selects per candidate) are only used by the backward.  An inside pixel is never culled by distance, so
+// its three projections only feed the coverage sigmoid (colour path, 1e-4): reciprocal multiply there.
+template <bool FAST>
+__device__ inline void euclidean_sign_dis(const FaceGeo& r, const Bary& b, float xp, float yp, float& sign,
+                                          float& dis) {
+    const bool inside = strictly_inside(b);
+    const int v0 = outside_edge(r, b, xp, yp);
+    const EdgeCand c = edge_candidate<FAST>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
+    if (inside) {
+        constexpr int TVI = tune::tv_divknown ? TV_RCP : TV_IEEE;
+        const float d1 = edge_candidate<FAST, TVI>(r, b, 1, false).dd;
+        const float d2 = edge_candidate<FAST, TVI>(r, b, 2, false).dd;
+        float best = 100000000.f;                    // SRK:68: candidates that are not < 1e8 (NaN) leave dis = 0
+        if (c.dd < best) best = c.dd;
+        if (d1 < best) best = d1;
+        if (d2 < best) best = d2;
+        sign = 1.f;
+        dis = best < 100000000.f ? best : 0.f;
+    } else {
+        sign = -1.f;
+        dis = v0 < 0 ? 0.f : c.dd;
+    }
 }
 
 __device__ inline float barycentric_dist(const Bary& b) {                             // SRK:150-154

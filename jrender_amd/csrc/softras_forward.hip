@@ -31,21 +31,30 @@
 
 namespace jr {
 
+// ids never feed a decision: with tune::fwd_ids_lds they live in LDS ([slot][lane] words, one ds_write per
+// insert instead of KCAP selects) and only the depths stay in registers.
 template <int KCAP>
 struct KBuffer {
-    int id[KCAP];
+    int id[tune::fwd_ids_lds ? 1 : KCAP];
     float z[KCAP];
     int size;
     float max_z;
     int max_slot;
+    int* lds_ids;                  // this lane's column of the [K][64] id table (tune::fwd_ids_lds)
 
     // Slots >= K are never written; their depth is -inf so that the rescan (which starts from -1) can
     // run over all KCAP registers without a per-slot "k < K" predicate (16 SGPR pairs otherwise).
-    __device__ inline void init(int K) {
+    __device__ inline void init(int K, int* ids_column) {
+        lds_ids = ids_column;
 #pragma unroll
-        for (int k = 0; k < KCAP; k++) { id[k] = -1; z[k] = k < K ? 0.f : -__builtin_inff(); }
+        for (int k = 0; k < KCAP; k++) {
+            if (!tune::fwd_ids_lds) id[k] = -1;
+            else if (k < K) lds_ids[k * 64] = -1;
+            z[k] = k < K ? 0.f : -__builtin_inff();
+        }
         size = 0; max_z = -1.f; max_slot = -1;
     }
+    __device__ inline int id_of(int k) const { return tune::fwd_ids_lds ? lds_ids[k * 64] : id[k]; }
     // K-nearest insert with the reference's slot semantics (SRK:369-385): append while not
     // full (tracking the first largest depth), afterwards overwrite the largest-depth slot
     // when strictly nearer and rescan, first maximum wins.
@@ -53,10 +62,11 @@ struct KBuffer {
         const bool filling = size < K;
         if (!filling && !(zp < max_z)) return;
         const int slot = filling ? size : max_slot;
+        if (tune::fwd_ids_lds) lds_ids[slot * 64] = fn;
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             const bool hit = k == slot;
-            id[k] = hit ? fn : id[k];
+            if (!tune::fwd_ids_lds) id[k] = hit ? fn : id[k];
             z[k] = hit ? zp : z[k];
         }
         if (filling) {
@@ -128,10 +138,15 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
         neg_num = -dis;
         D = coverage_fast(neg_num, p);
     } else {                                                                   // SRK:340-344
-        const Dist dd = euclidean_p2f<FAST>(r, w, xp, yp);
-        const float dis = dd.dx * dd.dx + dd.dy * dd.dy;
-        if (dd.sign < 0 && dis >= p.thr) return;
-        neg_num = -dd.sign * dis;
+        float sign, dis;
+        if (tune::fwd_dis_only) euclidean_sign_dis<FAST>(r, w, xp, yp, sign, dis);
+        else {
+            const Dist dd = euclidean_p2f<FAST>(r, w, xp, yp);
+            sign = dd.sign;
+            dis = dd.dx * dd.dx + dd.dy * dd.dy;
+        }
+        if (sign < 0 && dis >= p.thr) return;
+        neg_num = -sign * dis;
         D = coverage_fast(neg_num, p);
     }
     // alpha aggregation happens before the depth cull (SRK:350-358)
@@ -176,7 +191,7 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
 }
 
 template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) void k_softras_forward(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? (JR_TUNE_FWD_OCC4 ? 4 : 1) : (KCAP <= 32 ? 2 : 1)))) void k_softras_forward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
@@ -186,6 +201,7 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
     float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
+    int* s_ids = reinterpret_cast<int*>(s_vcol + (p.tex == 1 ? 9 * CHUNK : 0)); // [K][64] iff tune::fwd_ids_lds
 
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
     // bin (same list, same records) go to ONE XCD so that they share its L2.
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     else if (RGB == 1) { s.c0 = p.bg[0] * s.ssum; s.c1 = p.bg[1] * s.ssum; s.c2 = p.bg[2] * s.ssum; }
     s.depth_min = 10000000.f;
     s.face_min = -1;
-    s.q.init(p.K);
+    s.q.init(p.K, s_ids + lane);
 
     const unsigned long long* seg = pool + bin_base[bin];
     const FaceGeo* gbase = geo + (size_t)b * p.NF;
@@ -287,7 +303,80 @@ __global__ __launch_bounds__(64) void k_softras_forward(
                 ry[c] = ballot(have && !(yc(c) > box.w) && !(yc(c) < box.z));
             }
             // private mask of the faces that pass this pixel's border test
-            unsigned long long M = valid ? (select8(cx, lx) & select8(ry, ly)) : 0ull;
+            unsigned long long M;
+            if (DIST == 2 && tune::fwd_prepass) {
+                // Conservative pre-cull, lane = slot.  A pixel that lies more than the cull radius beyond the
+                // LINE of one edge (on its outer side) is farther than the radius from the triangle, and the
+                // reference culls that pair by distance (SRK:341-342) before it touches any state.  With w_k
+                // the barycentric of vertex k (affine in the pixel, |grad w_k| = g_k = 1 / altitude_k) the test is
+                //     w_k(pixel) < -g_k * (rad + margin)     for some k,
+                // evaluated for the face of this lane at all 64 pixel centres: 5 VALU per pixel, and the v_cmp
+                // result IS the 64-face reject mask of that pixel.
+                // The margin covers what the reference's float arithmetic can make of the distance, which this
+                // test does not reproduce ("pre-cull margin"; measured with tools/sim/precull_noise.py
+                // on 10^7 kept pairs: the reference's distance falls short of the geometric one by at most 0.91 E):
+                //   E1: face_inv is star/det with ONE rounded det, so the three w_k sum to 1 + delta instead of 1 and
+                //       the reference effectively measures from the pixel displaced by (a x + b y + c - 1) * position,
+                //       a, b, c = column sums of face_inv;
+                //   E2: rounding of w_k itself (3 eps S_k per weight, S_k = |inv0| X + |inv1| Y + |inv2|) times the
+                //       vertex positions, and of the three products that form the offset vector.
+                // margin = 2.5 (E1 + E2) + 1e-4 rad; a face whose margin would exceed rad / 2, or that is outside the
+                // fast-arithmetic range, never rejects.  Survivors run the exact arithmetic as before: the pre-cull
+                // can only remove work, never change a result.
+                float gx[3], gy[3], cc[3];
+                {
+                    const FaceRec& me = s_rec[have ? lane : 0];
+                    constexpr float EPS = 5.9604645e-08f;     // 2^-24
+                    const float X = fmaxf(fabsf(box.x), fabsf(box.y)), Y = fmaxf(fabsf(box.z), fabsf(box.w));
+                    const float pos = __builtin_sqrtf(__builtin_fmaf(X, X, Y * Y));
+                    const float ext = (box.y - box.x) + (box.w - box.z);
+                    const float* vx = &me.x0;
+                    float g[3], gmax = 0.f, ssum = 0.f, sv = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        gx[q] = me.inv[3 * q]; gy[q] = me.inv[3 * q + 1];
+                        g[q] = __builtin_sqrtf(__builtin_fmaf(gx[q], gx[q], gy[q] * gy[q]));
+                        gmax = fmaxf(gmax, g[q]);
+                        const float S = __builtin_fmaf(fabsf(gx[q]), X, __builtin_fmaf(fabsf(gy[q]), Y, fabsf(me.inv[3 * q + 2])));
+                        ssum += S;
+                        sv = __builtin_fmaf(S, __builtin_sqrtf(__builtin_fmaf(vx[2 * q], vx[2 * q], vx[2 * q + 1] * vx[2 * q + 1])), sv);
+                    }
+                    const float ca = fabsf((gx[0] + gx[1]) + gx[2]), cb = fabsf((gy[0] + gy[1]) + gy[2]);
+                    const float cd = fabsf(((me.inv[2] + me.inv[5]) + me.inv[8]) - 1.f);
+                    const float e1 = (__builtin_fmaf(ca, X, __builtin_fmaf(cb, Y, cd)) + 4.f * EPS * ssum) * pos;
+                    const float e2 = 3.f * EPS * sv + 4.f * EPS * __builtin_fmaf(gmax, ext, 1.f) * pos;
+                    const float margin = __builtin_fmaf(2.5f, e1 + e2, 1.0001f * p.rad);
+                    // NaN anywhere makes the comparison false -> never rejects
+                    const bool ok = have && (me.flags & FLAG_SAFE) && p.consts_safe && (margin <= 1.5f * p.rad);
+#pragma unroll
+                    for (int q = 0; q < 3; q++) cc[q] = __builtin_fmaf(margin, g[q], me.inv[3 * q + 2]);
+                    if (!ok) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) { gx[q] = 0.f; gy[q] = 0.f; cc[q] = 1.f; }
+                    }
+                }
+                int mlo = 0, mhi = 0;
+#pragma unroll
+                for (int rr = 0; rr < 8; rr++) {
+                    const float yq = yc(rr);
+                    const float b0 = __builtin_fmaf(gy[0], yq, cc[0]), b1 = __builtin_fmaf(gy[1], yq, cc[1]),
+                                b2 = __builtin_fmaf(gy[2], yq, cc[2]);
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const float xq = xc(c);
+                        const float smin = __builtin_fminf(__builtin_fminf(__builtin_fmaf(gx[0], xq, b0), __builtin_fmaf(gx[1], xq, b1)),
+                                                           __builtin_fmaf(gx[2], xq, b2));
+                        const unsigned long long keep = cx[c] & ry[rr] & ~ballot(smin < 0.f);
+                        // v_writelane_b32: the wave-uniform mask goes into lane (rr, c) of the mask registers
+                        // (clang has no builtin for it)
+                        asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((int)(unsigned)keep), "n"(rr * 8 + c));
+                        asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((int)(unsigned)(keep >> 32)), "n"(rr * 8 + c));
+                    }
+                }
+                M = valid ? (((unsigned long long)(unsigned)mhi << 32) | (unsigned)mlo) : 0ull;
+            } else {
+                M = valid ? (select8(cx, lx) & select8(ry, ly)) : 0ull;
+            }
             while (M) {
                 const int j = __builtin_ctzll(M);
                 M &= M - 1;
@@ -326,16 +415,21 @@ __global__ __launch_bounds__(64) void k_softras_forward(
     int32_t* io = ids + (size_t)b * p.K * pp + pn;
 #pragma unroll
     for (int k = 0; k < KCAP; k++)
-        if (k < p.K) io[(size_t)k * pp] = s.q.id[k];
+        if (k < p.K) io[(size_t)k * pp] = s.q.id_of(k);
 }
 
 template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
     const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
-    const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
+    const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0) +
+                        (tune::fwd_ids_lds ? sizeof(int) * 64 * (size_t)p.K : 0);
+    // K-buffer capacity: 16 (the default K), 32 (K = 17..32: 2 wavefronts per SIMD), 64 (1 wavefront per SIMD)
     if (p.K <= 16)
         k_softras_forward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+    else if (p.K <= 32)
+        k_softras_forward<DIST, RGB, 32><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
     else
         k_softras_forward<DIST, RGB, 64><<<grid, 64, smem, st>>>(

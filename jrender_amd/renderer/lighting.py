@@ -154,7 +154,14 @@ class Lighting:
             for d in self.directionals:
                 diffuse, specular = d(diffuse, specular, mesh.vertex_normals, mesh.vertices, eyes,
                                       mesh.with_specular, mesh.metallic_textures, mesh.roughness_textures)
-            mesh.textures = np.clip(mesh.textures * diffuse + np.ones_like(mesh.textures) * specular, 0.0, 1.0)
+            # lighting.py:212-218 handles 4-D and 6-D textures only; per-vertex colours [B,NV,3] (what Mesh
+            # stores for texture_type='vertex') match neither branch and stay UNLIT in the reference — kept.
+            if mesh.textures.ndim == 4:
+                mesh.textures = np.clip(mesh.textures * diffuse[:, :, None] +
+                                        np.ones_like(mesh.textures) * specular[:, :, None], 0.0, 1.0)
+            elif mesh.textures.ndim == 6:
+                mesh.textures = np.clip(mesh.textures * diffuse[:, :, None, None, None] +
+                                        np.ones_like(mesh.textures) * specular[:, :, None, None, None], 0.0, 1.0)
         return mesh
 
     execute = __call__

@@ -236,7 +236,12 @@ class Mesh(object):
         from ..io import load_obj
         textures = None
         face_texcoords = None
-        if load_texture:
+        if load_texture and dr_type == 'n3mr':
+            vertices, faces, textures = load_obj(
+                filename_obj, normalization=normalization, texture_res=texture_res, load_texture=True,
+                dr_type=dr_type, texture_type=texture_type, texture_wrapping=texture_wrapping,
+                use_bilinear=use_bilinear)
+        elif load_texture:
             vertices, faces, textures, _, _, face_texcoords = load_obj(
                 filename_obj, normalization=normalization, texture_res=texture_res, load_texture=True,
                 dr_type=dr_type, texture_type=texture_type)

@@ -297,3 +297,36 @@ class N3mrOracle:
         if rc:
             raise RuntimeError("n3mr reference backward failed rc=%d" % rc)
         return gf.reshape(B, NF, 3, 3), gt
+
+
+class TexturesOracle:
+    """The reference's texel-sampler kernels compiled for the host (oracle/_ref/libtextures_ref.so;
+    jrender/io/utils/load_textures.py:11-69 and :103-219).  Only exists where oracle/_ref was built."""
+
+    def __init__(self):
+        import importlib
+        path = importlib.import_module(__name__ + ".build_ref").build_textures()
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("oracle/_ref/libtextures_ref.so not built and /root/reference not mounted")
+        self.lib = C.CDLL(path)
+
+    def softras(self, image, faces, textures, is_update):
+        img = np.ascontiguousarray(image, np.float32)
+        f = np.ascontiguousarray(faces, np.float32)
+        out = np.array(textures, np.float32, copy=True)
+        upd = np.ascontiguousarray(is_update, np.int32)
+        NF, RR = out.shape[:2]
+        self.lib.ref_load_textures_softras(_fp(img), _fp(f), _ip(upd), _fp(out), NF, int(round(np.sqrt(RR))),
+                                           img.shape[0], img.shape[1])
+        return out
+
+    def n3mr(self, image, faces, textures, is_update, texture_wrapping=0, use_bilinear=True):
+        img = np.ascontiguousarray(image, np.float32)
+        f = np.ascontiguousarray(faces, np.float32)
+        out = np.array(textures, np.float32, copy=True)
+        upd = np.ascontiguousarray(is_update, np.int32)
+        rc = self.lib.ref_load_textures_n3mr(_fp(img), _fp(f), _ip(upd), _fp(out), out.shape[0], out.shape[1],
+                                             img.shape[0], img.shape[1], int(texture_wrapping), int(bool(use_bilinear)))
+        if rc:
+            raise RuntimeError("unknown (texture_wrapping, use_bilinear) pair")
+        return out

@@ -145,6 +145,63 @@ def build_n3mr(force=False):
     return N3_LIB
 
 
+LTX = os.path.join(REF_ROOT, "jrender/io/utils/load_textures.py")
+LTX_LIB = os.path.join(OUT_DIR, "libtextures_ref.so")
+
+
+def _extract_textures():
+    """`cuda_header` of the softras texel sampler and of the n3mr sampler for every
+    (texture_wrapping, use_bilinear) pair (the reference substitutes both into the source text)."""
+    captured = []
+    stub = types.ModuleType("jittor")
+
+    def code(shape, dtype, inputs, **kw):
+        captured.append(kw)
+        return _Var(shape, dtype)
+
+    stub.code = code
+    saved = sys.modules.get("jittor")
+    sys.modules["jittor"] = stub
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_ltx", LTX)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        img, faces, upd = _Var((4, 4, 3)), _Var((1, 3, 2)), _Var((1,), "int32")
+        mod._load_textures_for_softras(img, faces, _Var((1, 4, 3)), upd)
+        out = {"ltx_softras": captured[-1]["cuda_header"]}
+        for w in range(4):
+            for b in range(2):
+                mod._load_textures_for_n3mr(img, faces, _Var((1, 2, 2, 2, 3)), upd, w, b)
+                out["ltx_n3mr_%d_%d" % (w, b)] = captured[-1]["cuda_header"]
+    finally:
+        if saved is None:
+            del sys.modules["jittor"]
+        else:
+            sys.modules["jittor"] = saved
+    return out
+
+
+def build_textures(force=False):
+    """Build (or reuse) oracle/_ref/libtextures_ref.so; None when the reference tree is not mounted."""
+    if not os.path.exists(LTX):
+        return LTX_LIB if os.path.exists(LTX_LIB) else None
+    deps = [LTX, os.path.join(HERE, "ref_textures_driver.cpp"), os.path.join(HERE, "ref_shim/cuda_runtime.h"),
+            os.path.abspath(__file__)]
+    if (not force and os.path.exists(LTX_LIB)
+            and os.path.getmtime(LTX_LIB) >= max(os.path.getmtime(d) for d in deps)):
+        return LTX_LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    for name, src in _extract_textures().items():
+        with open(os.path.join(OUT_DIR, name + ".inc"), "w") as f:
+            f.write(src)
+    tmp = tempfile.mktemp(suffix=".so", dir=OUT_DIR)
+    flags = [f for f in CXXFLAGS if f != "-fopenmp"]
+    subprocess.check_call(["g++", *flags, "-I", HERE, "-I", os.path.join(HERE, "ref_shim"),
+                           os.path.join(HERE, "ref_textures_driver.cpp"), "-o", tmp], cwd=HERE)
+    os.replace(tmp, LTX_LIB)
+    return LTX_LIB
+
+
 def build(force=False):
     """Build (or reuse) oracle/_ref/libsoftras_ref.so.  Returns its path, or
     None when the reference tree is not mounted (e.g. on the GPU box)."""
@@ -172,3 +229,4 @@ def build(force=False):
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     print(build_n3mr(force="--force" in sys.argv))
+    print(build_textures(force="--force" in sys.argv))

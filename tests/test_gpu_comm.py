@@ -108,7 +108,7 @@ def test_bench_launcher_spawns_ranks():
     share the GPU and talk through the host communicator; with >= 2 GPUs the same command uses RCCL)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--faces", "1280", "--image-size", "128", "--batch", "2", "--no-cpu-baseline"],
+                          "--faces", "3300", "--image-size", "128", "--batch", "2", "--no-cpu-baseline"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])

@@ -203,3 +203,74 @@ def test_flatten_loss_analytic_backward_matches_central_differences():
         xm[0, i, d] -= h
         num = (total(xp) - total(xm)) / (2 * h)
         assert abs(num - g[0, i, d]) <= 1e-5 * max(1.0, abs(num))
+
+
+def _cook_torrance_f64(n, pos, eye, ldir, lint, lcol, metallic, roughness):
+    """Scalar float64 restatement of directional_lighting.py:86-130 (+ GGX :5-20, SchlickGGX :22-33,
+    GeometrySmith :35-47, fresnelSchlick :49-54) for ONE face: -> (diffuse[3], specular[3]) contributions."""
+    import math
+    L = np.asarray(ldir, np.float64)
+    L = L / math.sqrt(float(L @ L))
+    cosine = max(float(n @ L), 0.0)
+    V = np.asarray(eye, np.float64) - pos
+    V = V / max(math.sqrt(float(V @ V)), 1e-12)
+    H = V + L
+    H = H / max(math.sqrt(float(H @ H)), 1e-12)
+    F0 = 0.4 * (1 - metallic) + 1.0 * metallic
+    radiance = lint * np.asarray(lcol, np.float64) * cosine
+    a2 = (roughness * roughness) ** 2
+    ndh = max(float(n @ H), 0.0)
+    d = ndh * ndh * (a2 - 1.0) + 1.0
+    NDF = a2 / (3.1415 * d * d)
+    k = (roughness + 1.0) ** 2 / 8.0
+    ndv, ndl = max(float(n @ V), 0.0), max(float(n @ L), 0.0)
+    G = (ndl / (ndl * (1.0 - k) + k)) * (ndv / (ndv * (1.0 - k) + k))
+    Fr = F0 + (1.0 - F0) * (1.0 - max(float(H @ V), 0.0)) ** 5
+    KD = (1.0 - Fr) * (1.0 - metallic)
+    spec = NDF * G * Fr / max(4.0 * ndv * ndl, 0.01)
+    return KD * radiance, spec * radiance
+
+
+def test_cook_torrance_values_match_float64_restatement():
+    """VERDICT r1 (row f3): value-level pin of the Cook-Torrance branch, face by face."""
+    from jrender_amd.renderer.lighting import directional_lighting
+    rng = np.random.default_rng(5)
+    B, N = 2, 37
+    normals = rng.normal(size=(B, N, 3)).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=2, keepdims=True)
+    pos = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    eye = np.asarray([[0.3, 0.2, -2.7], [1.0, -0.5, -2.0]], np.float32)
+    metallic = rng.uniform(0, 1, (B, N, 4, 3)).astype(np.float32)        # [B,NF,T,3]: averaged over texels (:69-72)
+    rough = rng.uniform(0.05, 1, (B, N, 4, 3)).astype(np.float32)
+    ldir, lint, lcol = (0.3, 1.0, -0.4), 0.7, (1.0, 0.9, 0.8)
+    d0 = rng.uniform(0, 0.5, (B, N, 3)).astype(np.float32)
+    diff, spec = directional_lighting(d0, np.zeros_like(d0), normals, lint, lcol, ldir, pos, eye, True, metallic, rough)
+    m, r = metallic.astype(np.float64).sum(2) / 4.0, rough.astype(np.float64).sum(2) / 4.0
+    for b in range(B):
+        for i in range(N):
+            kd, sp = _cook_torrance_f64(normals[b, i].astype(np.float64), pos[b, i].astype(np.float64), eye[b], ldir, lint,
+                                        lcol, m[b, i], r[b, i])
+            assert np.allclose(diff[b, i], d0[b, i] + kd, rtol=2e-5, atol=2e-6), (b, i)
+            assert np.allclose(spec[b, i], sp, rtol=2e-4, atol=2e-6), (b, i)
+    assert spec.max() > 0.05                                            # the specular lobe is really exercised
+
+
+def test_lighting_surface_applies_diffuse_and_specular_and_vertex_rule():
+    v, f = jr.synthetic.uv_sphere(10, 7)
+    m = jr.Mesh(v, f, textures=np.full((f.shape[0], 4, 3), 0.5, np.float32))
+    m.with_specular = True
+    jr.Lighting(intensity_ambient=0.3, intensity_directionals=0.6, directions=[0.2, 1, -0.3])(m, eyes=[0.1, 0.4, -2.7])
+    from jrender_amd.renderer.lighting import ambient_lighting, directional_lighting
+    m0 = jr.Mesh(v, f)
+    d = ambient_lighting(np.zeros(m0.faces.shape, np.float32), 0.3, [1, 1, 1])
+    d, s = directional_lighting(d, np.zeros(m0.faces.shape, np.float32), m0.surface_normals, 0.6, [1, 1, 1], [0.2, 1, -0.3],
+                                np.sum(m0.face_vertices, axis=2) / np.float32(3.0), [0.1, 0.4, -2.7], True,
+                                m0.metallic_textures, m0.roughness_textures)
+    want = np.clip(0.5 * d[:, :, None] + s[:, :, None], 0, 1)
+    assert np.allclose(m.textures, np.broadcast_to(want, m.textures.shape), atol=1e-6)
+    # light_mode='vertex' with per-vertex colours [B,NV,3]: the reference's branches (lighting.py:212-218) match
+    # neither 4-D nor 6-D textures, so the colours stay unlit — pinned (ADVICE r1)
+    tv = np.random.default_rng(0).uniform(0, 1, (v.shape[0], 3)).astype(np.float32)
+    mv = jr.Mesh(v, f, textures=tv, texture_type='vertex')
+    jr.Lighting(light_mode='vertex')(mv, eyes=[0, 0, -2.7])
+    assert np.array_equal(mv.textures[0], tv)
