@@ -8,13 +8,19 @@
 #define JR_TUNE_TV_DIVKNOWN 0
 #endif
 #ifndef JR_TUNE_FWD_DIS_ONLY     // forward: carry only (sign, dis) out of the distance machinery
-#define JR_TUNE_FWD_DIS_ONLY 0
+#define JR_TUNE_FWD_DIS_ONLY 1
 #endif
 #ifndef JR_TUNE_FWD_PREPASS      // forward: conservative half-plane pre-cull of (pixel, face) pairs, lane = face
-#define JR_TUNE_FWD_PREPASS 0
+#define JR_TUNE_FWD_PREPASS 1
 #endif
 #ifndef JR_TUNE_FWD_IDS_LDS      // forward: K-buffer ids live in LDS (one ds_write per insert), depths stay in VGPRs
 #define JR_TUNE_FWD_IDS_LDS 0
+#endif
+#ifndef JR_TUNE_FWD_IDS_LDS_BIGK // forward: the same for K > 16 only (where the registers no longer hold ids + depths)
+#define JR_TUNE_FWD_IDS_LDS_BIGK 1
+#endif
+#ifndef JR_TUNE_FWD_INSIDE_RCP   // forward: 2nd / 3rd edge projection of INSIDE pixels (colour path only) by reciprocal multiply
+#define JR_TUNE_FWD_INSIDE_RCP 0
 #endif
 #ifndef JR_TUNE_FWD_OCC4         // forward: ask the register allocator for 4 wavefronts per SIMD at K <= 16 (128 VGPRs)
 #define JR_TUNE_FWD_OCC4 1
@@ -29,6 +35,8 @@ constexpr bool tv_divknown = JR_TUNE_TV_DIVKNOWN != 0;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
 constexpr bool fwd_ids_lds = JR_TUNE_FWD_IDS_LDS != 0;
+constexpr bool fwd_ids_lds_bigk = JR_TUNE_FWD_IDS_LDS_BIGK != 0;
+constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 }  // namespace tune
 }  // namespace jr

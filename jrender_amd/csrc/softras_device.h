@@ -345,7 +345,7 @@ __device__ inline void euclidean_sign_dis(const FaceGeo& r, const Bary& b, float
     const int v0 = outside_edge(r, b, xp, yp);
     const EdgeCand c = edge_candidate<FAST>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
     if (inside) {
-        constexpr int TVI = tune::tv_divknown ? TV_RCP : TV_IEEE;
+        constexpr int TVI = (tune::tv_divknown || tune::fwd_inside_rcp) ? TV_RCP : TV_IEEE;
         const float d1 = edge_candidate<FAST, TVI>(r, b, 1, false).dd;
         const float d2 = edge_candidate<FAST, TVI>(r, b, 2, false).dd;
         float best = 100000000.f;                    // SRK:68: candidates that are not < 1e8 (NaN) leave dis = 0

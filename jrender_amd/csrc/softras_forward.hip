@@ -31,11 +31,17 @@
 
 namespace jr {
 
-// ids never feed a decision: with tune::fwd_ids_lds they live in LDS ([slot][lane] words, one ds_write per
-// insert instead of KCAP selects) and only the depths stay in registers.
+// ids never feed a decision.  For K <= 16 they sit in registers next to the depths (measured: moving them to
+// LDS costs 18 % — the [K][64] table caps a CU at 10 wavefronts).  Above that the registers do not fit any
+// more (KCAP = 64: 256 VGPRs, one wavefront per SIMD), so the ids live in LDS ([slot][lane] words, one
+// ds_write per insert instead of KCAP selects) and only the depths stay in registers (KCAP = 64: 130 VGPRs).
+template <int KCAP>
+constexpr bool ids_in_lds() { return tune::fwd_ids_lds || (KCAP > 16 && tune::fwd_ids_lds_bigk); }
+
 template <int KCAP>
 struct KBuffer {
-    int id[tune::fwd_ids_lds ? 1 : KCAP];
+    static constexpr bool IDS_LDS = ids_in_lds<KCAP>();
+    int id[IDS_LDS ? 1 : KCAP];
     float z[KCAP];
     int size;
     float max_z;
@@ -48,13 +54,13 @@ struct KBuffer {
         lds_ids = ids_column;
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
-            if (!tune::fwd_ids_lds) id[k] = -1;
+            if (!IDS_LDS) id[k] = -1;
             else if (k < K) lds_ids[k * 64] = -1;
             z[k] = k < K ? 0.f : -__builtin_inff();
         }
         size = 0; max_z = -1.f; max_slot = -1;
     }
-    __device__ inline int id_of(int k) const { return tune::fwd_ids_lds ? lds_ids[k * 64] : id[k]; }
+    __device__ inline int id_of(int k) const { return IDS_LDS ? lds_ids[k * 64] : id[k]; }
     // K-nearest insert with the reference's slot semantics (SRK:369-385): append while not
     // full (tracking the first largest depth), afterwards overwrite the largest-depth slot
     // when strictly nearer and rescan, first maximum wins.
@@ -62,11 +68,11 @@ struct KBuffer {
         const bool filling = size < K;
         if (!filling && !(zp < max_z)) return;
         const int slot = filling ? size : max_slot;
-        if (tune::fwd_ids_lds) lds_ids[slot * 64] = fn;
+        if (IDS_LDS) lds_ids[slot * 64] = fn;
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             const bool hit = k == slot;
-            if (!tune::fwd_ids_lds) id[k] = hit ? fn : id[k];
+            if (!IDS_LDS) id[k] = hit ? fn : id[k];
             z[k] = hit ? zp : z[k];
         }
         if (filling) {
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
     float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
-    int* s_ids = reinterpret_cast<int*>(s_vcol + (p.tex == 1 ? 9 * CHUNK : 0)); // [K][64] iff tune::fwd_ids_lds
+    int* s_ids = reinterpret_cast<int*>(s_vcol + (p.tex == 1 ? 9 * CHUNK : 0)); // [K][64] iff ids_in_lds<KCAP>()
 
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
     // bin (same list, same records) go to ONE XCD so that they share its L2.
@@ -422,8 +428,9 @@ template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
     const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
+    const bool ids_lds = p.K <= 16 ? ids_in_lds<16>() : ids_in_lds<64>();
     const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0) +
-                        (tune::fwd_ids_lds ? sizeof(int) * 64 * (size_t)p.K : 0);
+                        (ids_lds ? sizeof(int) * 64 * (size_t)p.K : 0);
     // K-buffer capacity: 16 (the default K), 32 (K = 17..32: 2 wavefronts per SIMD), 64 (1 wavefront per SIMD)
     if (p.K <= 16)
         k_softras_forward<DIST, RGB, 16><<<grid, 64, smem, st>>>(

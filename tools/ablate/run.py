@@ -13,11 +13,13 @@ from variants import VARIANTS           # noqa: E402
 args = sys.argv[1:]
 rounds = int(args[args.index("--rounds") + 1]) if "--rounds" in args else 2
 parity = "--no-parity" not in args
-names = [a for a in args if not a.startswith("--") and not a.isdigit()] or list(VARIANTS)
+extra = args[args.index("--bench-args") + 1].split() if "--bench-args" in args else []
+skip = {args[i + 1] for i, a in enumerate(args) if a in ("--rounds", "--bench-args")}
+names = [a for a in args if not a.startswith("--") and a not in skip] or list(VARIANTS)
 
 
 def lib(n):
-    return os.path.join(ROOT, "jrender_amd", "csrc", "libjrender_hip_%s.so" % n)
+    return os.path.join(ROOT, "jrender_amd", "csrc", "libjrender_hip.so" if n == "product" else "libjrender_hip_%s.so" % n)
 
 
 res = {n: [] for n in names}
@@ -38,7 +40,7 @@ for r in range(rounds):
     for n in names:
         if status.get(n) == "missing":
             continue
-        p = subprocess.run([sys.executable, "bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"], cwd=ROOT,
+        p = subprocess.run([sys.executable, "bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"] + extra, cwd=ROOT,
                            env=dict(os.environ, JRENDER_LIB=lib(n)), capture_output=True, text=True)
         try:
             d = json.loads(p.stdout.strip().splitlines()[-1])

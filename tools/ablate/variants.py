@@ -2,18 +2,16 @@
 `python tools/ablate/build.py [names...]` builds them next to the product library (CPU box, hipcc);
 `python tools/ablate/run.py [names...]` (GPU box) checks parity and times each one in ONE process
 sequence on ONE box (boxes differ by a few per cent: only numbers from one call are comparable)."""
+OFF = ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_IDS_LDS_BIGK=0"]
 VARIANTS = {
-    "base": [],
-    "base_noocc": ["JR_TUNE_FWD_OCC4=0"],                    # without the waves-per-SIMD request (round-1 register allocation)
-    "pre_dis": ["JR_TUNE_FWD_PREPASS=1", "JR_TUNE_FWD_DIS_ONLY=1"],
-    "pre_noocc": ["JR_TUNE_FWD_PREPASS=1", "JR_TUNE_FWD_OCC4=0"],                                              # every switch off = round-1 kernels
-    "tv": ["JR_TUNE_TV_DIVKNOWN=1"],
-    "dis": ["JR_TUNE_FWD_DIS_ONLY=1"],
-    "tvdis": ["JR_TUNE_TV_DIVKNOWN=1", "JR_TUNE_FWD_DIS_ONLY=1"],
-    "pre": ["JR_TUNE_FWD_PREPASS=1"],
-    "idslds": ["JR_TUNE_FWD_IDS_LDS=1"],
-    "bwdrcp": ["JR_TUNE_BWD_TV_RCP=1"],
-    "all": ["JR_TUNE_TV_DIVKNOWN=1", "JR_TUNE_FWD_DIS_ONLY=1", "JR_TUNE_FWD_PREPASS=1", "JR_TUNE_BWD_TV_RCP=1"],
-    "all_ids": ["JR_TUNE_TV_DIVKNOWN=1", "JR_TUNE_FWD_DIS_ONLY=1", "JR_TUNE_FWD_PREPASS=1", "JR_TUNE_BWD_TV_RCP=1",
-                "JR_TUNE_FWD_IDS_LDS=1"],
+    "product": [],                                           # the defaults of jr_tuning.h
+    "r1": OFF,                                               # every switch off = round-1 kernels
+    "r1_occ4": OFF[:2] + OFF[3:],                            # + the 4-waves-per-SIMD request alone
+    "no_prepass": ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_OCC4=0"],
+    "no_dis": ["JR_TUNE_FWD_DIS_ONLY=0"],
+    "tv": ["JR_TUNE_TV_DIVKNOWN=1"],                         # dead: exact reciprocal-refinement quotient for tv
+    "ids_lds": ["JR_TUNE_FWD_IDS_LDS=1"],                    # dead at K <= 16: K-buffer ids in LDS
+    "bigk_regs": ["JR_TUNE_FWD_IDS_LDS_BIGK=0"],             # K > 16 with ids in registers (round 1)
+    "bwd_rcp": ["JR_TUNE_BWD_TV_RCP=1"],                     # dead: breaks the 1e-4 gradient bar
+    "inside_rcp": ["JR_TUNE_FWD_INSIDE_RCP=1"],
 }

@@ -17,8 +17,26 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from jrender_amd import synthetic as syn
 
 IS = int(os.environ.get("IS", 1024)); NF = int(os.environ.get("NF", 39000))
-fv, _ = syn.sphere_views(NF, 1)
+fv, _tex = syn.sphere_views(NF, 1)
 f = fv[0].astype(np.float64)                       # [NF,3,3]
+# the kernel's pre-cull margin needs the reference's float face_inv (its det rounding is the dominant term)
+from oracle import Oracle
+_info = Oracle("port").forward_subset(fv, _tex, np.zeros(1, np.int64), image_size=IS)["faces_info"][0]
+def kernel_margin(ids, rad):
+    F = np.float32; EPS = F(2.0 ** -24); rad = F(rad)
+    inv = _info[ids, :9]; xx = fv[0][ids][:, :, 0]; yy = fv[0][ids][:, :, 1]
+    xlo_, xhi_, ylo_, yhi_ = xx.min(1) - rad, xx.max(1) + rad, yy.min(1) - rad, yy.max(1) + rad
+    X = np.maximum(np.abs(xlo_), np.abs(xhi_)); Y = np.maximum(np.abs(ylo_), np.abs(yhi_))
+    pos = np.sqrt(X * X + Y * Y); ext = (xhi_ - xlo_) + (yhi_ - ylo_)
+    g = np.stack([np.sqrt(inv[:, 3 * q] ** 2 + inv[:, 3 * q + 1] ** 2) for q in range(3)], 1)
+    S = np.stack([np.abs(inv[:, 3 * q]) * X + np.abs(inv[:, 3 * q + 1]) * Y + np.abs(inv[:, 3 * q + 2]) for q in range(3)], 1)
+    sv = (S * np.sqrt(xx * xx + yy * yy)).sum(1)
+    ca = np.abs((inv[:, 0] + inv[:, 3]) + inv[:, 6]); cb = np.abs((inv[:, 1] + inv[:, 4]) + inv[:, 7])
+    cd = np.abs(((inv[:, 2] + inv[:, 5]) + inv[:, 8]) - F(1))
+    e1 = ((ca * X + cb * Y + cd) + F(4) * EPS * S.sum(1)) * pos
+    e2 = F(3) * EPS * sv + F(4) * EPS * (g.max(1) * ext + F(1)) * pos
+    m = F(2.5) * (e1 + e2) + F(1.0001) * rad
+    return np.where(m <= F(1.5) * rad, m, np.inf).astype(np.float64)
 sigma, dist_eps = 1e-5, np.log(1 / 1e-4 - 1)
 thr = dist_eps * sigma; rad = np.sqrt(thr)
 x = f[:, :, 0]; y = f[:, :, 1]
@@ -68,17 +86,7 @@ for t in sample:
     area2 = np.abs((X[:, 1] - X[:, 0]) * (Y[:, 2] - Y[:, 0]) - (X[:, 2] - X[:, 0]) * (Y[:, 1] - Y[:, 0]))
     sgn = np.sign((X[:, 1] - X[:, 0]) * (Y[:, 2] - Y[:, 0]) - (X[:, 2] - X[:, 0]) * (Y[:, 1] - Y[:, 0]))[:, None]
     L = [np.hypot(X[:, (k + 1) % 3] - X[:, k], Y[:, (k + 1) % 3] - Y[:, k])[:, None] for k in range(3)]
-    # the kernel's margin (softras_forward.hip): rad + 2.5 (E1 + E2); E1 (det rounding) is not modelled in
-    # float64, so take its measured typical size: E1 + E2 ~ 3 (3 eps sum S_k |v_k|)
-    eps = 2.0 ** -24
-    area = np.maximum(area2, 1e-300)
-    Xb = np.maximum(np.abs(xlo[ids]), np.abs(xhi[ids])); Yb = np.maximum(np.abs(ylo[ids]), np.abs(yhi[ids]))
-    gk = [L[(k + 1) % 3][:, 0] / area for k in range(3)]                 # |grad w_k| = opposite edge / (2 area)
-    Sk = [gk[k] * (Xb + Yb) * 2 for k in range(3)]
-    vn = [np.hypot(X[:, k], Y[:, k]) for k in range(3)]
-    E = 3 * (3 * eps * sum(Sk[k] * vn[k] for k in range(3)))
-    m = (1.0001 * rad + 2.5 * E)
-    m = np.where(m <= 1.5 * rad, m, np.inf)[:, None]
+    m = kernel_margin(ids, rad)[:, None]
     add("margin_over_rad", float(np.mean(np.minimum(m, 10 * rad)) / rad))
     halfplane = inbox & ~((sgn * e0 < -m * L[0]) | (sgn * e1 < -m * L[1]) | (sgn * e2 < -m * L[2]))
     cxm = X.mean(1)[:, None]; cym = Y.mean(1)[:, None]
@@ -95,6 +103,10 @@ for t in sample:
         for bs in (64, 128):
             trips = sum(int(Mk[s:s + bs].sum(0).max()) for s in range(0, n, bs))
             add("%s.trips%d" % (name, bs), trips)
+        # what the kernel does: batches are formed from the BOX survivors, the refined masks only thin them out
+        kb = inbox.any(1)
+        Mb = M[kb]
+        add(name + ".trips64boxbatch", sum(int(Mb[s:s + 64].sum(0).max()) for s in range(0, Mb.shape[0], 64)))
         add(name + ".stream", int(Mk.sum(0).max()) if n else 0)
         add(name + ".ideal", -(-int(Mk.sum()) // 64))
     add("tiles", 1)
@@ -104,6 +116,7 @@ print("mean margin/rad %.3f" % (acc["margin_over_rad"] / acc["tiles"]))
 print("survive %.3f of box pairs, inside %.3f" % (acc["survive_pairs"] / acc["box.pairs"], acc["inside_pairs"] / acc["box.pairs"]))
 for name in ("box", "halfplane", "hp+circle", "exact"):
     p = acc[name + ".pairs"]
+    print("%-10s box-batched trips64 %d (%.3f of box)" % (name, acc[name + ".trips64boxbatch"], acc[name + ".trips64boxbatch"] / acc["box.trips64boxbatch"]))
     print("%-10s pairs %.3f | trips64 %7d (util %.2f) trips128 %7d (%.2f) stream %7d (%.2f) ideal %7d | trips64 vs box %.3f"
           % (name, p / acc["box.pairs"], acc[name + ".trips64"], p / 64 / acc[name + ".trips64"],
              acc[name + ".trips128"], p / 64 / acc[name + ".trips128"], acc[name + ".stream"], p / 64 / acc[name + ".stream"],
