@@ -82,6 +82,7 @@ def main(argv=None):
     ap.add_argument('--iters', type=int, default=200)
     ap.add_argument('--image-size', type=int, default=64)
     ap.add_argument('-o', '--output', default=None, help="write the optimised mesh to this .obj")
+    ap.add_argument('--template-vertices', default=None, help=".obj, or .npz with 'vertices' / 'faces' (default: a 1 352-vertex UV sphere)")
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--gpus', type=int, default=1, help="spawn this many ranks (one process per GPU)")
     args = ap.parse_args(argv)
@@ -95,7 +96,13 @@ def main(argv=None):
     # one process per GPU: the context follows LOCAL_RANK; RCCL when every rank owns a GPU, else host sockets
     comm = jcomm.init_from_env(jr.Context.default()) if world > 1 else None
 
-    tv, tf = jr.synthetic.uv_sphere(52, 27)                                   # 1 352-vertex class template (sphere_1352)
+    if args.template_vertices and args.template_vertices.endswith(".npz"):
+        z = np.load(args.template_vertices)
+        tv, tf = z["vertices"], z["faces"]
+    elif args.template_vertices:
+        tv, tf = jr.load_obj(args.template_vertices)                         # demo2-deform.py:61 (sphere_1352.obj)
+    else:
+        tv, tf = jr.synthetic.uv_sphere(52, 27)                               # 1 352-vertex class template
     model = Model(tv, tf)
     renderer = jr.Renderer(image_size=args.image_size, sigma_val=1e-4, aggr_func_rgb='hard', camera_mode='look_at',
                            viewing_angle=15, dr_type='softras', bin_size=16, max_elems_per_bin=2700,

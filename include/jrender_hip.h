@@ -197,6 +197,14 @@ int jr_n3mr_backward(jr_ctx* ctx, const float* faces, const int32_t* face_index_
                      float* grad_textures, int B, int NF, int TS, int IS, float eps, int return_rgb,
                      int return_alpha, int return_depth);
 
+/* Output transform of the NMR functional API (n3mr.py:240-256, Jittor tensor ops in the reference): a map in the
+ * rasteriser's layout [B,H,W,C] with bottom-up rows -> [B,C,H/pool,W/pool] top-down, 2x2 mean when pool == 2
+ * (anti_aliasing); C = 3 for rgb, 1 for alpha / depth.  The backward spreads grad_out / pool^2 back. */
+int jr_n3mr_image_forward(jr_ctx* ctx, const float* in_nhwc, float* out_nchw, int B, int H, int W, int C,
+                          int pool);
+int jr_n3mr_image_backward(jr_ctx* ctx, const float* grad_out_nchw, float* grad_in_nhwc, int B, int H,
+                           int W, int C, int pool);
+
 /* ---- self-test of the exact-division identity the kernels rely on (softras_device.h):
  * evaluates n pseudo-random (a, b) pairs on the GPU and counts results of the reciprocal-refinement
  * quotient that differ in any bit from the IEEE quotient a / b.  Must return 0 mismatches. */

@@ -55,6 +55,8 @@ SIGNATURES = {
     "jr_avgpool2x2_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_n3mr_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float] * 3 + [c_float_p] + [C.c_int] * 3),
     "jr_n3mr_backward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_float] + [C.c_int] * 3),
+    "jr_n3mr_image_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5),
+    "jr_n3mr_image_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5),
     "jr_selftest_division": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "jr_selftest_reciprocal": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "jr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

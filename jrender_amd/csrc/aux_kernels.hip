@@ -80,6 +80,59 @@ __global__ __launch_bounds__(256) void k_avgpool_bwd(const float* __restrict__ g
     *reinterpret_cast<float2*>(d + 2 * Wo) = make_float2(g, g);
 }
 
+// NMR output transform (jrender/renderer/dr/n3mr/n3mr.py:240-256, Jittor tensor ops in the reference): the
+// rasteriser's maps are NHWC with BOTTOM-UP rows; the functional API returns NCHW, top-down, 2x2-mean-pooled when
+// anti_aliasing.  One thread per output pixel moves all C channels (C contiguous floats per input pixel).
+template <int S>
+__global__ __launch_bounds__(256) void k_n3mr_image_fwd(const float* __restrict__ in, float* __restrict__ out,
+                                                        int B, int H, int W, int C) {
+    const int Ho = H / S, Wo = W / S;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Ho * Wo) return;
+    const int x = (int)(i % Wo);
+    const long r = i / Wo;
+    const int y = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    for (int c = 0; c < C; c++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < S; dy++)
+#pragma unroll
+            for (int dx = 0; dx < S; dx++)
+                acc += in[(((long)b * H + (H - 1 - (S * y + dy))) * W + (S * x + dx)) * C + c];
+        out[(((long)b * C + c) * Ho + y) * Wo + x] = S == 1 ? acc : acc / (S * S);
+    }
+}
+template <int S>
+__global__ __launch_bounds__(256) void k_n3mr_image_bwd(const float* __restrict__ gout, float* __restrict__ gin,
+                                                        int B, int H, int W, int C) {
+    const int Ho = H / S, Wo = W / S;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per INPUT pixel (b, row, col)
+    if (i >= (long)B * H * W) return;
+    const int col = (int)(i % W);
+    const long r = i / W;
+    const int row = (int)(r % H);
+    const int b = (int)(r / H);
+    const int y = (H - 1 - row) / S, x = col / S;
+    for (int c = 0; c < C; c++) {
+        const float g = gout[(((long)b * C + c) * Ho + y) * Wo + x];
+        gin[i * C + c] = S == 1 ? g : g / (S * S);
+    }
+}
+
+void launch_n3mr_image_forward(hipStream_t st, const float* in, float* out, int B, int H, int W, int C, int pool) {
+    const long total = (long)B * (H / pool) * (W / pool);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (pool == 2) k_n3mr_image_fwd<2><<<grid, 256, 0, st>>>(in, out, B, H, W, C);
+    else k_n3mr_image_fwd<1><<<grid, 256, 0, st>>>(in, out, B, H, W, C);
+}
+void launch_n3mr_image_backward(hipStream_t st, const float* gout, float* gin, int B, int H, int W, int C, int pool) {
+    const long total = (long)B * H * W;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (pool == 2) k_n3mr_image_bwd<2><<<grid, 256, 0, st>>>(gout, gin, B, H, W, C);
+    else k_n3mr_image_bwd<1><<<grid, 256, 0, st>>>(gout, gin, B, H, W, C);
+}
+
 void launch_face_vertices_forward(hipStream_t st, const float* v, const int32_t* faces, float* fv, int B,
                                   int NV, int NF) {
     const long total = (long)B * NF * 3;

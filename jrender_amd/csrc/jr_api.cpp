@@ -544,6 +544,25 @@ int jr_n3mr_backward(jr_ctx* ctx, const float* faces, const int32_t* face_index_
     return 0;
 }
 
+int jr_n3mr_image_forward(jr_ctx* ctx, const float* in_nhwc, float* out_nchw, int B, int H, int W, int C, int pool) {
+    if (!ctx || !in_nhwc || !out_nchw) return fail("jr_n3mr_image_forward: NULL argument");
+    if (B < 1 || H < 1 || W < 1 || C < 1 || (pool != 1 && pool != 2) || (pool == 2 && ((H | W) & 1)))
+        return fail("jr_n3mr_image_forward: bad sizes (pool must be 1 or 2, H and W even when pooling)");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_n3mr_image_forward(ctx->stream, in_nhwc, out_nchw, B, H, W, C, pool);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_n3mr_image_backward(jr_ctx* ctx, const float* grad_out_nchw, float* grad_in_nhwc, int B, int H, int W, int C, int pool) {
+    if (!ctx || !grad_out_nchw || !grad_in_nhwc) return fail("jr_n3mr_image_backward: NULL argument");
+    if (B < 1 || H < 1 || W < 1 || C < 1 || (pool != 1 && pool != 2) || (pool == 2 && ((H | W) & 1)))
+        return fail("jr_n3mr_image_backward: bad sizes (pool must be 1 or 2, H and W even when pooling)");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_n3mr_image_backward(ctx->stream, grad_out_nchw, grad_in_nhwc, B, H, W, C, pool);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
 int jr_selftest_division(jr_ctx* ctx, uint64_t n, uint32_t seed, uint64_t* mismatches) {
     if (!ctx || !mismatches) return fail("NULL argument");
     JR_HIP(hipSetDevice(ctx->device));

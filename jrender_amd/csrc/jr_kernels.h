@@ -41,6 +41,8 @@ void launch_face_vertices_backward_shared(hipStream_t st, const float* gfv, cons
                                           float* gv, int B, int NV, int NF);
 void launch_avgpool2x2_forward(hipStream_t st, const float* in, float* out, int planes, int H, int W);
 void launch_avgpool2x2_backward(hipStream_t st, const float* gout, float* gin, int planes, int H, int W);
+void launch_n3mr_image_forward(hipStream_t st, const float* in, float* out, int B, int H, int W, int C, int pool);
+void launch_n3mr_image_backward(hipStream_t st, const float* gout, float* gin, int B, int H, int W, int C, int pool);
 void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textures, float* faces_inv,
                          unsigned long long* zkey, int32_t* face_index_map, float* weight_map, float* depth_map,
                          float* face_inv_map, float* rgb_map, float* alpha_map, int32_t* sampling_index_map,

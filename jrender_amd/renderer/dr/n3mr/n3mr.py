@@ -4,7 +4,8 @@
 ``grad(grad_rgb, grad_alpha, grad_depth)`` protocol and its ten saved tensors (N3F:116); the five
 JIT ops + the host compositing between them are ``jr_n3mr_forward`` / ``jr_n3mr_backward``.
 The functional API (``rasterize_rgbad`` & co., N3F:189-346) does the NHWC->NCHW permute, the
-vertical flip and the optional 2x2 mean pool on the host (NumPy), like the reference's tensor ops.
+vertical flip and the optional 2x2 mean pool on the device (``jr_n3mr_image_forward``) and returns
+DeviceArrays; ``RasterizeRGBAD`` is the same call as an object with a ``backward``.
 """
 import ctypes as C
 
@@ -12,7 +13,7 @@ import numpy as np
 
 from .... import _ffi
 
-__all__ = ["RasterizeFunction", "Rasterize", "rasterize_rgbad", "rasterize", "rasterize_silhouettes",
+__all__ = ["RasterizeFunction", "Rasterize", "RasterizeRGBAD", "rasterize_rgbad", "rasterize", "rasterize_silhouettes",
            "rasterize_depth", "DEFAULT_IMAGE_SIZE", "DEFAULT_ANTI_ALIASING", "DEFAULT_NEAR", "DEFAULT_FAR",
            "DEFAULT_EPS", "DEFAULT_BACKGROUND_COLOR"]
 
@@ -116,29 +117,71 @@ class Rasterize:
         return self.fn(faces, textures)
 
 
-def _pool2(x):
-    s = x.shape
-    return x.reshape(s[:-2] + (s[-2] // 2, 2, s[-1] // 2, 2)).mean((-3, -1)).astype(np.float32)
+def _image_forward(x, channels, pool):
+    """[B,H,W,C] bottom-up device map -> [B,C,H/pool,W/pool] top-down (jr_n3mr_image_forward)."""
+    ctx = x.ctx
+    B, H, W = x.shape[:3]
+    out = ctx.empty((B, channels, H // pool, W // pool))
+    _ffi._check(_ffi.load().jr_n3mr_image_forward(ctx.handle, x.ptr, out.ptr, B, H, W, channels, pool))
+    return out
+
+
+def _image_backward(g, ctx, B, H, W, channels, pool):
+    """gradient wrt [B,C,H/pool,W/pool] (host or device) -> gradient wrt the [B,H,W,C] bottom-up map."""
+    g = g if isinstance(g, _ffi.DeviceArray) else ctx.array(np.asarray(g, np.float32))
+    if g.size != B * channels * (H // pool) * (W // pool):
+        raise ValueError("gradient of %d elements for an image [%d,%d,%d,%d]" % (g.size, B, channels, H // pool, W // pool))
+    out = ctx.empty((B, H, W, channels) if channels > 1 else (B, H, W))
+    _ffi._check(_ffi.load().jr_n3mr_image_backward(ctx.handle, g.ptr, out.ptr, B, H, W, channels, pool))
+    return out
+
+
+class RasterizeRGBAD:
+    """rasterize_rgbad (N3F:189-265) as an object that remembers what its backward needs: the NMR op at the
+    super-sampled size, then the transpose / vertical flip / 2x2 mean pool ON THE DEVICE
+    (jr_n3mr_image_forward; Jittor tensor ops in the reference).  ``backward`` maps image gradients back
+    through the same chain to (grad_faces, grad_textures)."""
+
+    def __init__(self, image_size=DEFAULT_IMAGE_SIZE, anti_aliasing=DEFAULT_ANTI_ALIASING, near=DEFAULT_NEAR,
+                 far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR, return_rgb=True,
+                 return_alpha=True, return_depth=True, ctx=None):
+        self.pool = 2 if anti_aliasing else 1
+        self.size = image_size * self.pool
+        self.flags = (return_rgb, return_alpha, return_depth)
+        self.fn = RasterizeFunction(self.size, near, far, eps, background_color, return_rgb, return_alpha,
+                                    return_depth, ctx=ctx)
+
+    def __call__(self, faces, textures=None):
+        rgb, alpha, depth = self.fn(faces, textures)
+        rr, ra, rd = self.flags
+        out = {'rgb': None, 'alpha': None, 'depth': None}
+        if rr:
+            out['rgb'] = _image_forward(rgb, 3, self.pool)                                  # [B,3,IS,IS]
+        if ra:
+            a = _image_forward(alpha, 1, self.pool)
+            out['alpha'] = a if self.pool == 2 else a.reshape(a.shape[0], a.shape[2], a.shape[3])   # N3F:252-254
+        if rd:
+            d = _image_forward(depth, 1, self.pool)
+            out['depth'] = d if self.pool == 2 else d.reshape(d.shape[0], d.shape[2], d.shape[3])
+        return out
+
+    def backward(self, grad_rgb=None, grad_alpha=None, grad_depth=None):
+        ctx = self.fn._ctx
+        B, S = self.fn.batch_size, self.size
+        rr, ra, rd = self.flags
+        g_rgb = _image_backward(grad_rgb, ctx, B, S, S, 3, self.pool) if (rr and grad_rgb is not None) else None
+        g_a = _image_backward(grad_alpha, ctx, B, S, S, 1, self.pool) if (ra and grad_alpha is not None) else None
+        g_d = _image_backward(grad_depth, ctx, B, S, S, 1, self.pool) if (rd and grad_depth is not None) else None
+        return self.fn.grad(g_rgb, g_a, g_d)
 
 
 def rasterize_rgbad(faces, textures=None, image_size=DEFAULT_IMAGE_SIZE, anti_aliasing=DEFAULT_ANTI_ALIASING,
                     near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR,
                     return_rgb=True, return_alpha=True, return_depth=True):
-    """N3F:189-265 -> {'rgb': [B,3,IS,IS], 'alpha': [B,IS,IS], 'depth': [B,IS,IS]} (NumPy)."""
-    size = image_size * 2 if anti_aliasing else image_size
-    rgb, alpha, depth = Rasterize(size, near, far, eps, background_color, return_rgb, return_alpha,
-                                  return_depth)(faces, textures)
-    out = {'rgb': None, 'alpha': None, 'depth': None}
-    if return_rgb:
-        r = rgb.numpy().transpose(0, 3, 1, 2)[:, :, ::-1, :]                              # N3F:240-244
-        out['rgb'] = _pool2(r) if anti_aliasing else np.ascontiguousarray(r)
-    if return_alpha:
-        a = alpha.numpy()[:, ::-1, :]
-        out['alpha'] = _pool2(a[:, None]) if anti_aliasing else np.ascontiguousarray(a)
-    if return_depth:
-        d = depth.numpy()[:, ::-1, :]
-        out['depth'] = _pool2(d[:, None]) if anti_aliasing else np.ascontiguousarray(d)
-    return out
+    """N3F:189-265 -> {'rgb': [B,3,IS,IS], 'alpha', 'depth': [B,IS,IS] ([B,1,IS,IS] with anti_aliasing, like
+    the reference's nn.pool(x.unsqueeze(1)))} as DeviceArrays."""
+    return RasterizeRGBAD(image_size, anti_aliasing, near, far, eps, background_color, return_rgb, return_alpha,
+                          return_depth)(faces, textures)
 
 
 def rasterize(faces, textures, image_size=DEFAULT_IMAGE_SIZE, anti_aliasing=DEFAULT_ANTI_ALIASING,

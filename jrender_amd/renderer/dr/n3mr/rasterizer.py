@@ -1,7 +1,7 @@
 """N3mrRasterizer — host-side mirror of jrender/renderer/dr/n3mr/rasterizer.py (N3R:9-105)."""
 import numpy as np
 
-from .n3mr import rasterize, rasterize_depth, rasterize_rgbad, rasterize_silhouettes
+from .n3mr import RasterizeRGBAD
 from ....structures.mesh import face_vertices as vertices_to_faces
 
 __all__ = ["N3mrRasterizer", "vertices_to_faces"]
@@ -39,21 +39,28 @@ class N3mrRasterizer:
                 textures = np.concatenate((textures, textures.transpose(0, 1, 4, 3, 2, 5)), axis=1)
         return faces, textures
 
+    def _run(self, vertices, faces, textures, rgb, alpha, depth):
+        faces, textures = self._fill_back(faces, textures if rgb else None)
+        self._op = RasterizeRGBAD(self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
+                                  self.background_color if rgb else None, rgb, alpha, depth)
+        return self._op(vertices_to_faces(vertices, faces), textures)
+
     def render_silhouettes(self, vertices, faces):
-        faces, _ = self._fill_back(faces)
-        return rasterize_silhouettes(vertices_to_faces(vertices, faces), self.image_size, self.anti_aliasing)
+        return self._run(vertices, faces, None, False, True, False)['alpha']
 
     def render_depth(self, vertices, faces):
-        faces, _ = self._fill_back(faces)
-        return rasterize_depth(vertices_to_faces(vertices, faces), self.image_size, self.anti_aliasing)
+        return self._run(vertices, faces, None, False, False, True)['depth']
 
     def render_rgb(self, vertices, faces, textures):
-        faces, textures = self._fill_back(faces, textures)
-        return rasterize(vertices_to_faces(vertices, faces), textures, self.image_size, self.anti_aliasing,
-                         self.near, self.far, self.rasterizer_eps, self.background_color)
+        return self._run(vertices, faces, textures, True, False, False)['rgb']
 
     def render(self, vertices, faces, textures):
-        faces, textures = self._fill_back(faces, textures)
-        out = rasterize_rgbad(vertices_to_faces(vertices, faces), textures, self.image_size, self.anti_aliasing,
-                              self.near, self.far, self.rasterizer_eps, self.background_color)
+        out = self._run(vertices, faces, textures, True, True, True)
         return out['rgb'], out['depth'], out['alpha']
+
+    def backward(self, grad_rgb=None, grad_silhouettes=None, grad_depth=None):
+        """Image gradients of the last render -> (grad_face_vertices [B,NF',3,3], grad_textures or None) on the
+        device; NF' counts the back faces that fill_back appended (the caller folds them back)."""
+        if getattr(self, "_op", None) is None:
+            raise RuntimeError("backward before a render")
+        return self._op.backward(grad_rgb, grad_silhouettes, grad_depth)

@@ -143,11 +143,14 @@ class Lighting:
                 diffuse, specular = d(diffuse, specular, mesh.surface_normals, centres, eyes,
                                       mesh.with_specular, mesh.metallic_textures, mesh.roughness_textures)
             diffuse, specular = diffuse[:, :, None], specular[:, :, None]
-            if mesh.textures.ndim == 4:
-                mesh.textures = np.clip(mesh.textures * diffuse + np.ones_like(mesh.textures) * specular, 0.0, 1.0)
-            elif mesh.textures.ndim == 6:
-                mesh.textures = np.clip(mesh.textures * diffuse[:, :, None, None] +
-                                        np.ones_like(mesh.textures) * specular[:, :, None, None], 0.0, 1.0)
+            self._last = None
+            if mesh.textures.ndim == 6:
+                diffuse, specular = diffuse[:, :, None, None], specular[:, :, None, None]
+            if mesh.textures.ndim in (4, 6):
+                pre = mesh.textures * diffuse + np.ones_like(mesh.textures) * specular
+                # d(lit)/d(textures), kept for Renderer.grad_textures (autograd in the reference)
+                self._last = {"dlit": (np.broadcast_to(diffuse, pre.shape) * ((pre > 0.0) & (pre < 1.0))).astype(F32)}
+                mesh.textures = np.clip(pre, 0.0, 1.0)
         elif self.light_mode == 'vertex':
             diffuse = self.ambient(np.zeros(mesh.vertices.shape, F32))
             specular = np.zeros(mesh.vertices.shape, F32)

@@ -61,20 +61,47 @@ class Renderer:
         mesh = self.transform(mesh)
         return self.rasterizer(mesh, mode)
 
-    def grad_vertices(self, grad_silhouettes=None, grad_rgb=None):
-        """d(loss)/d(world-space vertices) [B,nv,3] of the last ``render_mesh`` (softras, look_at camera)
-        for upstream image gradients: rasteriser backward (HIP) -> scatter of the face-vertex gradients to
-        the vertices -> camera transform VJP.  The reference gets this chain from Jittor autograd."""
-        if self.dr_type != 'softras' or not hasattr(self.transform.transformer, 'backward'):
-            raise NotImplementedError("grad_vertices: softras rasteriser with a look_at camera only")
-        gfv, _ = self.rasterizer.backward(grad_silhouettes=grad_silhouettes, grad_rgb=grad_rgb)
-        v = self._world_vertices
+    def _fold_back(self, g, transpose_cube=False):
+        """fill_back appended the reversed faces (and, for NMR cube textures, their transposed textures):
+        fold the gradients of the appended half back onto the original faces."""
         nf = np.asarray(self._faces).shape[-2]
-        gfv = gfv.numpy().reshape(v.shape[0], -1, 3, 3)
-        if gfv.shape[1] == 2 * nf:          # fill_back doubled the faces: (f, f reversed) -> fold back
-            gfv = gfv[:, :nf] + gfv[:, nf:, ::-1]
+        if g.shape[1] != 2 * nf:
+            return g
+        if transpose_cube:                                  # N3R:84: textures.permute(0, 1, 4, 3, 2, 5)
+            return g[:, :nf] + g[:, nf:].transpose(0, 1, 4, 3, 2, 5)
+        return g[:, :nf] + g[:, nf:, ::-1]
+
+    def _rasterizer_backward(self, grad_silhouettes, grad_rgb, grad_depth):
+        if self.dr_type == 'softras':
+            if grad_depth is not None:
+                raise ValueError("the softras rasteriser has no depth output")
+            return self.rasterizer.backward(grad_silhouettes=grad_silhouettes, grad_rgb=grad_rgb)
+        return self.rasterizer.backward(grad_rgb=grad_rgb, grad_silhouettes=grad_silhouettes, grad_depth=grad_depth)
+
+    def grad_vertices(self, grad_silhouettes=None, grad_rgb=None, grad_depth=None):
+        """d(loss)/d(world-space vertices) [B,nv,3] of the last ``render_mesh`` (look_at camera) for upstream
+        image gradients: rasteriser backward (HIP: SoftRas, or NMR's approximate gradients) -> scatter of
+        the face-vertex gradients to the vertices -> camera transform VJP.  The reference gets this chain
+        from Jittor autograd."""
+        if not hasattr(self.transform.transformer, 'backward'):
+            raise NotImplementedError("grad_vertices: look_at camera only")
+        gfv, _ = self._rasterizer_backward(grad_silhouettes, grad_rgb, grad_depth)
+        v = self._world_vertices
+        gfv = self._fold_back(gfv.numpy().reshape(v.shape[0], -1, 3, 3))
         gndc = face_vertices_backward(gfv, self._faces, v.shape[1])
         return self.transform.transformer.backward(gndc, v)
+
+    def grad_textures(self, grad_rgb):
+        """d(loss)/d(mesh.textures) of the last ``render_mesh(mode='rgb')`` with 'surface' textures ([B,NF,T,3]
+        for softras, [B,NF,ts,ts,ts,3] for n3mr): rasteriser backward -> fold of the fill_back half ->
+        derivative of the lighting step clip(textures * diffuse + specular, 0, 1) (what demo4-optim_textures
+        differentiates through)."""
+        lit = getattr(self.lighting, "_last", None)
+        if lit is None:
+            raise RuntimeError("grad_textures: render_mesh(mode='rgb') with light_mode='surface' first")
+        _, gt = self._rasterizer_backward(None, grad_rgb, None)
+        gt = self._fold_back(gt.numpy(), transpose_cube=self.dr_type == 'n3mr')
+        return (gt * lit["dlit"]).astype(np.float32)
 
     def execute(self, vertices, faces, textures=None, mode='rgb', texture_type='surface',
                 metallic_textures=None, roughness_textures=None):

@@ -42,11 +42,10 @@ def draw(rng):
     return kind, faces.astype(np.float32), tex, kw, flags
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=200)
-    ap.add_argument("--seed", type=int, default=0)
-    args = ap.parse_args()
+def run(cases=200, seed=0):
+    """-> number of failed cases (stops at the first); tests/test_gpu_fuzz_slice.py runs a fixed-seed slice."""
+    import types
+    args = types.SimpleNamespace(cases=cases, seed=seed)
     o = N3mrOracle("port")        # the C restatement (bit-identical to the reference build, any image size)
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
@@ -82,8 +81,17 @@ def main():
             print("FAIL case %d (%s NF=%d B=%d ts=%d flags=%r %r): %s" % (i, kind, faces.shape[1], faces.shape[0], tex.shape[2], (rrgb, ra, rd), kw, ex), flush=True)
             os.makedirs("gpurun_out", exist_ok=True)
             np.savez("gpurun_out/fuzz_n3mr_fail_%d_%d.npz" % (args.seed, i), faces=faces, tex=tex, kw=repr(kw), flags=repr((rrgb, ra, rd)))
-            raise SystemExit(1)
+            return 1
     print("fuzz_n3mr: %d cases passed, seed %d, %.1f s" % (args.cases, args.seed, time.time() - t0))
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    raise SystemExit(run(args.cases, args.seed))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,53 @@
+"""A bounded, fixed-seed slice of the randomised sweeps (tests/fuzz_parity.py, tests/fuzz_n3mr.py) as pytest
+cases, so that the driver's `-m gpu` run exercises them; the full sweeps are run by hand on the GPU box and
+their logs committed under profiles/ (profiles/r02_fuzz_*.log).
+
+Bars are the sweep's own: faces_info and the face-index buffer bit-exact, RGBA / aggrs_info 1e-4, gradients
+1e-4 of the largest component.  Two classes of cases are exempt from the gradient bar, each by an explicit
+predicate evaluated on the REFERENCE's output (not on ours):
+  * `overflow`  — the reference's own gradient is non-finite or beyond 1e30 (back faces enter the backward's
+                  softmax, SRK:1308): the non-finite pattern must agree, the finite rest is held to 1e-2;
+  * `illcond`   — gradient error in (1e-4, 1e-2]: only tolerated when the operator divides the alpha gradient by
+                  NF (aggr_func_alpha='sum'), which leaves the forward's last-bit colour noise (k - o) / D of
+                  single-face pixels as the largest term.  With the fixed seeds below NO such case occurs, and
+                  the test asserts that (any new one must be looked at)."""
+import numpy as np
+import pytest
+
+from oracle import Oracle
+from jrender_amd import _ffi
+from jrender_amd.renderer.dr.softras import SoftRasterizeFunction
+from tests import fuzz_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed,cases", [(101, 110), (102, 110), (103, 110)])
+def test_softras_fuzz_slice(seed, cases):
+    rng = np.random.default_rng(seed)
+    ctx = _ffi.Context.default()
+    port = Oracle("port", nthreads=0)
+    counts = {"ok": 0, "overflow": 0, "illcond": 0, "skipped": 0}
+    for i in range(cases):
+        kind, fv, tex, kw = fuzz_parity.draw_case(rng)
+        ref = port.forward(fv, tex, **kw)
+        if port.ub_events():
+            counts["skipped"] += 1                   # the reference's undefined-behaviour corner (SRK:107-121)
+            continue
+        fn = SoftRasterizeFunction(ctx=ctx, **kw)
+        fn(fv, tex)
+        g = rng.uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
+        try:
+            st = fuzz_parity.check_against(ref, fn, g, port.backward(ref, g))
+        except AssertionError as e:
+            raise AssertionError("seed %d case %d (%s, NF=%d, %r): %s" % (seed, i, kind, fv.shape[1], kw, e))
+        if st == "illcond":
+            assert kw["aggr_func_alpha"] == "sum", "ill-conditioned gradient outside the exempt class: case %d %r" % (i, kw)
+        counts[st] += 1
+    assert counts["illcond"] == 0, counts
+    assert counts["ok"] >= cases // 2, counts
+
+
+def test_n3mr_fuzz_slice():
+    import tests.fuzz_n3mr as fz
+    assert fz.run(cases=120, seed=201) == 0

@@ -96,7 +96,7 @@ def test_n3mr_silhouette_only_and_renderer_api():
                    dr_type='n3mr')
     r = jr.Renderer(image_size=32, dr_type='n3mr', anti_aliasing=True)
     rgb = r.render_mesh(mesh, mode='rgb')
-    assert rgb.shape == (1, 3, 32, 32) and rgb.max() <= 1.0 + 1e-6
+    assert rgb.shape == (1, 3, 32, 32) and rgb.numpy().max() <= 1.0 + 1e-6
     mesh.reset_()
     sil = r.render_mesh(mesh, mode='silhouettes')
     assert sil.shape == (1, 1, 32, 32) or sil.shape == (1, 32, 32)
@@ -144,3 +144,88 @@ def test_n3mr_degenerate_and_nan_faces():
         assert bits_equal(alpha.numpy(), ref["alpha_map"])
         w, wr = wm.numpy(), ref["weight_map"]
         assert np.array_equal(np.isnan(w), np.isnan(wr)) and bits_equal(np.nan_to_num(w), np.nan_to_num(wr))
+
+
+def test_n3mr_functional_api_on_device_and_its_backward():
+    """N3F:240-256 (permute, vertical flip, 2x2 mean pool) as HIP kernels: values against NumPy on the raw maps,
+    the backward of the whole call against the oracle's gradients pushed through the same transform."""
+    from oracle import N3mrOracle
+    from jrender_amd.renderer.dr.n3mr import RasterizeRGBAD
+    from jrender_amd import _ffi
+    o = N3mrOracle()
+    faces, tex = _scene(280, 2, 2, 7)
+    rng = np.random.default_rng(8)
+    for aa in (False, True):
+        IS = 32
+        S = IS * (2 if aa else 1)
+        op = RasterizeRGBAD(IS, aa, 0.1, 100, 1e-3, (0.2, 0.3, 0.4), True, True, True)
+        out = op(faces, tex)
+        assert all(isinstance(out[k], _ffi.DeviceArray) for k in ("rgb", "alpha", "depth"))
+        raw_rgb, raw_a, raw_d = op.fn.save_vars[5].numpy(), op.fn.save_vars[6].numpy(), op.fn.save_vars[4].numpy()
+
+        def tr(x):                                        # [B,S,S,C] bottom-up -> [B,C,IS,IS]
+            x = x.transpose(0, 3, 1, 2)[:, :, ::-1, :]
+            return x.reshape(x.shape[0], x.shape[1], IS, S // IS, IS, S // IS).mean((3, 5)) if aa else x
+        assert np.allclose(out["rgb"].numpy(), tr(raw_rgb), atol=1e-6) and out["rgb"].shape == (2, 3, IS, IS)
+        a = out["alpha"].numpy()
+        assert a.shape == ((2, 1, IS, IS) if aa else (2, IS, IS))
+        assert np.allclose(a.reshape(2, 1, IS, IS), tr(raw_a[..., None]), atol=1e-6)
+        assert np.allclose(out["depth"].numpy().reshape(2, 1, IS, IS), tr(raw_d[..., None]), atol=1e-5)
+        g_rgb = rng.uniform(-1, 1, (2, 3, IS, IS)).astype(np.float32)
+        g_a = rng.uniform(-1, 1, a.shape).astype(np.float32)
+        g_d = rng.uniform(-1, 1, a.shape).astype(np.float32)
+        gf, gt = op.backward(g_rgb, g_a, g_d)
+
+        def trb(g):                                       # adjoint of tr: [B,C,IS,IS] -> [B,S,S,C] bottom-up
+            g = g.reshape(2, -1, IS, IS)
+            if aa:
+                g = np.repeat(np.repeat(g, 2, axis=2), 2, axis=3) / 4
+            return np.ascontiguousarray(g[:, :, ::-1, :].transpose(0, 2, 3, 1))
+        ref = o.forward(faces, tex, image_size=S, background_color=(0.2, 0.3, 0.4))
+        rgf, rgt = o.backward(ref, trb(g_rgb), trb(g_a)[..., 0], trb(g_d)[..., 0])
+        assert grad_err(gf.numpy().reshape(rgf.shape), rgf) <= 1e-4 and grad_err(gt.numpy(), rgt) <= 1e-4
+
+
+def test_n3mr_renderer_gradients_textures_and_vertices():
+    """Renderer(dr_type='n3mr') end to end on the device with gradients (demo4-optim_textures' chain):
+    d/d textures is exact (the image is linear in the texels) -> finite differences; d/d vertices is NMR's
+    approximate gradient -> the oracle's gradients pushed through the same host chain."""
+    from oracle import N3mrOracle
+    from jrender_amd.structures.mesh import face_vertices_backward
+    v, f = jr.synthetic.sphere_mesh(280)
+    v = (v * 0.6).astype(np.float32)
+    rng = np.random.default_rng(3)
+    tex = rng.uniform(0.2, 0.8, (1, f.shape[0], 2, 2, 2, 3)).astype(np.float32)
+    r = jr.Renderer(image_size=24, camera_mode='look_at', light_intensity_directionals=0.3, light_intensity_ambient=0.6,
+                    dr_type='n3mr', anti_aliasing=True)
+    r.transform.set_eyes_from_angles(2.732, 20.0, 40.0)
+
+    def render(t):
+        return r.render_mesh(jr.Mesh(v, f, textures=t.copy(), dr_type='n3mr'), mode='rgb')
+    img = render(tex)
+    assert img.shape == (1, 3, 24, 24)
+    G = rng.uniform(-1, 1, img.shape).astype(np.float32)
+    gt = r.grad_textures(G)
+    assert gt.shape == tex.shape
+    base = float((img.numpy().astype(np.float64) * G).sum())
+    big = np.argsort(-np.abs(gt).reshape(-1))[:4]
+    for i in big:
+        t2 = tex.copy().reshape(-1)
+        t2[i] += 0.05
+        fd = (float((render(t2.reshape(tex.shape)).numpy().astype(np.float64) * G).sum()) - base) / 0.05
+        assert np.isclose(gt.reshape(-1)[i], fd, rtol=2e-3, atol=1e-5), (i, gt.reshape(-1)[i], fd)
+    # vertices: same forward, then the oracle's backward on the rasteriser's own inputs
+    render(tex)
+    gv = r.grad_vertices(grad_rgb=G)
+    op = r.rasterizer._op
+    fv_in, tex_in = op.fn.save_vars[0].numpy(), op.fn.save_vars[1].numpy()
+    o = N3mrOracle()
+    S = 48
+    ref = o.forward(fv_in, tex_in, image_size=S, near=r.rasterizer.near, far=r.rasterizer.far, eps=r.rasterizer.rasterizer_eps,
+                    background_color=r.rasterizer.background_color, return_rgb=True, return_alpha=False, return_depth=False)
+    g = np.repeat(np.repeat(G, 2, axis=2), 2, axis=3) / 4
+    rgf, _ = o.backward(ref, np.ascontiguousarray(g[:, :, ::-1, :].transpose(0, 2, 3, 1)), None, None)
+    nf = f.shape[0]
+    rgf = rgf[:, :nf] + rgf[:, nf:, ::-1]
+    want = r.transform.transformer.backward(face_vertices_backward(rgf, f[None], v.shape[0]), v[None])
+    assert grad_err(gv, want) <= 1e-4
