@@ -216,6 +216,9 @@ int jr_selftest_reciprocal(jr_ctx* ctx, uint64_t* mismatches);
 /* statistics of the last forward on this context: [0]=bin-face pairs, [1]=non-empty 32x32 bins,
  * [2]=max faces in a bin, [3]=bins per image */
 int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]);
+/* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
+ * previous call, [0..7] forward raster, [8..15] backward raster; all zero in the product build */
+int jr_debug_section_clocks(jr_ctx* ctx, uint64_t clocks[20]);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "jr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "jr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "jr_softras_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "jr_debug_section_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "jr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "jr_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "jr_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -281,6 +282,12 @@ class Context:
         bad = C.c_uint64(0)
         _check(load().jr_selftest_reciprocal(self.handle, C.byref(bad)))
         return bad.value
+
+    def section_clocks(self):
+        """Instrumented builds only: shader-clock totals per kernel section since the previous call."""
+        a = (C.c_uint64 * 20)()
+        _check(load().jr_debug_section_clocks(self.handle, a))
+        return list(a)
 
     def last_stats(self):
         s = (C.c_int64 * 4)()

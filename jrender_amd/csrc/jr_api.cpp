@@ -247,7 +247,8 @@ int jr_ctx_create(int device, jr_ctx** out) {
     c->device = device;
     JR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     JR_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * 4, hipHostMallocDefault));
-    JR_HIP(hipMalloc((void**)&c->ws.counters, sizeof(unsigned long long) * 4));
+    JR_HIP(hipMalloc((void**)&c->ws.counters, sizeof(unsigned long long) * 24));   // [0..3] bin totals, [4..23] section clocks (instrumented builds)
+    JR_HIP(hipMemset(c->ws.counters, 0, sizeof(unsigned long long) * 24));
     JR_HIP(hipEventCreateWithFlags(&c->ev_counters, hipEventDisableTiming));
     *out = c;
     return 0;
@@ -606,6 +607,15 @@ int jr_profile_collect(jr_ctx* ctx, double ms[JR_NUM_PHASES], int64_t launches[J
     }
     ctx->prof_phase.clear();
     ctx->prof_used = 0;
+    return 0;
+}
+
+int jr_debug_section_clocks(jr_ctx* ctx, uint64_t clocks[20]) {
+    if (!ctx || !clocks) return fail("NULL argument");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    JR_HIP(hipMemcpy(clocks, ctx->ws.counters + 4, sizeof(uint64_t) * 20, hipMemcpyDeviceToHost));
+    JR_HIP(hipMemset(ctx->ws.counters + 4, 0, sizeof(uint64_t) * 20));
     return 0;
 }
 

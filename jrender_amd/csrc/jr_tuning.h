@@ -20,7 +20,7 @@
 #define JR_TUNE_FWD_IDS_LDS_BIGK 1
 #endif
 #ifndef JR_TUNE_FWD_INSIDE_RCP   // forward: 2nd / 3rd edge projection of INSIDE pixels (colour path only) by reciprocal multiply
-#define JR_TUNE_FWD_INSIDE_RCP 0
+#define JR_TUNE_FWD_INSIDE_RCP 1
 #endif
 #ifndef JR_TUNE_FWD_OCC4         // forward: ask the register allocator for 4 wavefronts per SIMD at K <= 16 (128 VGPRs)
 #define JR_TUNE_FWD_OCC4 1
@@ -29,8 +29,18 @@
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
 
+#ifndef JR_TUNE_BWD_HOLDER_LISTS  // backward: per-face holder lists in LDS instead of the n-th-set-bit search
+#define JR_TUNE_BWD_HOLDER_LISTS 0
+#endif
+
+#ifndef JR_TUNE_PROFILE_SECTIONS  // instrumented build: per-section shader-clock totals of the raster kernels (tools/ablate)
+#define JR_TUNE_PROFILE_SECTIONS 0
+#endif
+
 namespace jr {
 namespace tune {
+constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
+constexpr bool bwd_holder_lists = JR_TUNE_BWD_HOLDER_LISTS != 0;
 constexpr bool tv_divknown = JR_TUNE_TV_DIVKNOWN != 0;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;

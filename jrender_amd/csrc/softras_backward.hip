@@ -228,12 +228,18 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
     const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
-    float* __restrict__ grad_faces, float* __restrict__ grad_textures) {
+    float* __restrict__ grad_faces, float* __restrict__ grad_textures, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 s_dyn[];
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
     float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
-    __shared__ unsigned long long s_has[CHUNK];      // slot -> pixels (lanes) that hold the face
+    __shared__ unsigned long long s_has[tune::bwd_holder_lists ? 1 : CHUNK];   // slot -> pixels (lanes) that hold the face
     __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
+    // tune::bwd_holder_lists: the holders of every face of the batch as a LIST of lane numbers (bytes), written
+    // by the holders themselves while the batch is extracted (rank = mbcnt of the holder ballot): a work lane
+    // reads "its" pixel with one ds_read_u8 instead of a 50-instruction n-th-set-bit search.  A lane holds at
+    // most KCAP faces, so a batch has at most 64 * KCAP entries.
+    __shared__ unsigned char s_list[tune::bwd_holder_lists ? CHUNK * KCAP : 1];
+    __shared__ int s_meta[tune::bwd_holder_lists ? CHUNK : 1];      // slot -> first entry | holders << 16
 
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
     const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
@@ -256,6 +262,8 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     const float xp = pixel_centre(col, p.IS);
     const float yp = pixel_centre(p.IS - 1 - row, p.IS);                      // SRK:1218-1221
 
+    SectionClock clk;            // instrumented builds only: 0 tile state, 1 extraction, 2 staging + items, 3 gather, 4 pair, 5 reduce + atomics
+    clk.start();
     // this pixel's buffered face ids; the reference stops at the first -1 (SRK:1236-1238)
     constexpr int BIG = 0x7fffffff;
     int mine[KCAP];
@@ -304,8 +312,9 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     // face's holder mask, and those lanes advance.  Up to 64 distinct faces form a batch (a tile of the
     // headline workload needs ~40): slot = extraction order = ascending id, lane j keeps slot j's id and
     // holder mask.  No list walk, no binary search, no bit-matrix transpose.
+    clk.lap(0);
     for (;;) {
-        int fill = 0, myid = 0;
+        int fill = 0, myid = 0, off = 0, mymeta = 0;
         unsigned long long has = 0ull;
         while (fill < CHUNK) {
             const int m = wave_min(cur);
@@ -313,6 +322,12 @@ __global__ __launch_bounds__(64) void k_softras_backward(
             const bool hit = cur == m;
             const unsigned long long h = ballot(hit);
             if (lane == fill) { myid = m; has = h; }
+            if (tune::bwd_holder_lists) {
+                const int nh = __builtin_popcountll(h);
+                if (hit) s_list[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(h >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)h, 0u))] = (unsigned char)lane;
+                if (lane == fill) mymeta = off | (nh << 16);
+                off += nh;
+            }
             if (hit) {
 #pragma unroll
                 for (int k = 0; k + 1 < KCAP; k++) mine[k] = mine[k + 1];
@@ -322,6 +337,7 @@ __global__ __launch_bounds__(64) void k_softras_backward(
             fill++;
         }
         if (fill == 0) break;
+        clk.lap(1);
 
         // ---- stage the batch's records (lane = slot) ----
         if (lane < fill) {
@@ -345,7 +361,8 @@ __global__ __launch_bounds__(64) void k_softras_backward(
             if (lane >= d) incl += o;
         }
         const int nitems = __builtin_amdgcn_readlane(incl, 63);
-        s_has[lane] = has;
+        if (tune::bwd_holder_lists) s_meta[lane] = mymeta;
+        else s_has[lane] = has;
         s_ioff[lane] = incl - items;
         if (lane == 0) s_ioff[64] = nitems;
         __syncthreads();
@@ -353,20 +370,30 @@ __global__ __launch_bounds__(64) void k_softras_backward(
         // ---- each 16-lane DPP row takes one item per trip (four faces in flight per wavefront): gather
         //      the pixels' state, pair arithmetic, row-local transpose-reduction -> lane k of the row
         //      holds component k -> ONE atomic instruction per row and item ----
+        clk.lap(2);
         int j = 0;
         for (int i0 = 0; i0 < nitems; i0 += 4) {
             const int item = i0 + blk;
             const bool ract = item < nitems;                     // uniform within a row
             if (ract) while (s_ioff[j + 1] <= item) j++;
-            const unsigned long long hs = ract ? s_has[j] : 0ull;
             const int nth = ract ? (item - s_ioff[j]) * 16 + li : 64;
-            const bool act = nth < __builtin_popcountll(hs);
-            const int src = act ? select_bit(hs, nth) : lane;    // the pixel (lane) this pair belongs to
+            bool act;
+            int src;                                             // the pixel (lane) this pair belongs to
+            if (tune::bwd_holder_lists) {
+                const int meta = ract ? s_meta[j] : 0;
+                act = nth < (meta >> 16);
+                src = act ? (int)s_list[(meta & 0xffff) + nth] : lane;
+            } else {
+                const unsigned long long hs = ract ? s_has[j] : 0ull;
+                act = nth < __builtin_popcountll(hs);
+                src = act ? select_bit(hs, nth) : lane;
+            }
             PixelGrad q;
             q.g0 = gather(px.g0, src); q.g1 = gather(px.g1, src); q.g2 = gather(px.g2, src); q.g3 = gather(px.g3, src);
             q.o0 = gather(px.o0, src); q.o1 = gather(px.o1, src); q.o2 = gather(px.o2, src); q.o3 = gather(px.o3, src);
             q.ssum = gather(px.ssum, src); q.smax = gather(px.smax, src); q.r_ssum = gather(px.r_ssum, src);
             const float qx = gather(xp, src), qy = gather(yp, src);
+            if (tune::profile_sections) { __builtin_amdgcn_s_waitcnt(0); clk.lap(3); }
             const FaceRec& fr = s_rec[j];
             float v[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float gt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -405,6 +432,7 @@ __global__ __launch_bounds__(64) void k_softras_backward(
                 for (int k = 0; k < 9; k++) v[k] = gv[k];
                 if (ntex == 3) { v[9] = gt[0]; v[10] = gt[1]; v[11] = gt[2]; }
             }
+            clk.lap(4);
             const int fn = fr.id;
             const float s = row_transpose_reduce(v, li);         // lane li: component li summed over the row
             if (ract && s != 0.f) {                              // SRK:1349-1358 does one atomic per pixel
@@ -418,9 +446,12 @@ __global__ __launch_bounds__(64) void k_softras_backward(
                 const float st = row_transpose_reduce(u, li);
                 if (ract && li < 9 && st != 0.f) atomicAdd(gtbase + (size_t)fn * p.T * 3 + li, st);
             }
+            clk.lap(5);
         }
         __syncthreads();                        // the batch's records and tables are free again
     }
+    clk.lap(1);
+    clk.flush(counters, 12);
 }
 
 template <int DIST, int RGB>
@@ -432,15 +463,15 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
     if (p.K <= 16)
         k_softras_backward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
-            grad_faces, grad_textures);
+            grad_faces, grad_textures, ws.counters);
     else if (p.K <= 32)
         k_softras_backward<DIST, RGB, 32><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
-            grad_faces, grad_textures);
+            grad_faces, grad_textures, ws.counters);
     else
         k_softras_backward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
-            grad_faces, grad_textures);
+            grad_faces, grad_textures, ws.counters);
 }
 
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,

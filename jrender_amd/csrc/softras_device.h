@@ -393,6 +393,33 @@ __device__ inline int surface_texel(const Bary& c, int R) {
     return (R - 1 - wy) * R + (R - 1 - wx);
 }
 
+// ---- instrumented builds only (tune::profile_sections): wall-clock (s_memtime) totals per kernel section,
+// summed over wavefronts into BinWorkspace::counters[4 + section] ---------------------------------
+struct SectionClock {
+    unsigned long long t, acc[8];
+    __device__ inline void start() {
+        if (tune::profile_sections) {
+            t = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[i] = 0;
+        }
+    }
+    __device__ inline void lap(int section) {
+        if (tune::profile_sections) {
+            const unsigned long long n = __builtin_amdgcn_s_memtime();
+            acc[section] += n - t;
+            t = n;
+        }
+    }
+    __device__ inline void flush(unsigned long long* out, int base) {
+        if (tune::profile_sections && threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (acc[i]) atomicAdd(out + base + i, acc[i]);
+        }
+    }
+};
+
 // ---- wavefront helpers (64 lanes) ----------------------------------------------------------
 __device__ inline unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
-    const unsigned long long* __restrict__ counters, unsigned long long pool_cap,
+    unsigned long long* __restrict__ counters, unsigned long long pool_cap,
     float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     extern __shared__ float4 s_dyn[];
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
@@ -233,6 +233,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     auto xc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xp), c)); };
     auto yc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yp), 8 * c)); };
 
+    SectionClock clk;            // instrumented builds only: 0 set-up, 1 cull + stage, 2 ballots + pre-cull, 3 raster loop, 4 stores
+    clk.start();
     PixelState<KCAP> s;
     s.c0 = 1.f; s.c1 = 1.f; s.c2 = 1.f;
     s.alpha = p.alpha == 2 ? 1.f : 0.f;
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     // raster loop only runs on a full batch: its trip count is the MAXIMUM number of faces any pixel
     // needs, and max/mean over 64 lanes shrinks with the batch (measured: 17 survivors per list chunk
     // -> 64 per batch), and the per-batch ballots are paid 4x less often.
+    clk.lap(0);
     int s0 = 0, fill = 0, cnt = 0;
     bool pending = false, keep = false;
     const FaceGeo* gp = gbase;
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         }
         if (fill == 0) break;
         __syncthreads();
+        clk.lap(1);
 
         // ---- raster: lane = slot for the ballots, then lane = pixel ----
         {
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             } else {
                 M = valid ? (select8(cx, lx) & select8(ry, ly)) : 0ull;
             }
+            clk.lap(2);
             while (M) {
                 const int j = __builtin_ctzll(M);
                 M &= M - 1;
@@ -396,8 +401,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         }
         fill = 0;
         __syncthreads();                        // readers are done with s_rec before it is refilled
+        clk.lap(3);
     }
+    clk.lap(1);
 
+    if (tune::profile_sections && !valid) clk.flush(counters, 4);
     if (!valid) return;
     // ---- finalise (SRK:426-455) ----
     const size_t pp = (size_t)p.IS * p.IS;
@@ -422,6 +430,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
 #pragma unroll
     for (int k = 0; k < KCAP; k++)
         if (k < p.K) io[(size_t)k * pp] = s.q.id_of(k);
+    clk.lap(4);
+    clk.flush(counters, 4);
 }
 
 template <int DIST, int RGB>

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""GPU box: where do the raster kernels spend their (wall-clock, per-wavefront) time?  Needs the instrumented
+build (python tools/ablate/build.py sections): s_memtime laps per section, summed over wavefronts.  The laps
+perturb the kernels (each is an s_memtime + s_waitcnt): read the SHARES, not the totals."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("JRENDER_LIB", os.path.join(ROOT, "jrender_amd", "csrc", "libjrender_hip_sections.so"))
+sys.path.insert(0, ROOT)
+from jrender_amd import _ffi, synthetic as syn                                     # noqa: E402
+from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction   # noqa: E402
+
+ctx = _ffi.Context(0)
+fv, tex = syn.sphere_views(39000, 8)
+fv, tex = ctx.array(fv), ctx.array(tex)
+g = ctx.array(np.random.default_rng(7).uniform(-1, 1, (8, 4, 1024, 1024)).astype(np.float32))
+fn = SoftRasterizeFunction(image_size=1024, ctx=ctx)
+for _ in range(2):
+    fn.execute(fv, tex); fn.grad(g)
+ctx.section_clocks()
+for _ in range(5):
+    fn.execute(fv, tex); fn.grad(g)
+c = np.asarray(ctx.section_clocks(), np.float64)
+for name, lo, labels in (("forward", 0, ["set-up", "cull + stage", "ballots + pre-cull", "raster loop", "stores"]),
+                         ("backward", 8, ["tile state + sort", "extraction", "staging + items", "gather", "pair arithmetic", "reduce + atomics"])):
+    tot = c[lo:lo + 8].sum()
+    print(name, "total clocks %.3g" % tot)
+    for i, lab in enumerate(labels):
+        print("   %-20s %5.1f %%" % (lab, 100 * c[lo + i] / max(tot, 1)))

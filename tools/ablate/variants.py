@@ -2,7 +2,7 @@
 `python tools/ablate/build.py [names...]` builds them next to the product library (CPU box, hipcc);
 `python tools/ablate/run.py [names...]` (GPU box) checks parity and times each one in ONE process
 sequence on ONE box (boxes differ by a few per cent: only numbers from one call are comparable)."""
-OFF = ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_IDS_LDS_BIGK=0"]
+OFF = ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_IDS_LDS_BIGK=0", "JR_TUNE_FWD_INSIDE_RCP=0"]
 VARIANTS = {
     "product": [],                                           # the defaults of jr_tuning.h
     "r1": OFF,                                               # every switch off = round-1 kernels
@@ -13,5 +13,7 @@ VARIANTS = {
     "ids_lds": ["JR_TUNE_FWD_IDS_LDS=1"],                    # dead at K <= 16: K-buffer ids in LDS
     "bigk_regs": ["JR_TUNE_FWD_IDS_LDS_BIGK=0"],             # K > 16 with ids in registers (round 1)
     "bwd_rcp": ["JR_TUNE_BWD_TV_RCP=1"],                     # dead: breaks the 1e-4 gradient bar
-    "inside_rcp": ["JR_TUNE_FWD_INSIDE_RCP=1"],
+    "no_inside_rcp": ["JR_TUNE_FWD_INSIDE_RCP=0"],
+    "holders": ["JR_TUNE_BWD_HOLDER_LISTS=1"],
+    "sections": ["JR_TUNE_PROFILE_SECTIONS=1"],              # instrumented: tools/ablate/sections.py
 }
