@@ -20,16 +20,18 @@
 //                  not fit the bitmap and take k_bin_sort: LDS bitonic, rank sort when a bin is huge.)
 // Neighbouring faces of a mesh fall into the same few bins, so the per-bin counters are bumped once
 // per (wavefront, bin) with a ballot-matched group instead of once per (face, bin).
-// The rectangle is only a conservative superset: the exact per-pixel border test of the
-// reference is re-applied in the raster kernels, so results never depend on the binning.
+// The rectangle is the exact set of pixel columns / rows whose centres pass the border test of the face (per
+// axis); the per-pixel test is re-applied in the raster kernels anyway, so results never depend on the binning.
 #include "jr_kernels.h"
 
 namespace jr {
 
-// Conservative pixel range [lo, hi] of centres c(i) = (2i+1-IS)/IS that can satisfy vlo <= c(i) <= vhi.
-// One pixel of slack on both sides covers every rounding in this estimate and in the reference's
-// float compare.  NaN bounds -> full range (the reference's compares are all false for NaN, i.e.
-// the face is NOT culled).
+// EXACT pixel range [lo, hi] of the centres c(i) = pixel_centre(i) that pass the reference's border test on one
+// axis, !(c(i) < vlo) && !(c(i) > vhi) (SRK:28-34): a real-valued estimate with one pixel of slack on both
+// sides, then walked inwards with the kernel's own float compare (pixel_centre is monotone in i).  The
+// raster kernels re-apply the per-pixel test, so a superset would be harmless; exactness is what lets the
+// forward skip its own box test per (tile, face) and keeps faces that touch no pixel centre out of the lists.
+// NaN bounds -> full range (the reference's compares are all false for NaN, i.e. the face is NOT culled).
 __device__ inline void pixel_range(float vlo, float vhi, int is, int& lo, int& hi) {
     const double a = ((double)vlo * is + is - 1.0) * 0.5;
     const double b = ((double)vhi * is + is - 1.0) * 0.5;
@@ -41,6 +43,8 @@ __device__ inline void pixel_range(float vlo, float vhi, int is, int& lo, int& h
     if (!(flo <= fhi)) { lo = 1; hi = 0; return; }
     lo = (int)flo;
     hi = (int)fhi;
+    for (int it = 0; it < 4 && lo <= hi && pixel_centre(lo, is) < vlo; it++) lo++;
+    for (int it = 0; it < 4 && lo <= hi && pixel_centre(hi, is) > vhi; it++) hi--;
 }
 
 // Wave-aggregated counter bump: lanes that target the same bin form a group (ballot match against the

@@ -22,6 +22,12 @@
 #ifndef JR_TUNE_FWD_INSIDE_RCP   // forward: 2nd / 3rd edge projection of INSIDE pixels (colour path only) by reciprocal multiply
 #define JR_TUNE_FWD_INSIDE_RCP 1
 #endif
+#ifndef JR_TUNE_FWD_TPW          // forward: tiles of a bin rendered by one wavefront, one after the other (1, 2, 4, 8, 16)
+#define JR_TUNE_FWD_TPW 1
+#endif
+#ifndef JR_TUNE_FWD_TILE_BOXTEST // forward: load every listed face's box and test it against the tile before staging (round 1)
+#define JR_TUNE_FWD_TILE_BOXTEST 0
+#endif
 #ifndef JR_TUNE_FWD_OCC4         // forward: ask the register allocator for 4 wavefronts per SIMD at K <= 16 (128 VGPRs)
 #define JR_TUNE_FWD_OCC4 1
 #endif
@@ -47,6 +53,8 @@ constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
 constexpr bool fwd_ids_lds = JR_TUNE_FWD_IDS_LDS != 0;
 constexpr bool fwd_ids_lds_bigk = JR_TUNE_FWD_IDS_LDS_BIGK != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
+constexpr int fwd_tiles_per_wave = JR_TUNE_FWD_TPW;
+constexpr bool fwd_tile_boxtest = JR_TUNE_FWD_TILE_BOXTEST != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 }  // namespace tune
 }  // namespace jr

@@ -211,19 +211,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
 
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
     // bin (same list, same records) go to ONE XCD so that they share its L2.
+    // A wavefront renders TPW tiles of its bin one after the other (a run of horizontally adjacent tiles):
+    // the store tail of one tile overlaps with the list walk of the next, and the bin look-ups are paid once.
+    constexpr int TPW = tune::fwd_tiles_per_wave, WPB = 16 / TPW;      // tiles per wavefront, wavefronts per bin
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
-    const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
+    const int brank = (k / WPB) * 8 + (blockIdx.x & 7);  // bins are dealt round-robin to the XCDs ...
     if (brank * 16 >= ntiles_total) return;
-    const int bin = bin_order[brank], sub = k & 15;      // ... heaviest first (k_bin_schedule)
+    const int bin = bin_order[brank];                    // ... heaviest first (k_bin_schedule)
     const int bins_per_img = p.bins_x * p.bins_y;
     const int b = bin / bins_per_img;
     const int bb = bin - b * bins_per_img;
     const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
-    const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
-    if (col0 >= p.IS || row0 >= p.IS) return;            // tile lies outside the image
     const int n = bin_count[bin];
-
     const int lane = threadIdx.x, lx = lane & 7, ly = lane >> 3;
+    SectionClock clk;            // instrumented builds only: 0 set-up, 1 cull + stage, 2 ballots + pre-cull, 3 raster loop, 4 stores
+    clk.start();
+#pragma nounroll
+    for (int tw = 0; tw < TPW; tw++) {
+    const int sub = (k % WPB) * TPW + tw;
+    const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
+    if (col0 >= p.IS || row0 >= p.IS) continue;          // tile lies outside the image
     const int col = col0 + lx, row = row0 + ly;
     const bool valid = col < p.IS && row < p.IS;
     const float xp = pixel_centre(col, p.IS);
@@ -233,8 +240,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     auto xc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xp), c)); };
     auto yc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yp), 8 * c)); };
 
-    SectionClock clk;            // instrumented builds only: 0 set-up, 1 cull + stage, 2 ballots + pre-cull, 3 raster loop, 4 stores
-    clk.start();
     PixelState<KCAP> s;
     s.c0 = 1.f; s.c1 = 1.f; s.c2 = 1.f;
     s.alpha = p.alpha == 2 ? 1.f : 0.f;
@@ -259,21 +264,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     bool pending = false, keep = false;
     const FaceGeo* gp = gbase;
     int rank = 0;                                   // of this lane's entry among the chunk's survivors
+    // the list is read one chunk AHEAD of its use (the entry load is the head of a chain of dependent loads)
+    unsigned long long e_next = lane < n ? seg[lane] : 0ull;
     for (;;) {
         // ---- cull + stage: lane = list entry ----
         while (pending || s0 < n) {
             if (!pending) {
-                const int idx = s0 + lane;
+                const unsigned long long e = e_next;
                 s0 += CHUNK;
-                const unsigned long long e = idx < n ? seg[idx] : 0ull;
-                const bool need = (e >> sub) & 1ull;
-                if (!ballot(need)) continue;        // no face of this chunk touches this tile
+                e_next = s0 + lane < n ? seg[s0 + lane] : 0ull;
+                // The entry's tile mask is exact per axis (binning.hip: pixel_range), i.e. the face's border box
+                // reaches a pixel column AND a pixel row of this tile: no box load, no second test here.
+                keep = (e >> sub) & 1ull;
+                if (!ballot(keep)) continue;        // no face of this chunk touches this tile
                 gp = gbase + (int)(e >> 32);
-                float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (need) box = *reinterpret_cast<const float4*>(gp);         // xlo xhi ylo yhi
-                // conservative tile test with check_border's own compare form (SRK:28-34: NaN passes);
-                // column centres ascend with c, row centres descend
-                keep = need && !(xc(0) > box.y) && !(xc(7) < box.x) && !(yc(7) > box.w) && !(yc(0) < box.z);
+                if (tune::fwd_tile_boxtest) {       // round-1 form: conservative float test of the box against the tile
+                    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (keep) box = *reinterpret_cast<const float4*>(gp);         // xlo xhi ylo yhi
+                    keep = keep && !(xc(0) > box.y) && !(xc(7) < box.x) && !(yc(7) > box.w) && !(yc(0) < box.z);
+                }
                 const unsigned long long surv = ballot(keep);
                 if (!surv) continue;
                 cnt = __builtin_popcountll(surv);
@@ -405,8 +414,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     }
     clk.lap(1);
 
-    if (tune::profile_sections && !valid) clk.flush(counters, 4);
-    if (!valid) return;
+    if (!valid) continue;
     // ---- finalise (SRK:426-455) ----
     const size_t pp = (size_t)p.IS * p.IS;
     const size_t pn = (size_t)row * p.IS + col;
@@ -431,13 +439,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     for (int k = 0; k < KCAP; k++)
         if (k < p.K) io[(size_t)k * pp] = s.q.id_of(k);
     clk.lap(4);
+    }   // tiles of this wavefront
     clk.flush(counters, 4);
 }
 
 template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
-    const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
+    const int grid = ((ntiles + 127) / 128) * 128 / tune::fwd_tiles_per_wave;   // whole bins (16 tiles) per XCD slot
     const bool ids_lds = p.K <= 16 ? ids_in_lds<16>() : ids_in_lds<64>();
     const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0) +
                         (ids_lds ? sizeof(int) * 64 * (size_t)p.K : 0);

@@ -2,11 +2,11 @@
 `python tools/ablate/build.py [names...]` builds them next to the product library (CPU box, hipcc);
 `python tools/ablate/run.py [names...]` (GPU box) checks parity and times each one in ONE process
 sequence on ONE box (boxes differ by a few per cent: only numbers from one call are comparable)."""
-OFF = ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_IDS_LDS_BIGK=0", "JR_TUNE_FWD_INSIDE_RCP=0"]
+OFF = ["JR_TUNE_FWD_TILE_BOXTEST=1", "JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_IDS_LDS_BIGK=0", "JR_TUNE_FWD_INSIDE_RCP=0"]
 VARIANTS = {
     "product": [],                                           # the defaults of jr_tuning.h
     "r1": OFF,                                               # every switch off = round-1 kernels
-    "r1_occ4": OFF[:2] + OFF[3:],                            # + the 4-waves-per-SIMD request alone
+    "r1_occ4": OFF[:3] + OFF[4:],                            # + the 4-waves-per-SIMD request alone
     "no_prepass": ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_OCC4=0"],
     "no_dis": ["JR_TUNE_FWD_DIS_ONLY=0"],
     "tv": ["JR_TUNE_TV_DIVKNOWN=1"],                         # dead: exact reciprocal-refinement quotient for tv
@@ -15,5 +15,8 @@ VARIANTS = {
     "bwd_rcp": ["JR_TUNE_BWD_TV_RCP=1"],                     # dead: breaks the 1e-4 gradient bar
     "no_inside_rcp": ["JR_TUNE_FWD_INSIDE_RCP=0"],
     "holders": ["JR_TUNE_BWD_HOLDER_LISTS=1"],
+    "boxtest": ["JR_TUNE_FWD_TILE_BOXTEST=1"],
+    "tpw2": ["JR_TUNE_FWD_TPW=2"],
+    "tpw4": ["JR_TUNE_FWD_TPW=4"],
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1"],              # instrumented: tools/ablate/sections.py
 }
