@@ -28,6 +28,12 @@
 #ifndef JR_TUNE_FWD_TILE_BOXTEST // forward: load every listed face's box and test it against the tile before staging (round 1)
 #define JR_TUNE_FWD_TILE_BOXTEST 0
 #endif
+#ifndef JR_TUNE_FWD_BATCH        // forward: faces per batch (LDS record slots per wavefront), <= 64; 56 x 176 B = 9.6 KB -> 16 wavefronts per CU
+#define JR_TUNE_FWD_BATCH 56
+#endif
+#ifndef JR_TUNE_FWD_KBUF_SALU    // forward: K-buffer slot masks from 4 bit ballots + scalar logic instead of 16 v_cmp
+#define JR_TUNE_FWD_KBUF_SALU 0
+#endif
 #ifndef JR_TUNE_FWD_OCC4         // forward: ask the register allocator for 4 wavefronts per SIMD at K <= 16 (128 VGPRs)
 #define JR_TUNE_FWD_OCC4 1
 #endif
@@ -35,6 +41,12 @@
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
 
+#ifndef JR_TUNE_BWD_BATCH         // backward: faces per batch (LDS record slots per wavefront), <= 64; 52 slots + tables < 10 KB -> 16 wavefronts per CU
+#define JR_TUNE_BWD_BATCH 52
+#endif
+#ifndef JR_TUNE_BWD_WAVES         // backward: wavefronts per SIMD asked of the register allocator at K <= 16
+#define JR_TUNE_BWD_WAVES 4
+#endif
 #ifndef JR_TUNE_BWD_HOLDER_LISTS  // backward: per-face holder lists in LDS instead of the n-th-set-bit search
 #define JR_TUNE_BWD_HOLDER_LISTS 0
 #endif
@@ -47,6 +59,7 @@ namespace jr {
 namespace tune {
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
 constexpr bool bwd_holder_lists = JR_TUNE_BWD_HOLDER_LISTS != 0;
+constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr bool tv_divknown = JR_TUNE_TV_DIVKNOWN != 0;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
@@ -54,6 +67,8 @@ constexpr bool fwd_ids_lds = JR_TUNE_FWD_IDS_LDS != 0;
 constexpr bool fwd_ids_lds_bigk = JR_TUNE_FWD_IDS_LDS_BIGK != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
 constexpr int fwd_tiles_per_wave = JR_TUNE_FWD_TPW;
+constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
+constexpr bool fwd_kbuf_salu = JR_TUNE_FWD_KBUF_SALU != 0;
 constexpr bool fwd_tile_boxtest = JR_TUNE_FWD_TILE_BOXTEST != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 }  // namespace tune

@@ -223,16 +223,18 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
 }
 
 template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) void k_softras_backward(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? JR_TUNE_BWD_WAVES : 1))) void k_softras_backward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
     const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
     float* __restrict__ grad_faces, float* __restrict__ grad_textures, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 s_dyn[];
-    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
-    float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
-    __shared__ unsigned long long s_has[tune::bwd_holder_lists ? 1 : CHUNK];   // slot -> pixels (lanes) that hold the face
+    // faces per batch: a tile of the headline workload needs ~40; 64 slots of 176 B cap a CU at 13 wavefronts
+    constexpr int BATCH = tune::bwd_batch;
+    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
+    float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
+    __shared__ unsigned long long s_has[tune::bwd_holder_lists ? 1 : BATCH];   // slot -> pixels (lanes) that hold the face
     __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
     // tune::bwd_holder_lists: the holders of every face of the batch as a LIST of lane numbers (bytes), written
     // by the holders themselves while the batch is extracted (rank = mbcnt of the holder ballot): a work lane
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64) void k_softras_backward(
     for (;;) {
         int fill = 0, myid = 0, off = 0, mymeta = 0;
         unsigned long long has = 0ull;
-        while (fill < CHUNK) {
+        while (fill < BATCH) {
             const int m = wave_min(cur);
             if (m == BIG) break;
             const bool hit = cur == m;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(64) void k_softras_backward(
         }
         const int nitems = __builtin_amdgcn_readlane(incl, 63);
         if (tune::bwd_holder_lists) s_meta[lane] = mymeta;
-        else s_has[lane] = has;
+        else if (lane < BATCH) s_has[lane] = has;
         s_ioff[lane] = incl - items;
         if (lane == 0) s_ioff[64] = nitems;
         __syncthreads();
@@ -459,7 +461,7 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
                      const BinWorkspace& ws, const float* rgba, const float* aggrs, const int32_t* ids,
                      const float* grad_rgba, float* grad_faces, float* grad_textures) {
     const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
-    const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0);
+    const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0);
     if (p.K <= 16)
         k_softras_backward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,

@@ -69,11 +69,26 @@ struct KBuffer {
         if (!filling && !(zp < max_z)) return;
         const int slot = filling ? size : max_slot;
         if (IDS_LDS) lds_ids[slot * 64] = fn;
+        if (tune::fwd_kbuf_salu && KCAP == 16) {
+            // The 16 "slot == k" masks from 4 bit ballots and scalar and / andn2 (SALU, issued beside the vector
+            // pipe) instead of 16 v_cmp: v_cmp and v_cndmask are half-rate on gfx950 (tools/ubench/valu_rates2).
+            const unsigned long long b0 = ballot((slot & 1) != 0), b1 = ballot((slot & 2) != 0),
+                                     b2 = ballot((slot & 4) != 0), b3 = ballot((slot & 8) != 0);
+            const unsigned long long lo[4] = {~b0 & ~b1, b0 & ~b1, ~b0 & b1, b0 & b1};
+            const unsigned long long hi[4] = {~b2 & ~b3, b2 & ~b3, ~b2 & b3, b2 & b3};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const unsigned long long m = lo[k & 3] & hi[k >> 2];
+                if (!IDS_LDS) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(id[k]) : "v"(fn), "s"(m));
+                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(z[k]) : "v"(zp), "s"(m));
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             const bool hit = k == slot;
             if (!IDS_LDS) id[k] = hit ? fn : id[k];
             z[k] = hit ? zp : z[k];
+        }
         }
         if (filling) {
             if (zp > max_z) { max_z = zp; max_slot = size; }
@@ -197,7 +212,7 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
 }
 
 template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? (JR_TUNE_FWD_OCC4 ? 4 : 1) : (KCAP <= 32 ? 2 : 1)))) void k_softras_forward(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? (JR_TUNE_FWD_OCC4 ? (JR_TUNE_FWD_OCC4 > 1 ? JR_TUNE_FWD_OCC4 : 4) : 1) : (KCAP <= 32 ? 2 : 1)))) void k_softras_forward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
@@ -205,9 +220,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     extern __shared__ float4 s_dyn[];
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
-    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [CHUNK]
-    float* s_vcol = reinterpret_cast<float*>(s_rec + CHUNK);                   // [CHUNK*9] iff vertex colours
-    int* s_ids = reinterpret_cast<int*>(s_vcol + (p.tex == 1 ? 9 * CHUNK : 0)); // [K][64] iff ids_in_lds<KCAP>()
+    constexpr int BATCH = tune::fwd_batch;       // record slots per wavefront (64 x 176 B cap a CU at 14 wavefronts)
+    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
+    float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
+    int* s_ids = reinterpret_cast<int*>(s_vcol + (p.tex == 1 ? 9 * BATCH : 0)); // [K][64] iff ids_in_lds<KCAP>()
 
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
     // bin (same list, same records) go to ONE XCD so that they share its L2.
@@ -289,9 +305,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(surv >> 32),
                                                       __builtin_amdgcn_mbcnt_lo((unsigned)surv, 0u));
             }
-            if (fill + cnt > CHUNK) { pending = true; break; }
-            pending = false;
-            if (keep) {
+            // take as many of the chunk's survivors as the batch still has room for (ascending order kept);
+            // the rest stays pending for the next batch
+            const int take = min(cnt, BATCH - fill);
+            if (keep && rank < take) {
                 const int slot = fill + rank;
                 const float4* src = reinterpret_cast<const float4*>(gp);
                 float4* dst = reinterpret_cast<float4*>(&s_rec[slot]);
@@ -303,7 +320,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                     for (int k = 0; k < 9; k++) s_vcol[slot * 9 + k] = tx_[k];
                 }
             }
-            fill += cnt;
+            fill += take;
+            pending = take < cnt;
+            if (pending) {
+                keep = keep && rank >= take;
+                rank -= take;
+                cnt -= take;
+                break;
+            }
         }
         if (fill == 0) break;
         __syncthreads();
@@ -448,7 +472,7 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
     const int grid = ((ntiles + 127) / 128) * 128 / tune::fwd_tiles_per_wave;   // whole bins (16 tiles) per XCD slot
     const bool ids_lds = p.K <= 16 ? ids_in_lds<16>() : ids_in_lds<64>();
-    const size_t smem = sizeof(FaceRec) * CHUNK + (p.tex == 1 ? sizeof(float) * 9 * CHUNK : 0) +
+    const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0) +
                         (ids_lds ? sizeof(int) * 64 * (size_t)p.K : 0);
     // K-buffer capacity: 16 (the default K), 32 (K = 17..32: 2 wavefronts per SIMD), 64 (1 wavefront per SIMD)
     if (p.K <= 16)

@@ -2,11 +2,11 @@
 `python tools/ablate/build.py [names...]` builds them next to the product library (CPU box, hipcc);
 `python tools/ablate/run.py [names...]` (GPU box) checks parity and times each one in ONE process
 sequence on ONE box (boxes differ by a few per cent: only numbers from one call are comparable)."""
-OFF = ["JR_TUNE_FWD_TILE_BOXTEST=1", "JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_IDS_LDS_BIGK=0", "JR_TUNE_FWD_INSIDE_RCP=0"]
+OFF = ["JR_TUNE_FWD_BATCH=64", "JR_TUNE_BWD_BATCH=64", "JR_TUNE_FWD_TILE_BOXTEST=1", "JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_IDS_LDS_BIGK=0", "JR_TUNE_FWD_INSIDE_RCP=0"]
 VARIANTS = {
     "product": [],                                           # the defaults of jr_tuning.h
     "r1": OFF,                                               # every switch off = round-1 kernels
-    "r1_occ4": OFF[:3] + OFF[4:],                            # + the 4-waves-per-SIMD request alone
+    "r1_occ4": OFF[:5] + OFF[6:],                            # + the 4-waves-per-SIMD request alone
     "no_prepass": ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_OCC4=0"],
     "no_dis": ["JR_TUNE_FWD_DIS_ONLY=0"],
     "tv": ["JR_TUNE_TV_DIVKNOWN=1"],                         # dead: exact reciprocal-refinement quotient for tv
@@ -18,5 +18,19 @@ VARIANTS = {
     "boxtest": ["JR_TUNE_FWD_TILE_BOXTEST=1"],
     "tpw2": ["JR_TUNE_FWD_TPW=2"],
     "tpw4": ["JR_TUNE_FWD_TPW=4"],
+    "fwd64": ["JR_TUNE_FWD_BATCH=64"],                       # 64 record slots: 14 wavefronts per CU (round 1)
+    "fwd48": ["JR_TUNE_FWD_BATCH=48"],
+    "bwd64": ["JR_TUNE_BWD_BATCH=64"],                       # 13 wavefronts per CU (round 1)
+    "bwd48": ["JR_TUNE_BWD_BATCH=48"],
+    "bwd56": ["JR_TUNE_BWD_BATCH=56"],
+    "bwd44": ["JR_TUNE_BWD_BATCH=44"],
+    "bwd40": ["JR_TUNE_BWD_BATCH=40"],
+    "bwd44w5": ["JR_TUNE_BWD_BATCH=44", "JR_TUNE_BWD_WAVES=5"],
+    "bwd40w5": ["JR_TUNE_BWD_BATCH=40", "JR_TUNE_BWD_WAVES=5"],
+    "bwd36w6": ["JR_TUNE_BWD_BATCH=36", "JR_TUNE_BWD_WAVES=6"],
+    "bwd48w5": ["JR_TUNE_BWD_BATCH=48", "JR_TUNE_BWD_WAVES=5"],
+    "fwd44w5": ["JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_OCC4=5"],
+    "fwd52": ["JR_TUNE_FWD_BATCH=52"],
+    "kbuf_salu": ["JR_TUNE_FWD_KBUF_SALU=1"],
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1"],              # instrumented: tools/ablate/sections.py
 }
