@@ -51,6 +51,10 @@
 #define JR_TUNE_BWD_HOLDER_LISTS 0
 #endif
 
+#ifndef JR_TUNE_BWD_REDUCE_BANKMASK // backward: row transpose-reduction with bank-masked DPP adds instead of selects
+#define JR_TUNE_BWD_REDUCE_BANKMASK 0
+#endif
+
 #ifndef JR_TUNE_PROFILE_SECTIONS  // instrumented build: per-section shader-clock totals of the raster kernels (tools/ablate)
 #define JR_TUNE_PROFILE_SECTIONS 0
 #endif
@@ -58,6 +62,7 @@
 namespace jr {
 namespace tune {
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
+constexpr bool bwd_reduce_bankmask = JR_TUNE_BWD_REDUCE_BANKMASK != 0;
 constexpr bool bwd_holder_lists = JR_TUNE_BWD_HOLDER_LISTS != 0;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr bool tv_divknown = JR_TUNE_TV_DIVKNOWN != 0;

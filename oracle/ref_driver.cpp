@@ -30,7 +30,7 @@ namespace ref_bwd {
 }
 
 static void set_threads(int nthreads) {
-    if (nthreads > 0) omp_set_num_threads(nthreads);
+    omp_set_num_threads(nthreads > 0 ? nthreads : omp_get_num_procs());   // 0 = all host cores
 }
 
 extern "C" {

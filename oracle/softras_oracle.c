@@ -304,7 +304,8 @@ int orc_softras_forward(const float* faces, const float* textures, float* faces_
     fill_params(&p, B, NF, T, IS, K, near_, far_, eps, sigma, dist, dist_eps, gamma, rgb, alpha,
                 tex_type, double_side, bg);
 #ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
+    /* 0 = all host cores (a serial backward before this call leaves the OpenMP default at 1) */
+    omp_set_num_threads(nthreads > 0 ? nthreads : omp_get_num_procs());
 #endif
     memset(faces_info, 0, sizeof(float) * (size_t)B * NF * 27);
     for (long i = 0; i < (long)B * NF; i++) orc_face_setup(faces + i * 9, faces_info + i * 27);
@@ -497,7 +498,8 @@ int orc_softras_forward_subset(const float* faces, const float* textures, const 
     fill_params(&p, B, NF, T, IS, K, near_, far_, eps, sigma, dist, dist_eps, gamma, rgb, alpha,
                 tex_type, double_side, bg);
 #ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
+    /* 0 = all host cores (a serial backward before this call leaves the OpenMP default at 1) */
+    omp_set_num_threads(nthreads > 0 ? nthreads : omp_get_num_procs());
 #endif
     const long pp = (long)IS * IS;
 #pragma omp parallel for schedule(dynamic, 16)

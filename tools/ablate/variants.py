@@ -32,5 +32,6 @@ VARIANTS = {
     "fwd44w5": ["JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_OCC4=5"],
     "fwd52": ["JR_TUNE_FWD_BATCH=52"],
     "kbuf_salu": ["JR_TUNE_FWD_KBUF_SALU=1"],
+    "bankmask": ["JR_TUNE_BWD_REDUCE_BANKMASK=1"],          # dead (+2 % bwd): bank-masked DPP adds instead of selects — v_add_f32_dpp costs what v_cndmask costs
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1"],              # instrumented: tools/ablate/sections.py
 }
