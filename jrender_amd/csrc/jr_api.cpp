@@ -112,6 +112,7 @@ int grow(T*& ptr, size_t& cap, size_t need, double slack) {
 int validate(int B, int NF, int T, int IS, int K, int dist, int rgb, int alpha, int tex) {
     if (B < 1 || NF < 1 || T < 1 || IS < 1) return fail("B, NF, T, image_size must be >= 1 (got %d %d %d %d)", B, NF, T, IS);
     if (IS > jr::MAX_IMAGE) return fail("image_size %d exceeds the supported maximum %d", IS, jr::MAX_IMAGE);
+    if (NF > jr::MAX_FACES_PER_IMAGE) return fail("NF = %d faces per image exceed the %d the face records index", NF, jr::MAX_FACES_PER_IMAGE);
     if ((long long)B * NF > 0x7fffffffLL) return fail("B * NF = %lld faces exceed the 2^31 - 1 the kernels index", (long long)B * NF);
     if (K < 1 || K > JR_MAX_FACES_PER_PIXEL)
         return fail("max_faces_per_pixel_for_grad must be in [1,%d] (got %d)", JR_MAX_FACES_PER_PIXEL, K);

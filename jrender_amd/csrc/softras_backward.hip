@@ -152,8 +152,9 @@ template <int DIST, int RGB, bool FAST>
 __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
                                     const PixelGrad& px, float xp, float yp,
                                     const float* __restrict__ tbase, float (&gv)[9], float (&gt)[9],
-                                    float& tgs, bool& tex_on) {
-    const int fn = r.id;
+                                    float& tgs, bool& tex_on, unsigned long long* __restrict__ counters) {
+    const int meta = r.meta;
+    const int fn = face_id(meta);
     const Bary w = barycentric(r, xp, yp);
     float D, dis = 0.f;
     Dist dd;
@@ -162,7 +163,20 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_fast(-dis, p); }
     else {
         // nothing is decided from the projection parameter here (sign and region come from the exact w)
-        dd = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE)>(r, w, xp, yp);
+        dd = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE)>(r, meta, w, xp, yp);
+        if (tune::check_inside_select && FAST && strictly_inside(w)) {
+            // instrumented build: the same pair with all three edges projected must give the same bits
+            const Dist full = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE), false>(r, meta, w, xp, yp);
+            const bool same = __builtin_bit_cast(int, full.dx) == __builtin_bit_cast(int, dd.dx) &&
+                              __builtin_bit_cast(int, full.dy) == __builtin_bit_cast(int, dd.dy) &&
+                              __builtin_bit_cast(int, full.t0) == __builtin_bit_cast(int, dd.t0) &&
+                              __builtin_bit_cast(int, full.t1) == __builtin_bit_cast(int, dd.t1) &&
+                              __builtin_bit_cast(int, full.t2) == __builtin_bit_cast(int, dd.t2);
+            atomicAdd(counters + 22, 1ull);
+            if (inside_edge_select(r, w) >= 0) atomicAdd(counters + 20, 1ull);
+            if (__builtin_amdgcn_ballot_w64(inside_edge_select(r, w) < 0) != 0ull) atomicAdd(counters + 21, 1ull);
+            if (!same) atomicAdd(counters + 23, 1ull);
+        }
         dis = dd.dx * dd.dx + dd.dy * dd.dy;
         D = coverage_fast(-dd.sign * dis, p);
     }
@@ -433,11 +447,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 float tgs;
                 bool tex_on;
                 const float* vc = s_vcol + j * 9;
-                const int texel = ((fr.flags & FLAG_SAFE) && p.consts_safe)
-                    ? backward_pair<DIST, RGB, true>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on)
-                    : backward_pair<DIST, RGB, false>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on);
+                const int texel = (face_safe(fr.meta) && p.consts_safe)
+                    ? backward_pair<DIST, RGB, true>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on, counters)
+                    : backward_pair<DIST, RGB, false>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on, counters);
                 if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: straight to global
-                    float* gtf = gtbase + (size_t)fr.id * p.T * 3;
+                    float* gtf = gtbase + (size_t)face_id(fr.meta) * p.T * 3;
                     const float c0 = tgs * q.g0, c1 = tgs * q.g1, c2 = tgs * q.g2;
                     atomicAdd(gtf + texel * 3 + 0, c0);
                     atomicAdd(gtf + texel * 3 + 1, c1);
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 if (ntex == 3) { v[9] = gt[0]; v[10] = gt[1]; v[11] = gt[2]; }
             }
             clk.lap(4);
-            const int fn = fr.id;
+            const int fn = face_id(fr.meta);
             const float s = row_transpose_reduce(v, li);         // lane li: component li summed over the row
             if (ract && s != 0.f) {                              // SRK:1349-1358 does one atomic per pixel
                 if (li < 9) atomicAdd(gfbase + (size_t)fn * 9 + li, s);

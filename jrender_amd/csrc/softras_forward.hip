@@ -134,7 +134,7 @@ __device__ inline void sample_colour(const RasterParams& p, const FaceRec& r, co
     if (p.tex == 0) {
         if (p.T == 1) { k0 = r.col[0]; k1 = r.col[1]; k2 = r.col[2]; }
         else {
-            const float* tx_ = tbase + ((size_t)r.id * p.T + surface_texel(wc, p.R)) * 3;
+            const float* tx_ = tbase + ((size_t)face_id(r.meta) * p.T + surface_texel(wc, p.R)) * 3;
             k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
         }
     } else {                                                                   // SRK:168-171
@@ -149,6 +149,7 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
                                     const float* __restrict__ tbase, float xp, float yp,
                                     PixelState<KCAP>& s) {
     const Bary w = barycentric(r, xp, yp);
+    const int meta = r.meta;
     float D, neg_num = -1.f;            // neg_num = the sigmoid's numerator, -sign*dis (any negative value for 'hard')
     if (DIST == 0) {                                                           // SRK:331-333
         if (!pixel_inside(w)) return;
@@ -160,9 +161,9 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
         D = coverage_fast(neg_num, p);
     } else {                                                                   // SRK:340-344
         float sign, dis;
-        if (tune::fwd_dis_only) euclidean_sign_dis<FAST>(r, w, xp, yp, sign, dis);
+        if (tune::fwd_dis_only) euclidean_sign_dis<FAST>(r, meta, w, xp, yp, sign, dis);
         else {
-            const Dist dd = euclidean_p2f<FAST>(r, w, xp, yp);
+            const Dist dd = euclidean_p2f<FAST>(r, meta, w, xp, yp);
             sign = dd.sign;
             dis = dd.dx * dd.dx + dd.dy * dd.dy;
         }
@@ -186,16 +187,16 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
     const Bary wc = barycentric_clip<FAST>(w);
     const float zp = depth_of<FAST>(r, wc);
     if (zp < p.near_ || zp > p.far_) return;                                  // SRK:365
-    const int fn = r.id;
+    const int fn = face_id(meta);
     s.q.insert(fn, zp, p.K);
 
     if (RGB == 0) {                                                            // SRK:390-397
-        if (zp < s.depth_min && pixel_inside(w) && (p.double_side || (r.flags & FLAG_FRONT))) {
+        if (zp < s.depth_min && pixel_inside(w) && (p.double_side || face_front(meta))) {
             s.depth_min = zp; s.face_min = fn;
             sample_colour<FAST>(p, r, vc, tbase, wc, zp, s.c0, s.c1, s.c2);
         }
     } else if (RGB == 1) {                                                     // SRK:399-419
-        if ((r.flags & FLAG_FRONT) || p.double_side) {
+        if (face_front(meta) || p.double_side) {
             // zn must carry the reference's exact bits: the softmax divides differences of it by gamma
             const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
             float ed = 1.f;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                     const float e2 = 3.f * EPS * sv + 4.f * EPS * __builtin_fmaf(gmax, ext, 1.f) * pos;
                     const float margin = __builtin_fmaf(2.5f, e1 + e2, 1.0001f * p.rad);
                     // NaN anywhere makes the comparison false -> never rejects
-                    const bool ok = have && (me.flags & FLAG_SAFE) && p.consts_safe && (margin <= 1.5f * p.rad);
+                    const bool ok = have && face_safe(me.meta) && p.consts_safe && (margin <= 1.5f * p.rad);
 #pragma unroll
                     for (int q = 0; q < 3; q++) cc[q] = __builtin_fmaf(margin, g[q], me.inv[3 * q + 2]);
                     if (!ok) {
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 M &= M - 1;
                 const FaceRec& r = s_rec[j];
                 const float* vc = s_vcol + j * 9;
-                if ((r.flags & FLAG_SAFE) && p.consts_safe)
+                if (face_safe(r.meta) && p.consts_safe)
                     forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
                 else
                     forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);

@@ -33,5 +33,8 @@ VARIANTS = {
     "fwd52": ["JR_TUNE_FWD_BATCH=52"],
     "kbuf_salu": ["JR_TUNE_FWD_KBUF_SALU=1"],
     "bankmask": ["JR_TUNE_BWD_REDUCE_BANKMASK=1"],          # dead (+2 % bwd): bank-masked DPP adds instead of selects — v_add_f32_dpp costs what v_cndmask costs
+    "select": ["JR_TUNE_INSIDE_SELECT=1"],                   # dead: inside pixels project only the edge their weights name (fwd +5 %, bwd -0.5 %)
+    "check_select": ["JR_TUNE_INSIDE_SELECT=1", "JR_TUNE_CHECK_INSIDE_SELECT=1"],       # instrumented: tools/ablate/check_select.py
+    "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1"],              # instrumented: tools/ablate/sections.py
 }

@@ -2,24 +2,26 @@
 """Which edge is nearest to an INSIDE pixel?  (CPU; needs the oracle.)
 
 The reference projects an inside pixel onto all three edge LINES and keeps the nearest (SRK:68-105, strict '<',
-first edge wins ties).  Geometrically the distance to the line of edge e (vertices e, e+1) is w_k * h_k for the
-opposite vertex k = e+2: its barycentric weight times its altitude h_k = 1 / |grad w_k|.  The kernels use that to
-SELECT the edge worth projecting exactly (softras_device.h: inside_edge_select): with a per-face band B that bounds
-how far the reference's float result can be from the geometric distance, every edge with
-        w_k h_k <= min_j (w_j h_j) + 2 B
-is a candidate; one candidate -> only that edge is projected (it IS the reference's argmin), several -> all three
-as before.  The record stores s_k = h_k / (2 B), so the test is  w_k s_k <= min_j (w_j s_j) + 1.
+first edge wins ties).  The kernels SELECT the edge worth projecting (softras_device.h: inside_edge_select) from
+a geometric model of what the reference's float arithmetic computes, and fall back to all three projections when
+the model cannot separate the edges:
 
-B (float32, the formula of csrc/softras_device.h: build_face_geo) = 32 EPS / sqrt(min |Dn|) + 3 (E1 + E2):
-  EPS / sqrt(Dn_e) = scale of the foot point's displacement along the edge (sym differences carry ~4 EPS absolute
-                     error, the quotient divides by |edge|^2),
-  E1               = the weights do not sum to 1 (one rounded det): pixel displaced by (sum w - 1) * position,
-  E2               = rounding of the weights times the vertex positions, of the offset products.
+  * the reference measures from pixel' = sum_k w_k P_k (SRK:87-92: u = t - w, offset = sum u_k P_k), and its weights
+    do not sum to one (face_inv is star / det with ONE rounded det): with sm1 = ((w0 + w1) + w2) - 1 the weight of
+    pixel' is   wr_k = w_k - sm1 * inv[3k+2]   (w_k is affine: w_k(sum w_j P_j) = w_k + c_k (1 - sum w_j)),
+    so the distance of pixel' to the line opposite vertex k is  q_k = |wr_k| h_k,  h_k = 1 / |grad w_k|;
+  * the foot point is displaced ALONG the edge by the error of the projection parameter (differences of
+    face_sym = x x' + y y' + 1 carry ~4 EPS absolute error, the quotient divides by |edge|^2): the reference's
+    distance is sqrt(q_k^2 + d^2) with  d <= dl_k = 32 EPS (2 + sqrt(Dmax / Dn_e)) / sqrt(Dn_e)  (second order!);
+  * everything else (rounding of w, of the offsets) stays below  eta = 32 EPS (max_k S_k h_k + pos + max_k |c_k| h_k).
+Edge k is a CANDIDATE iff  q_k - eta <= min_j sqrt(q_j^2 + dl_j^2) + eta.  The record stores s_k = h_k / (2 eta) and
+(dl_k / (2 eta))^2, so the test is  q~_k <= min_j sqrt(q~_j^2 + dl~_j^2) + 1  (3 sqrt per pair, no division).
+
 This tool replays the reference's float32 arithmetic (association order of SRK:73-92) on sampled inside pairs:
-  wrong    = pairs whose reference argmin edge is NOT a candidate            (must be 0),
-  noise/B  = max |sqrt(dd_e) - w_k h_k| / B                                  (safety factor = 1 / that),
-  share of inside pairs with 1 / 2 / 3 candidates (the second and third cost a full three-edge evaluation of
-  the wavefront trip they are in).
+  wrong    = single-candidate pairs whose candidate is NOT the reference's argmin          (must be 0),
+  up/down  = max of (reference - model upper bound) / band, (model lower bound - reference) / band  (must be < 1;
+             1 / that = safety factor),
+  share of inside pairs with 1 / 2 / 3 candidates (2 and 3 cost a full three-edge evaluation of their trip).
 usage: inside_edge.py IS NFACES sphere|soup|fuzz [views] [seed]"""
 import os
 import sys
@@ -64,29 +66,30 @@ yp = ((2 * (IS - 1 - row) + 1 - IS).astype(F) / F(IS)).astype(F)
 
 
 def select_scales(inv, x, y, Dn):
-    """s_k = h_k / (2 B) in float32, mirroring build_face_geo"""
+    """s_k = h_k / (2 eta), dl2_k = (dl_k / (2 eta))^2 by VERTEX k (edge k+1 is opposite), float32 like build_face_geo"""
     X = np.abs(x).max(1)
     Y = np.abs(y).max(1)
     pos = np.sqrt(X * X + Y * Y)
-    ext = (x.max(1) - x.min(1)) + (y.max(1) - y.min(1))
-    g = np.stack([np.sqrt(inv[:, 3 * q] * inv[:, 3 * q] + inv[:, 3 * q + 1] * inv[:, 3 * q + 1]) for q in range(3)], 1).astype(F)
-    S = np.stack([np.abs(inv[:, 3 * q]) * X + np.abs(inv[:, 3 * q + 1]) * Y + np.abs(inv[:, 3 * q + 2]) for q in range(3)], 1).astype(F)
-    sv = (S * np.sqrt(x * x + y * y)).sum(1)
-    ca = np.abs((inv[:, 0] + inv[:, 3]) + inv[:, 6])
-    cb = np.abs((inv[:, 1] + inv[:, 4]) + inv[:, 7])
-    cd = np.abs(((inv[:, 2] + inv[:, 5]) + inv[:, 8]) - F(1))
-    e1 = ((ca * X + cb * Y + cd) + F(4) * EPS * S.sum(1)) * pos
-    e2 = F(3) * EPS * sv + F(4) * EPS * (g.max(1) * ext + F(1)) * pos
-    dmin = np.abs(Dn).min(1)
     with np.errstate(all="ignore"):
-        band = (F(32) * EPS / np.sqrt(dmin) + F(3) * (e1 + e2)).astype(F)
+        g = np.stack([np.sqrt(inv[:, 3 * q] * inv[:, 3 * q] + inv[:, 3 * q + 1] * inv[:, 3 * q + 1]) for q in range(3)], 1).astype(F)
         h = (F(1) / g).astype(F)
-        s = (h / (F(2) * band)[:, None]).astype(F)
-    return s, h, band
+        S = np.stack([np.abs(inv[:, 3 * q]) * X + np.abs(inv[:, 3 * q + 1]) * Y + np.abs(inv[:, 3 * q + 2]) for q in range(3)], 1).astype(F)
+        aD = np.abs(Dn)
+        slack = F(16) * EPS                                         # absolute error allowance of a sym difference
+        ehi = np.sqrt(aD + slack)                                   # upper bound of the edge length
+        L = np.sqrt(aD.max(1) + slack) + F(2.0 ** -10) * pos        # how far pixel' can be from a vertex (|sm1| <= 2^-10)
+        tvb = (ehi * L[:, None] + slack) / aD + F(1)                # bound of |tv| of the reference's quotient
+        dl_e = (F(float(os.environ.get("C1", 12))) * EPS * (F(1) + tvb) * ehi / aD).astype(F)   # by edge
+        eta = (F(32) * EPS * ((S * h).max(1) + pos + (np.abs(inv[:, [2, 5, 8]]) * h).max(1)) + F(8) * EPS * tvb.max(1) * pos).astype(F)
+        dl_v = np.stack([dl_e[:, 1], dl_e[:, 2], dl_e[:, 0]], 1)                               # vertex k <- edge k+1
+        r2e = (F(1) / (F(2) * eta)).astype(F)
+        s_ = (h * r2e[:, None]).astype(F)
+        dl2 = ((dl_v * r2e[:, None]) ** 2).astype(F)
+    return s_, dl2, h, eta, dl_v
 
 
 tot = wrong = 0
-noise_rel = 0.0
+noise = [0.0, 0.0]
 need = np.zeros(4, np.int64)
 for k in range(K):
     fid = ids[:, k]
@@ -120,27 +123,37 @@ for k in range(K):
     ddc = np.where(dd < F(1e8), dd, np.inf)
     ref_e = np.argmin(ddc, 1)
     has_ref = np.isfinite(ddc).any(1)
-    s, h, band = select_scales(inv, x, y, Dn)
+    s, dl2, h, eta, dl_v = select_scales(inv, x, y, Dn)
     with np.errstate(all="ignore"):
-        q = (w * s).astype(F)                                       # by vertex
-        lim = q.min(1) + F(1)
+        sm1 = (((w[:, 0] + w[:, 1]) + w[:, 2]) - F(1)).astype(F)
+        wr = np.stack([w[:, q] - sm1 * inv[:, 3 * q + 2] for q in range(3)], 1).astype(F)
+        q = (np.abs(wr) * s).astype(F)                              # by vertex, in units of 2 eta
+        rr = np.sqrt((q * q + dl2).astype(F)).astype(F)
+        lim = rr.min(1) + F(1)
         cand_v = q <= lim[:, None]
+        cond = np.abs(sm1) <= F(2.0 ** -10)
     cand_e = np.stack([cand_v[:, 2], cand_v[:, 0], cand_v[:, 1]], 1)   # edge e is opposite vertex e+2
     nb = cand_e.sum(1)
-    single = nb == 1
-    # single-candidate pairs must have picked the reference's edge (and the reference must have one)
+    single = (nb == 1) & cond
     sel_e = np.argmax(cand_e, 1)
-    bad = single & has_ref & (sel_e != ref_e)
+    bad = single & (~has_ref | (sel_e != ref_e))
     wrong += int(bad.sum())
     tot += len(ref_e)
+    nb = np.where(cond, nb, 3)                                  # ill-conditioned pair: all three edges
     for c in (0, 1, 2, 3):
         need[c] += int((nb == c).sum())
     with np.errstate(all="ignore"):
-        qe = np.stack([w[:, 2] * h[:, 2], w[:, 0] * h[:, 0], w[:, 1] * h[:, 1]], 1).astype(np.float64)
-        d = np.abs(np.sqrt(dd.astype(np.float64)) - qe) / band.astype(np.float64)[:, None]
-    d = d[np.isfinite(d)]
-    if d.size:
-        noise_rel = max(noise_rel, float(d.max()))
-print("%s NF=%d IS=%d views=%d seed=%d: inside pairs %d, wrong %d, noise/B %.3f, candidates 0/1/2/3: %.4f %.4f %.4f %.4f"
-      % (scene, NF, IS, B, seed, tot, wrong, noise_rel, need[0] / max(tot, 1), need[1] / max(tot, 1), need[2] / max(tot, 1),
+        qd = (np.abs(wr) * h).astype(np.float64)                    # by vertex, NDC
+        qe = np.stack([qd[:, 2], qd[:, 0], qd[:, 1]], 1)
+        dle = np.stack([dl_v[:, 2], dl_v[:, 0], dl_v[:, 1]], 1).astype(np.float64)
+        ref = np.sqrt(dd.astype(np.float64))
+        e64 = eta.astype(np.float64)[:, None]
+        up = np.where(cond[:, None], (ref - np.sqrt(qe * qe + dle * dle)) / e64, 0.0)   # must stay <= 1
+        down = np.where(cond[:, None], (qe - ref) / e64, 0.0)
+    for arr, idx in ((up, 0), (down, 1)):
+        arr = arr[np.isfinite(arr)]
+        if arr.size:
+            noise[idx] = max(noise[idx], float(arr.max()))
+print("%s NF=%d IS=%d views=%d seed=%d: inside pairs %d, wrong %d, up %.3f down %.3f (of eta), candidates 0/1/2/3: %.4f %.4f %.4f %.4f"
+      % (scene, NF, IS, B, seed, tot, wrong, noise[0], noise[1], need[0] / max(tot, 1), need[1] / max(tot, 1), need[2] / max(tot, 1),
          need[3] / max(tot, 1)))
