@@ -47,11 +47,12 @@
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
 
-#ifndef JR_TUNE_BWD_BATCH         // backward: faces per batch (LDS record slots per wavefront), <= 64; 52 slots + tables < 10 KB -> 16 wavefronts per CU
-#define JR_TUNE_BWD_BATCH 52
+#ifndef JR_TUNE_BWD_BATCH         // backward: faces per batch (LDS record slots per wavefront), <= 64; 40 slots + tables = 7.6 KB -> 20 wavefronts per CU
+#define JR_TUNE_BWD_BATCH 40
 #endif
-#ifndef JR_TUNE_BWD_WAVES         // backward: wavefronts per SIMD asked of the register allocator at K <= 16
-#define JR_TUNE_BWD_WAVES 4
+#ifndef JR_TUNE_BWD_WAVES         // backward: wavefronts per SIMD asked of the register allocator at K <= 16 (5 -> 96 VGPRs, still 32 B of scratch;
+                                  // 6 and 7 spill 64-112 B and are 1.5-2.2x slower: profiles/r02_ablation_sweep.log)
+#define JR_TUNE_BWD_WAVES 5
 #endif
 #ifndef JR_TUNE_BWD_HOLDER_LISTS  // backward: per-face holder lists in LDS instead of the n-th-set-bit search
 #define JR_TUNE_BWD_HOLDER_LISTS 0

@@ -6,7 +6,7 @@ Bars are the sweep's own: faces_info and the face-index buffer bit-exact, RGBA /
 1e-4 of the largest component.  Two classes of cases are exempt from the gradient bar, each by an explicit
 predicate evaluated on the REFERENCE's output (not on ours):
   * `overflow`  — the reference's own gradient is non-finite or beyond 1e30 (back faces enter the backward's
-                  softmax, SRK:1308): the non-finite pattern must agree, the finite rest is held to 1e-2;
+                  softmax, SRK:1308): the non-finite pattern must agree, the finite rest is held to 5e-2;
   * `illcond`   — gradient error in (1e-4, 1e-2]: only tolerated when the operator divides the alpha gradient by
                   NF (aggr_func_alpha='sum'), which leaves the forward's last-bit colour noise (k - o) / D of
                   single-face pixels as the largest term.  With the fixed seeds below NO such case occurs, and
