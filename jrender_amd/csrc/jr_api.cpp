@@ -145,6 +145,8 @@ jr::RasterParams make_params(int B, int NF, int T, int IS, int K, float near_, f
     p.r_gamma = 1.0f / gamma;
     p.r_far_minus_near = 1.0f / p.far_minus_near;
     p.r_near_minus_far = 1.0f / p.near_minus_far;
+    p.rs_log2e = (float)(1.4426950408889634 / (double)sigma);
+    p.rg_log2e = (float)(1.4426950408889634 / (double)gamma);
     auto in_range = [](float v) { const float a = std::fabs(v); return a >= 9.094947017729282e-13f && a <= 1.099511627776e12f; };
     p.consts_safe = in_range(sigma) && in_range(gamma) && in_range(p.far_minus_near) && in_range(near_) &&
                     in_range(far_) && (eps == 0.f || in_range(eps));

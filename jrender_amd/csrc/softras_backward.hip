@@ -193,7 +193,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
         if ((float)fn == px.smax) { tgs = 1.f; tex_on = true; }
     } else if (RGB == 1) {                                                // SRK:1308-1332
         const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
-        const float zs = D * fast_exp(over_gamma<FAST>(zn - px.smax, p)) * px.r_ssum;
+        const float zs = D * exp_over_gamma(zn - px.smax, p) * px.r_ssum;
         tgs = zs; tex_on = true;
         float k0, k1, k2;
         if (p.tex == 0) {

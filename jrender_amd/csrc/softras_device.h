@@ -45,6 +45,7 @@ struct RasterParams {
     // correctly rounded reciprocals of the per-call divisors + "they are in the safe range"
     float far_minus_near, near_minus_far;
     float r_sigma, r_gamma, r_far_minus_near, r_near_minus_far;
+    float rs_log2e, rg_log2e;   // log2(e) / sigma, log2(e) / gamma: exp(x / sigma) = exp2(x * rs_log2e) on the colour path
     int consts_safe;
 };
 
@@ -353,6 +354,12 @@ __device__ inline int outside_edge(const FaceGeo& r, int obt, const Bary& b, flo
 __device__ inline bool strictly_inside(const Bary& b) {
     return b.w0 > 0 && b.w1 > 0 && b.w2 > 0 && b.w0 < 1 && b.w1 < 1 && b.w2 < 1;
 }
+// the same for finite weights (FLAG_SAFE faces): v_min3 / v_max3 and two compares instead of six compares
+template <bool FAST>
+__device__ inline bool strictly_inside_t(const Bary& b) {
+    if (FAST) return fminf(fminf(b.w0, b.w1), b.w2) > 0 && fmaxf(fmaxf(b.w0, b.w1), b.w2) < 1;
+    return strictly_inside(b);
+}
 
 // Which edge is nearest to an INSIDE pixel?  The reference projects the pixel onto all three edge lines and keeps
 // the nearest (SRK:68-105).  The nearest edge can be told from the weights alone — unless two edges are nearly
@@ -391,7 +398,7 @@ __device__ inline int inside_edge_select(const FaceGeo& r, const Bary& b) {
 // lane could not be decided.
 template <bool FAST, int TV = (tune::tv_divknown ? TV_EXACT : TV_IEEE), bool SELECT = tune::inside_select>
 __device__ inline Dist euclidean_p2f(const FaceGeo& r, int meta, const Bary& b, float xp, float yp) {
-    const bool inside = strictly_inside(b);
+    const bool inside = strictly_inside_t<FAST>(b);
     const int v0 = outside_edge(r, face_obtuse(meta), b, xp, yp);
     int esel = -1;
     if (FAST && SELECT && inside) esel = inside_edge_select(r, b);
@@ -437,7 +444,7 @@ __device__ inline Dist euclidean_p2f(const FaceGeo& r, int meta, const Bary& b, 
 template <bool FAST>
 __device__ inline void euclidean_sign_dis(const FaceGeo& r, int meta, const Bary& b, float xp, float yp, float& sign,
                                           float& dis) {
-    const bool inside = strictly_inside(b);
+    const bool inside = strictly_inside_t<FAST>(b);
     const int v0 = outside_edge(r, face_obtuse(meta), b, xp, yp);
     int esel = -1;
     if (FAST && tune::inside_select && inside) esel = inside_edge_select(r, b);
@@ -480,16 +487,18 @@ __device__ inline float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.
 __device__ inline float over_sigma(float x, const RasterParams& p) {
     return p.consts_safe ? x * p.r_sigma : x / p.sigma;
 }
-// x / gamma feeds exp() with arguments of magnitude up to 1e4: keep the IEEE quotient (the
-// refinement form is exact for these operands: differences of normalised depths are multiples
-// of 2^-48 or larger).
-template <bool FAST>
-__device__ inline float over_gamma(float x, const RasterParams& p) {
-    return div_known<FAST>(x, p.gamma, p.r_gamma);
+// exp(x / gamma) of the softmax weights, x = zn - smax <= 0 (SRK:401-411, :1308).  Colour path: the weights only
+// have to be good to 1e-4 where they are not negligible (|x / gamma| < ~20), so the quotient and the change of
+// base are ONE multiply by the precomputed log2(e) / gamma (argument error <= 2 ulp: relative error of the weight
+// 1.2e-7 * |x / gamma|).  zn itself keeps the reference's exact bits (div_known at the call sites): differences of
+// it are divided by gamma, an ulp there would be 6e-4 of the weight.
+__device__ inline float exp_over_gamma(float x, const RasterParams& p) {
+    return p.consts_safe ? __builtin_amdgcn_exp2f(x * p.rg_log2e) : fast_exp(x / p.gamma);
 }
 // sigmoid coverage 1/(1+exp(neg_num/sigma)) (SRK:338, :344; the reference adds and divides in double)
 __device__ inline float coverage_fast(float neg_num, const RasterParams& p) {
-    return __builtin_amdgcn_rcpf(1.0f + fast_exp(over_sigma(neg_num, p)));
+    const float e = p.consts_safe ? __builtin_amdgcn_exp2f(neg_num * p.rs_log2e) : fast_exp(neg_num / p.sigma);
+    return __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // 'surface' sampler texel choice (SRK:159-166, identical in SRK:1138-1145)

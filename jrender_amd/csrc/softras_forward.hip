@@ -182,7 +182,12 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
         if (x < -8.940696716308594e-08f) s.alpha = 1.f;
     }
     else if (p.alpha == 1) s.alpha += D;
-    else s.alpha = (float)((double)s.alpha * (1. - (double)D));
+    else {
+        // SRK:357 multiplies in double and rounds to float: alpha * (1 - D) with 1 - D exact.  One float fma
+        // returns the correctly rounded alpha - alpha * D — the same value up to the (rare, half-ulp) double rounding of
+        // the reference; alpha only has to meet 1e-4.
+        s.alpha = __builtin_fmaf(-s.alpha, D, s.alpha);
+    }
 
     const Bary wc = barycentric_clip<FAST>(w);
     const float zp = depth_of<FAST>(r, wc);
@@ -200,8 +205,8 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
             // zn must carry the reference's exact bits: the softmax divides differences of it by gamma
             const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
             float ed = 1.f;
-            if (zn > s.smax) { ed = fast_exp(over_gamma<FAST>(s.smax - zn, p)); s.smax = zn; }
-            const float ez = fast_exp(over_gamma<FAST>(zn - s.smax, p));
+            if (zn > s.smax) { ed = exp_over_gamma(s.smax - zn, p); s.smax = zn; }
+            const float ez = exp_over_gamma(zn - s.smax, p);
             s.ssum = ed * s.ssum + ez * D;
             float k0, k1, k2;
             sample_colour<FAST>(p, r, vc, tbase, wc, zp, k0, k1, k2);
