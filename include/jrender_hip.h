@@ -78,7 +78,8 @@ int jr_event_elapsed_ms(jr_ctx* ctx, void* start, void* stop, float* ms); /* syn
  *      faces_id_buffer [B,K,IS,IS] i32 (-1 = empty slot).  Outputs need no pre-initialisation.
  * background_rgb: host pointer to 3 floats, or NULL = the reference's behaviour (background
  *      colour ignored, i.e. 0; soft_rasterize.py:68-74 vs SRK:469).
- * K = max_faces_per_pixel_for_grad, 1..JR_MAX_FACES_PER_PIXEL.  IS <= 4096.
+ * K = max_faces_per_pixel_for_grad, 1..JR_MAX_FACES_PER_PIXEL.  IS <= 4096.  NF <= 2^28 - 1 faces per image,
+ * B * NF <= 2^31 - 1 (the face records and the bin lists index with these widths); violations return non-zero.
  */
 int jr_softras_forward(jr_ctx* ctx, const float* face_vertices, const float* textures,
                        float* faces_info, float* aggrs_info, float* soft_colors,
