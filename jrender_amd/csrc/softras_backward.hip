@@ -142,7 +142,9 @@ __device__ inline float gdiv(float x, float c, float rc, const RasterParams& p) 
     return p.consts_safe ? x * rc : x / c;
 }
 
-// Contribution of one (pixel, face) pair: gv = d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2), gt = colour gradient
+// Contribution of one (pixel, face) pair: gv = d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2); the colour gradient is tgs * upstream
+// (times the clipped weights wcw for vertex colours) and is formed by the caller right where it is reduced: a gt[9]
+// array carried through this function cost two scratch slots with a load on the critical path of every trip.
 // (3 values for a single-texel surface, 9 for vertex colours).  Returns the sampled texel.
 // The forward quantities it re-derives (w, distance, coverage, clipped depth, normalised depth) go
 // through the SAME device functions as the forward kernel, so they carry the forward's exact bits
@@ -151,7 +153,7 @@ __device__ inline float gdiv(float x, float c, float rc, const RasterParams& p) 
 template <int DIST, int RGB, bool FAST>
 __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
                                     const PixelGrad& px, float xp, float yp,
-                                    const float* __restrict__ tbase, float (&gv)[9], float (&gt)[9],
+                                    const float* __restrict__ tbase, float (&gv)[9], float (&wcw)[3],
                                     float& tgs, bool& tex_on, unsigned long long* __restrict__ counters) {
     const int meta = r.meta;
     const int fn = face_id(meta);
@@ -218,19 +220,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
         gv[5] = cz * wc.w1 * r.rz[1] * r.rz[1];
         gv[8] = cz * wc.w2 * r.rz[2] * r.rz[2];
     }
-    if (tex_on) {
-        if (p.tex == 1) {                    // backward_sample_texture vertex: w[j]*grad (SRK:1170-1172)
-            const float wj[3] = {wc.w0, wc.w1, wc.w2};
-#pragma unroll
-            for (int jv = 0; jv < 3; jv++) {
-                gt[3 * jv + 0] = tgs * (wj[jv] * px.g0);
-                gt[3 * jv + 1] = tgs * (wj[jv] * px.g1);
-                gt[3 * jv + 2] = tgs * (wj[jv] * px.g2);
-            }
-        } else if (p.T == 1) {
-            gt[0] = tgs * px.g0; gt[1] = tgs * px.g1; gt[2] = tgs * px.g2;
-        }
-    }
+    wcw[0] = wc.w0; wcw[1] = wc.w1; wcw[2] = wc.w2;      // backward_sample_texture vertex: w[j]*grad (SRK:1170-1172)
     cxy *= gdiv(D * (1 - D), p.sigma, p.r_sigma, p);                      // SRK:1336
     if (DIST == 1) {                                                      // SRK:1118-1132
         const int q = w.w0 > w.w1 ? (w.w1 > w.w2 ? 2 : 1) : (w.w0 > w.w2 ? 2 : 0);
@@ -437,7 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             if (tune::profile_sections) { __builtin_amdgcn_s_waitcnt(0); clk.lap(3); }
             const FaceRec& fr = s_rec[j];
             float v[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            float gt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float tw = 0.f, wcw[3] = {0.f, 0.f, 0.f};               // colour-gradient weight of this pair, clipped weights
             // check_border is repeated by the reference's backward (SRK:1244); one predicate, no
             // short-circuit ladder (every rung would re-materialise the zeroed outputs)
             const float4 box = *reinterpret_cast<const float4*>(&fr);       // xlo xhi ylo yhi
@@ -448,8 +438,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 bool tex_on;
                 const float* vc = s_vcol + j * 9;
                 const int texel = (face_safe(fr.meta) && p.consts_safe)
-                    ? backward_pair<DIST, RGB, true>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on, counters)
-                    : backward_pair<DIST, RGB, false>(p, fr, vc, q, qx, qy, tbase, gv, gt, tgs, tex_on, counters);
+                    ? backward_pair<DIST, RGB, true>(p, fr, vc, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters)
+                    : backward_pair<DIST, RGB, false>(p, fr, vc, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters);
                 if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: straight to global
                     float* gtf = gtbase + (size_t)face_id(fr.meta) * p.T * 3;
                     const float c0 = tgs * q.g0, c1 = tgs * q.g1, c2 = tgs * q.g2;
@@ -471,7 +461,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 }
 #pragma unroll
                 for (int k = 0; k < 9; k++) v[k] = gv[k];
-                if (ntex == 3) { v[9] = gt[0]; v[10] = gt[1]; v[11] = gt[2]; }
+                tw = tex_on ? tgs : 0.f;
+                if (ntex == 3) { v[9] = tw * q.g0; v[10] = tw * q.g1; v[11] = tw * q.g2; }
             }
             clk.lap(4);
             const int fn = face_id(fr.meta);
@@ -483,7 +474,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             if (ntex == 9) {                                     // vertex colours: 9 more components
                 float u[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 9; k++) u[k] = gt[k];
+                for (int jv = 0; jv < 3; jv++) {
+                    u[3 * jv + 0] = tw * (wcw[jv] * q.g0);
+                    u[3 * jv + 1] = tw * (wcw[jv] * q.g1);
+                    u[3 * jv + 2] = tw * (wcw[jv] * q.g2);
+                }
                 const float st = row_transpose_reduce(u, li);
                 if (ract && li < 9 && st != 0.f) atomicAdd(gtbase + (size_t)fn * p.T * 3 + li, st);
             }

@@ -33,6 +33,7 @@ VARIANTS = {
     "bwd32w5": ["JR_TUNE_BWD_BATCH=32", "JR_TUNE_BWD_WAVES=5"],
     "bwd28w7": ["JR_TUNE_BWD_BATCH=28", "JR_TUNE_BWD_WAVES=7"],
     "bwd52w4": ["JR_TUNE_BWD_BATCH=52", "JR_TUNE_BWD_WAVES=4"],   # round-2 start
+    "bwd34w6": ["JR_TUNE_BWD_BATCH=34", "JR_TUNE_BWD_WAVES=6"],
     "bwd48w5": ["JR_TUNE_BWD_BATCH=48", "JR_TUNE_BWD_WAVES=5"],
     "fwd44w5": ["JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_OCC4=5"],
     "fwd52": ["JR_TUNE_FWD_BATCH=52"],
