@@ -54,9 +54,6 @@
                                   // 6 and 7 spill 64-112 B and are 1.5-2.2x slower: profiles/r02_ablation_sweep.log)
 #define JR_TUNE_BWD_WAVES 5
 #endif
-#ifndef JR_TUNE_BWD_HOLDER_LISTS  // backward: per-face holder lists in LDS instead of the n-th-set-bit search
-#define JR_TUNE_BWD_HOLDER_LISTS 0
-#endif
 
 #ifndef JR_TUNE_BWD_REDUCE_BANKMASK // backward: row transpose-reduction with bank-masked DPP adds instead of selects
 #define JR_TUNE_BWD_REDUCE_BANKMASK 0
@@ -74,7 +71,6 @@ namespace jr {
 namespace tune {
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
 constexpr bool bwd_reduce_bankmask = JR_TUNE_BWD_REDUCE_BANKMASK != 0;
-constexpr bool bwd_holder_lists = JR_TUNE_BWD_HOLDER_LISTS != 0;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr bool check_inside_select = JR_TUNE_CHECK_INSIDE_SELECT != 0;
 constexpr bool inside_select = JR_TUNE_INSIDE_SELECT != 0;

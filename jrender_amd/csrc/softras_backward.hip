@@ -263,14 +263,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     constexpr int BATCH = tune::bwd_batch;
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
     float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
-    __shared__ unsigned long long s_has[tune::bwd_holder_lists ? 1 : BATCH];   // slot -> pixels (lanes) that hold the face
+    __shared__ unsigned long long s_has[BATCH];     // slot -> pixels (lanes) that hold the face
     __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
-    // tune::bwd_holder_lists: the holders of every face of the batch as a LIST of lane numbers (bytes), written
-    // by the holders themselves while the batch is extracted (rank = mbcnt of the holder ballot): a work lane
-    // reads "its" pixel with one ds_read_u8 instead of a 50-instruction n-th-set-bit search.  A lane holds at
-    // most KCAP faces, so a batch has at most 64 * KCAP entries.
-    __shared__ unsigned char s_list[tune::bwd_holder_lists ? CHUNK * KCAP : 1];
-    __shared__ int s_meta[tune::bwd_holder_lists ? CHUNK : 1];      // slot -> first entry | holders << 16
 
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
     const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
@@ -345,7 +339,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     // holder mask.  No list walk, no binary search, no bit-matrix transpose.
     clk.lap(0);
     for (;;) {
-        int fill = 0, myid = 0, off = 0, mymeta = 0;
+        int fill = 0, myid = 0;
         unsigned long long has = 0ull;
         while (fill < BATCH) {
             const int m = wave_min(cur);
@@ -353,12 +347,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             const bool hit = cur == m;
             const unsigned long long h = ballot(hit);
             if (lane == fill) { myid = m; has = h; }
-            if (tune::bwd_holder_lists) {
-                const int nh = __builtin_popcountll(h);
-                if (hit) s_list[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(h >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)h, 0u))] = (unsigned char)lane;
-                if (lane == fill) mymeta = off | (nh << 16);
-                off += nh;
-            }
             if (hit) {
 #pragma unroll
                 for (int k = 0; k + 1 < KCAP; k++) mine[k] = mine[k + 1];
@@ -392,8 +380,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             if (lane >= d) incl += o;
         }
         const int nitems = __builtin_amdgcn_readlane(incl, 63);
-        if (tune::bwd_holder_lists) s_meta[lane] = mymeta;
-        else if (lane < BATCH) s_has[lane] = has;
+        if (lane < BATCH) s_has[lane] = has;
         s_ioff[lane] = incl - items;
         if (lane == 0) s_ioff[64] = nitems;
         __syncthreads();
@@ -402,30 +389,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         //      the pixels' state, pair arithmetic, row-local transpose-reduction -> lane k of the row
         //      holds component k -> ONE atomic instruction per row and item ----
         clk.lap(2);
-        int j = 0;
+        // The item of the NEXT trip is looked up (slot, rank base, holder mask: dependent LDS reads) before the
+        // reduction of the current one, so that the latency hides behind the reduction instead of heading the trip.
+        int j = 0, nth = 64;
+        unsigned long long hs = 0ull;
+        bool ract = blk < nitems;                                // uniform within a row
+        if (ract) {
+            while (s_ioff[j + 1] <= blk) j++;
+            nth = (blk - s_ioff[j]) * 16 + li;
+            hs = s_has[j];
+        }
         for (int i0 = 0; i0 < nitems; i0 += 4) {
-            const int item = i0 + blk;
-            const bool ract = item < nitems;                     // uniform within a row
-            if (ract) while (s_ioff[j + 1] <= item) j++;
-            const int nth = ract ? (item - s_ioff[j]) * 16 + li : 64;
-            bool act;
-            int src;                                             // the pixel (lane) this pair belongs to
-            if (tune::bwd_holder_lists) {
-                const int meta = ract ? s_meta[j] : 0;
-                act = nth < (meta >> 16);
-                src = act ? (int)s_list[(meta & 0xffff) + nth] : lane;
-            } else {
-                const unsigned long long hs = ract ? s_has[j] : 0ull;
-                act = nth < __builtin_popcountll(hs);
-                src = act ? select_bit(hs, nth) : lane;
-            }
+            const int jc = j;                                    // slot of this trip's item
+            const bool ractc = ract;
+            const bool act = nth < __builtin_popcountll(hs);
+            const int src = act ? select_bit(hs, nth) : lane;    // the pixel (lane) this pair belongs to
             PixelGrad q;
             q.g0 = gather(px.g0, src); q.g1 = gather(px.g1, src); q.g2 = gather(px.g2, src); q.g3 = gather(px.g3, src);
             q.o0 = gather(px.o0, src); q.o1 = gather(px.o1, src); q.o2 = gather(px.o2, src); q.o3 = gather(px.o3, src);
             q.ssum = gather(px.ssum, src); q.smax = gather(px.smax, src); q.r_ssum = gather(px.r_ssum, src);
             const float qx = gather(xp, src), qy = gather(yp, src);
             if (tune::profile_sections) { __builtin_amdgcn_s_waitcnt(0); clk.lap(3); }
-            const FaceRec& fr = s_rec[j];
+            const FaceRec& fr = s_rec[jc];
             float v[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float tw = 0.f, wcw[3] = {0.f, 0.f, 0.f};               // colour-gradient weight of this pair, clipped weights
             // check_border is repeated by the reference's backward (SRK:1244); one predicate, no
@@ -436,7 +421,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // x0 y0 z0 x1 y1 z1 x2 y2 z2
                 float tgs;
                 bool tex_on;
-                const float* vc = s_vcol + j * 9;
+                const float* vc = s_vcol + jc * 9;
                 const int texel = (face_safe(fr.meta) && p.consts_safe)
                     ? backward_pair<DIST, RGB, true>(p, fr, vc, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters)
                     : backward_pair<DIST, RGB, false>(p, fr, vc, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters);
@@ -466,8 +451,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             }
             clk.lap(4);
             const int fn = face_id(fr.meta);
+            {                                                    // next trip's item
+                const int item = i0 + 4 + blk;
+                ract = item < nitems;
+                nth = 64; hs = 0ull;
+                if (ract) {
+                    while (s_ioff[j + 1] <= item) j++;
+                    nth = (item - s_ioff[j]) * 16 + li;
+                    hs = s_has[j];
+                }
+            }
             const float s = row_transpose_reduce(v, li);         // lane li: component li summed over the row
-            if (ract && s != 0.f) {                              // SRK:1349-1358 does one atomic per pixel
+            if (ractc && s != 0.f) {                              // SRK:1349-1358 does one atomic per pixel
                 if (li < 9) atomicAdd(gfbase + (size_t)fn * 9 + li, s);
                 else if (li < 9 + (ntex == 3 ? 3 : 0)) atomicAdd(gtbase + (size_t)fn * p.T * 3 + (li - 9), s);
             }
@@ -480,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                     u[3 * jv + 2] = tw * (wcw[jv] * q.g2);
                 }
                 const float st = row_transpose_reduce(u, li);
-                if (ract && li < 9 && st != 0.f) atomicAdd(gtbase + (size_t)fn * p.T * 3 + li, st);
+                if (ractc && li < 9 && st != 0.f) atomicAdd(gtbase + (size_t)fn * p.T * 3 + li, st);
             }
             clk.lap(5);
         }

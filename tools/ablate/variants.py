@@ -14,7 +14,6 @@ VARIANTS = {
     "bigk_regs": ["JR_TUNE_FWD_IDS_LDS_BIGK=0"],             # K > 16 with ids in registers (round 1)
     "bwd_rcp": ["JR_TUNE_BWD_TV_RCP=1"],                     # dead: breaks the 1e-4 gradient bar
     "no_inside_rcp": ["JR_TUNE_FWD_INSIDE_RCP=0"],
-    "holders": ["JR_TUNE_BWD_HOLDER_LISTS=1"],
     "boxtest": ["JR_TUNE_FWD_TILE_BOXTEST=1"],
     "tpw2": ["JR_TUNE_FWD_TPW=2"],
     "tpw4": ["JR_TUNE_FWD_TPW=4"],
