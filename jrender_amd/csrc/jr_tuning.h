@@ -4,7 +4,8 @@
 // implementations (same face-index buffer bits, colours / gradients within tolerance).
 #pragma once
 
-#ifndef JR_TUNE_TV_DIVKNOWN      // edge-projection parameter: reciprocal-refinement quotient instead of IEEE '/'
+#ifndef JR_TUNE_TV_DIVKNOWN      // edge-projection parameter: refinement quotient with the record's RN(1/Dn) instead of IEEE '/' (same bits).
+                                 // DEAD twice: +3 % with the reciprocal formed on the fly, +0.5 % / +1.2 % with it stored in the record
 #define JR_TUNE_TV_DIVKNOWN 0
 #endif
 #ifndef JR_TUNE_FWD_DIS_ONLY     // forward: carry only (sign, dis) out of the distance machinery
@@ -21,12 +22,6 @@
 #endif
 #ifndef JR_TUNE_FWD_INSIDE_RCP   // forward: 2nd / 3rd edge projection of INSIDE pixels (colour path only) by reciprocal multiply
 #define JR_TUNE_FWD_INSIDE_RCP 1
-#endif
-#ifndef JR_TUNE_INSIDE_SELECT    // both kernels: an inside pixel projects only the edge its weights name as nearest (softras_device.h:
-                                 // inside_edge_select).  Exact (2 x 10^7 pairs, 0 mismatches) but DEAD: 99 % of the inside pairs are decided,
-                                 // VALU instructions -2.4 % / -3.1 %, yet the forward is 5 % slower (sqrt -> min -> compare -> branch
-                                 // latency chain) and the backward 0.5 % faster (profiles/r02_ab_inside_select.log)
-#define JR_TUNE_INSIDE_SELECT 0
 #endif
 #ifndef JR_TUNE_FWD_TPW          // forward: tiles of a bin rendered by one wavefront, one after the other (1, 2, 4, 8, 16)
 #define JR_TUNE_FWD_TPW 1
@@ -59,10 +54,6 @@
 #define JR_TUNE_BWD_REDUCE_BANKMASK 0
 #endif
 
-#ifndef JR_TUNE_CHECK_INSIDE_SELECT // instrumented build: the backward also projects all three edges of every inside pair and counts
-#define JR_TUNE_CHECK_INSIDE_SELECT 0 // the pairs where inside_edge_select led to different bits (jr_debug_section_clocks slots 18, 19)
-#endif
-
 #ifndef JR_TUNE_PROFILE_SECTIONS  // instrumented build: per-section shader-clock totals of the raster kernels (tools/ablate)
 #define JR_TUNE_PROFILE_SECTIONS 0
 #endif
@@ -72,8 +63,6 @@ namespace tune {
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
 constexpr bool bwd_reduce_bankmask = JR_TUNE_BWD_REDUCE_BANKMASK != 0;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
-constexpr bool check_inside_select = JR_TUNE_CHECK_INSIDE_SELECT != 0;
-constexpr bool inside_select = JR_TUNE_INSIDE_SELECT != 0;
 constexpr bool tv_divknown = JR_TUNE_TV_DIVKNOWN != 0;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;

@@ -166,19 +166,6 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     else {
         // nothing is decided from the projection parameter here (sign and region come from the exact w)
         dd = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE)>(r, meta, w, xp, yp);
-        if (tune::check_inside_select && FAST && strictly_inside(w)) {
-            // instrumented build: the same pair with all three edges projected must give the same bits
-            const Dist full = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE), false>(r, meta, w, xp, yp);
-            const bool same = __builtin_bit_cast(int, full.dx) == __builtin_bit_cast(int, dd.dx) &&
-                              __builtin_bit_cast(int, full.dy) == __builtin_bit_cast(int, dd.dy) &&
-                              __builtin_bit_cast(int, full.t0) == __builtin_bit_cast(int, dd.t0) &&
-                              __builtin_bit_cast(int, full.t1) == __builtin_bit_cast(int, dd.t1) &&
-                              __builtin_bit_cast(int, full.t2) == __builtin_bit_cast(int, dd.t2);
-            atomicAdd(counters + 22, 1ull);
-            if (inside_edge_select(r, w) >= 0) atomicAdd(counters + 20, 1ull);
-            if (__builtin_amdgcn_ballot_w64(inside_edge_select(r, w) < 0) != 0ull) atomicAdd(counters + 21, 1ull);
-            if (!same) atomicAdd(counters + 23, 1ull);
-        }
         dis = dd.dx * dd.dx + dd.dy * dd.dy;
         D = coverage_fast(-dd.sign * dis, p);
     }

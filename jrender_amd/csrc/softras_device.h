@@ -61,11 +61,10 @@ struct FaceGeo {
     float inv[9];                  // face_inv                            (SRK:205-217)
     float z[3];
     float x0, y0, x1, y1, x2, y2;
-    float A[9];                    // A[e] = sym[e] - sym[e+1]            (SRK:77-79); the divisor of SRK:81 is
-                                   // A[e][e] - A[e][e+1], formed where it is used (one subtraction, same bits)
+    float A[9];                    // A[e] = sym[e] - sym[e+1]            (SRK:77-79)
+    float Dn[3];                   // A[e][e] - A[e][e+1]                 (SRK:81 denominator)
+    float rDn[3];                  // RN(1/Dn[e]): the projection parameter is a refinement quotient (edge_candidate)
     float rz[3];                   // RN(1/z[k])
-    float ss[3];                   // inside-edge selection (inside_edge_select): altitude of vertex k / (2 eta)
-    float sd[3];                   //   (bound of the foot displacement on the edge opposite vertex k / (2 eta))^2
     int meta;                      // face index inside its image | FLAG_* << 28 | (obtuse vertex + 1) << 30 (SRK:227-235)
     float col[3];                  // surface colour when T == 1
 };
@@ -136,7 +135,6 @@ __device__ inline void build_face_geo(FaceGeo& r, const float* __restrict__ f,
     r.z[0] = f[2]; r.z[1] = f[5]; r.z[2] = f[8];
     r.x0 = x0; r.y0 = y0; r.x1 = x1; r.y1 = y1; r.x2 = x2; r.y2 = y2;
     const float* sym = fi + 9;
-    float Dn[3];
 #pragma unroll
     for (int e = 0; e < 3; e++) {
         const int e1 = (e + 1) % 3;
@@ -145,9 +143,10 @@ __device__ inline void build_face_geo(FaceGeo& r, const float* __restrict__ f,
             r.A[3 * e + c] = sym[3 * e + c] - sym[3 * e1 + c];
             safe = safe && zero_or_in_fast_range(r.A[3 * e + c]);
         }
-        Dn[e] = r.A[3 * e + e] - r.A[3 * e + e1];
+        r.Dn[e] = r.A[3 * e + e] - r.A[3 * e + e1];
+        r.rDn[e] = 1.0f / r.Dn[e];
         r.rz[e] = 1.0f / r.z[e];
-        safe = safe && in_fast_range(Dn[e]) && in_fast_range(r.z[e]);
+        safe = safe && in_fast_range(r.Dn[e]) && in_fast_range(r.z[e]);
     }
     safe = safe && fabsf(x0) <= 1024.f && fabsf(y0) <= 1024.f && fabsf(x1) <= 1024.f &&
            fabsf(y1) <= 1024.f && fabsf(x2) <= 1024.f && fabsf(y2) <= 1024.f;
@@ -156,49 +155,6 @@ __device__ inline void build_face_geo(FaceGeo& r, const float* __restrict__ f,
     r.meta = id | (flags << META_ID_BITS) | ((obt + 1) << 30);
     r.col[0] = 0.f; r.col[1] = 0.f; r.col[2] = 0.f;
 
-    // Constants of inside_edge_select (model and constants: tools/sim/inside_edge.py, which replays the
-    // reference's float arithmetic against them).  eta bounds the rounding of the weights, of the offsets and of
-    // the projection parameter times the positions; dl[e] bounds how far the reference's foot point on edge e can
-    // slide ALONG the edge: the sym differences carry <= 16 EPS absolute error (slack) and the quotient divides by
-    // |edge|^2, with |tv| <= tvb for a point within 2^-10 |position| of the triangle.
-    {
-        constexpr float EPS = 5.9604645e-08f;     // 2^-24
-        const float X = fmaxf(fmaxf(fabsf(x0), fabsf(x1)), fabsf(x2)), Y = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fabsf(y2));
-        const float pos = sqrtf(X * X + Y * Y);
-        float h[3], Sh = 0.f, ch = 0.f, aD[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            h[k] = 1.0f / sqrtf(fi[3 * k] * fi[3 * k] + fi[3 * k + 1] * fi[3 * k + 1]);
-            const float S = (fabsf(fi[3 * k]) * X + fabsf(fi[3 * k + 1]) * Y) + fabsf(fi[3 * k + 2]);
-            Sh = fmaxf(Sh, S * h[k]);
-            ch = fmaxf(ch, fabsf(fi[3 * k + 2]) * h[k]);
-            aD[k] = fabsf(Dn[k]);
-        }
-        const float slack = 16.f * EPS;
-        const float L = sqrtf(fmaxf(fmaxf(aD[0], aD[1]), aD[2]) + slack) + 0.0009765625f * pos;
-        float dl[3], tvmax = 0.f;
-#pragma unroll
-        for (int e = 0; e < 3; e++) {
-            const float ehi = sqrtf(aD[e] + slack);
-            const float tvb = (ehi * L + slack) / aD[e] + 1.f;
-            tvmax = fmaxf(tvmax, tvb);
-            dl[e] = 12.f * EPS * (1.f + tvb) * ehi / aD[e];
-        }
-        const float eta = 32.f * EPS * ((Sh + pos) + ch) + 8.f * EPS * tvmax * pos;
-        const float r2e = 1.0f / (2.f * eta);
-        bool fin = true;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float d = dl[(k + 1) % 3] * r2e;          // the edge opposite vertex k is edge k + 1
-            r.ss[k] = h[k] * r2e;
-            r.sd[k] = d * d;
-            fin = fin && r.ss[k] > 0.f && r.ss[k] < 3.0e38f && r.sd[k] < 3.0e38f;   // NaN fails every comparison
-        }
-        if (!fin) {          // degenerate face: every edge is a candidate for every pixel -> all three are projected
-#pragma unroll
-            for (int k = 0; k < 3; k++) { r.ss[k] = 0.f; r.sd[k] = 0.f; }
-        }
-    }
 }
 
 // pixel centre in NDC: (2*i + 1 - IS) / IS evaluated in double, rounded once (SRK:280-283)
@@ -287,7 +243,7 @@ struct EdgeCand { float u0, u1, u2, ex, ey, dd; };
 // TV selects how the quotient of SRK:81 / :132 is formed:
 //   TV_IEEE   plain IEEE division (~50 cycles)
 //   TV_EXACT  the same bits from the reciprocal-refinement quotient: the divisor's correctly rounded
-//             reciprocal comes from recip_exact (FLAG_SAFE faces have Dn in its proven range), the numerator
+//             reciprocal travels with the record (FLAG_SAFE faces have Dn in the proven range), the numerator
 //             — which can be a rounding crumb when the pixel projects exactly onto a vertex — is checked
 //             against the refinement's guarantee domain (0 or 2^-80 <= |a| <= 2^60) and takes the IEEE
 //             division otherwise
@@ -304,12 +260,12 @@ __device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e
     const int e1 = e == 2 ? 0 : e + 1;
     const float a0 = r.A[3 * e], a1 = r.A[3 * e + 1], a2 = r.A[3 * e + 2];
     const float av1 = r.A[3 * e + e1];
-    const float dn = r.A[4 * e] - av1;                  // A[e][e] - A[e][e+1]: the divisor of SRK:81 / :132
+    const float dn = r.Dn[e];
     const float num = ((b.w0 * a0 + b.w1 * a1) + b.w2 * a2) - av1;                       // SRK:81 / :132
     float tv;
     if (FAST && TV == TV_RCP) tv = num * __builtin_amdgcn_rcpf(dn);
     else if (FAST && TV == TV_EXACT) {
-        tv = div_known<true>(num, dn, recip_exact(dn));
+        tv = div_known<true>(num, dn, r.rDn[e]);
         if (__builtin_expect(!in_refinement_domain(num), 0)) tv = num / dn;
     } else tv = num / dn;
     const float tn = 1 - tv;
@@ -361,70 +317,27 @@ __device__ inline bool strictly_inside_t(const Bary& b) {
     return strictly_inside(b);
 }
 
-// Which edge is nearest to an INSIDE pixel?  The reference projects the pixel onto all three edge lines and keeps
-// the nearest (SRK:68-105).  The nearest edge can be told from the weights alone — unless two edges are nearly
-// equidistant — so only that edge is projected (exactly, as before) and the other two projections (~45 VALU
-// each in the backward) are skipped.  Model of what the reference's float arithmetic measures, validated by
-// replaying that arithmetic (tools/sim/inside_edge.py: 10^7 pairs, sliver meshes included, >= 6x margin):
-//   * it measures from pixel' = sum_k w_k P_k, and its weights do not sum to 1 (ONE rounded det): with
-//     sm1 = sum w - 1 the weight of pixel' is wr_k = w_k - sm1 * inv[3k+2] (w_k is affine), so the distance to
-//     the line opposite vertex k is q_k = |wr_k| * altitude_k;
-//   * its foot point slides ALONG the edge by at most dl_k (error of the projection parameter): it reports
-//     sqrt(q_k^2 + d^2), d <= dl_k; everything else stays below eta.
-// Edge k is a candidate iff q_k - eta <= min_j sqrt(q_j^2 + dl_j^2) + eta; the record holds altitude_k / (2 eta)
-// and (dl_k / (2 eta))^2 (build_face_geo).  Returns the edge index when exactly ONE edge is a candidate (then it
-// IS the reference's argmin: every other edge is strictly farther), -1 otherwise (all three are projected).
-__device__ inline int inside_edge_select(const FaceGeo& r, const Bary& b) {
-    const float sm1 = ((b.w0 + b.w1) + b.w2) - 1.f;
-    const float q0 = fabsf(__builtin_fmaf(-sm1, r.inv[2], b.w0)) * r.ss[0];
-    const float q1 = fabsf(__builtin_fmaf(-sm1, r.inv[5], b.w1)) * r.ss[1];
-    const float q2 = fabsf(__builtin_fmaf(-sm1, r.inv[8], b.w2)) * r.ss[2];
-    const float r0 = __builtin_amdgcn_sqrtf(__builtin_fmaf(q0, q0, r.sd[0]));
-    const float r1 = __builtin_amdgcn_sqrtf(__builtin_fmaf(q1, q1, r.sd[1]));
-    const float r2 = __builtin_amdgcn_sqrtf(__builtin_fmaf(q2, q2, r.sd[2]));
-    const float lim = fminf(fminf(r0, r1), r2) + 1.f;
-    const bool c0 = q0 <= lim, c1 = q1 <= lim, c2 = q2 <= lim;         // NaN: no candidate -> -1
-    const bool one = (c0 != c1) != c2 && !(c0 && c1);                  // exactly one of the three
-    // the edge opposite vertex k is edge k + 1 (mod 3); an ill-conditioned pair (weights far from summing to 1:
-    // pixel' may lie far outside the triangle, the bound of the projection parameter no longer holds) -> -1
-    const int e = c0 ? 1 : (c1 ? 2 : 0);
-    return (one && fabsf(sm1) <= 0.0009765625f) ? e : -1;
-}
-
-// squared-distance machinery, euclidean mode (SRK:57-147).  The inside case (edge projections, keep the
-// nearest) and the outside case (one edge chosen from the sign pattern of w, clamped) share the first
-// projection so that a wavefront with both kinds of pixels does not execute two separate code paths; an inside
-// lane projects the edge inside_edge_select names, and the two further projections run only if some inside
-// lane could not be decided.
-template <bool FAST, int TV = (tune::tv_divknown ? TV_EXACT : TV_IEEE), bool SELECT = tune::inside_select>
+// squared-distance machinery, euclidean mode (SRK:57-147).  The inside case (three edge
+// projections, keep the nearest) and the outside case (one edge chosen from the sign pattern of
+// w, clamped) share the first projection so that a wavefront with both kinds of pixels does not
+// execute two separate code paths; the two further projections run only if some lane is inside.
+// (Projecting only the edge the weights name as nearest was built, proven exact and measured slower:
+// tools/ablate/patches/, profiles/r02_ab_inside_select.log.)
+template <bool FAST, int TV = (tune::tv_divknown ? TV_EXACT : TV_IEEE)>
 __device__ inline Dist euclidean_p2f(const FaceGeo& r, int meta, const Bary& b, float xp, float yp) {
     const bool inside = strictly_inside_t<FAST>(b);
     const int v0 = outside_edge(r, face_obtuse(meta), b, xp, yp);
-    int esel = -1;
-    if (FAST && SELECT && inside) esel = inside_edge_select(r, b);
     Dist d;
-    EdgeCand c = edge_candidate<FAST, TV>(r, b, inside ? (esel < 0 ? 0 : esel) : (v0 < 0 ? 0 : v0), !inside);
-    if (FAST && SELECT) {
-        // the named edge must qualify like the reference's candidates do (dis_min starts at 1e8, SRK:68); if it does
-        // not (practically never) the lane goes through all three.  The empty volatile asm keeps the compiler from
-        // flattening the branch into an unconditional fourth projection (the projection has no side effects).
-        const bool redo = inside && esel >= 0 && !(c.dd < 100000000.f);
-        if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-            asm volatile("; inside_edge_select: named edge does not qualify");
-            if (redo) { esel = -1; c = edge_candidate<FAST, TV>(r, b, 0, false); }
-        }
-    }
+    const EdgeCand c = edge_candidate<FAST, TV>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
     if (inside) {
         // SRK:68-105: dis_min starts at 1e8, strict '<' keeps the first of equal candidates
         float best = 100000000.f;
         d.dx = 0.f; d.dy = 0.f; d.t0 = 0.f; d.t1 = 0.f; d.t2 = 0.f;
         if (c.dd < best) { best = c.dd; d.dx = c.ex; d.dy = c.ey; d.t0 = c.u0; d.t1 = c.u1; d.t2 = c.u2; }
-        if (esel < 0) {                                   // undecided: c is edge 0, the other two follow
-            const EdgeCand c1 = edge_candidate<FAST, TV>(r, b, 1, false);
-            if (c1.dd < best) { best = c1.dd; d.dx = c1.ex; d.dy = c1.ey; d.t0 = c1.u0; d.t1 = c1.u1; d.t2 = c1.u2; }
-            const EdgeCand c2 = edge_candidate<FAST, TV>(r, b, 2, false);
-            if (c2.dd < best) { best = c2.dd; d.dx = c2.ex; d.dy = c2.ey; d.t0 = c2.u0; d.t1 = c2.u1; d.t2 = c2.u2; }
-        }
+        const EdgeCand c1 = edge_candidate<FAST, TV>(r, b, 1, false);
+        if (c1.dd < best) { best = c1.dd; d.dx = c1.ex; d.dy = c1.ey; d.t0 = c1.u0; d.t1 = c1.u1; d.t2 = c1.u2; }
+        const EdgeCand c2 = edge_candidate<FAST, TV>(r, b, 2, false);
+        if (c2.dd < best) { best = c2.dd; d.dx = c2.ex; d.dy = c2.ey; d.t0 = c2.u0; d.t1 = c2.u1; d.t2 = c2.u2; }
         d.sign = 1.f;
     } else if (v0 < 0) {
         // Reference indexes t[-1]/a0[-1] here (undefined behaviour; only reachable when some
@@ -439,33 +352,22 @@ __device__ inline Dist euclidean_p2f(const FaceGeo& r, int meta, const Bary& b, 
 // What the FORWARD needs of it: the sign and the squared distance dx*dx + dy*dy (SRK:341-342), which is
 // bit for bit the candidate's own dd = ex*ex + ey*ey; the nearest point and its barycentric offsets (six
 // selects per candidate) are only used by the backward.  An inside pixel is never culled by distance, so
-// its distance only feeds the coverage sigmoid (colour path, 1e-4): where all three edges have to be
-// projected, the 2nd and 3rd use a reciprocal multiply.
+// its three projections only feed the coverage sigmoid (colour path, 1e-4): the 2nd and 3rd use a
+// reciprocal multiply.
 template <bool FAST>
 __device__ inline void euclidean_sign_dis(const FaceGeo& r, int meta, const Bary& b, float xp, float yp, float& sign,
                                           float& dis) {
     const bool inside = strictly_inside_t<FAST>(b);
     const int v0 = outside_edge(r, face_obtuse(meta), b, xp, yp);
-    int esel = -1;
-    if (FAST && tune::inside_select && inside) esel = inside_edge_select(r, b);
-    EdgeCand c = edge_candidate<FAST>(r, b, inside ? (esel < 0 ? 0 : esel) : (v0 < 0 ? 0 : v0), !inside);
-    if (FAST && tune::inside_select) {                    // see euclidean_p2f
-        const bool redo = inside && esel >= 0 && !(c.dd < 100000000.f);
-        if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-            asm volatile("; inside_edge_select: named edge does not qualify");
-            if (redo) { esel = -1; c = edge_candidate<FAST>(r, b, 0, false); }
-        }
-    }
+    const EdgeCand c = edge_candidate<FAST>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
     if (inside) {
         float best = 100000000.f;                    // SRK:68: candidates that are not < 1e8 (NaN) leave dis = 0
         if (c.dd < best) best = c.dd;
-        if (esel < 0) {
-            constexpr int TVI = (tune::tv_divknown || tune::fwd_inside_rcp) ? TV_RCP : TV_IEEE;
-            const float d1 = edge_candidate<FAST, TVI>(r, b, 1, false).dd;
-            const float d2 = edge_candidate<FAST, TVI>(r, b, 2, false).dd;
-            if (d1 < best) best = d1;
-            if (d2 < best) best = d2;
-        }
+        constexpr int TVI = tune::fwd_inside_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE);
+        const float d1 = edge_candidate<FAST, TVI>(r, b, 1, false).dd;
+        const float d2 = edge_candidate<FAST, TVI>(r, b, 2, false).dd;
+        if (d1 < best) best = d1;
+        if (d2 < best) best = d2;
         sign = 1.f;
         dis = best < 100000000.f ? best : 0.f;
     } else {

@@ -9,7 +9,7 @@ VARIANTS = {
     "r1_occ4": OFF[:5] + OFF[6:],                            # + the 4-waves-per-SIMD request alone
     "no_prepass": ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_OCC4=0"],
     "no_dis": ["JR_TUNE_FWD_DIS_ONLY=0"],
-    "tv": ["JR_TUNE_TV_DIVKNOWN=1"],                         # dead: exact reciprocal-refinement quotient for tv
+    "tv": ["JR_TUNE_TV_DIVKNOWN=1"],                         # dead: refinement quotient with the stored reciprocal for tv (fwd +0.5 %, bwd +1.2 %)
     "ids_lds": ["JR_TUNE_FWD_IDS_LDS=1"],                    # dead at K <= 16: K-buffer ids in LDS
     "bigk_regs": ["JR_TUNE_FWD_IDS_LDS_BIGK=0"],             # K > 16 with ids in registers (round 1)
     "bwd_rcp": ["JR_TUNE_BWD_TV_RCP=1"],                     # dead: breaks the 1e-4 gradient bar
@@ -38,8 +38,6 @@ VARIANTS = {
     "fwd52": ["JR_TUNE_FWD_BATCH=52"],
     "kbuf_salu": ["JR_TUNE_FWD_KBUF_SALU=1"],
     "bankmask": ["JR_TUNE_BWD_REDUCE_BANKMASK=1"],          # dead (+2 % bwd): bank-masked DPP adds instead of selects — v_add_f32_dpp costs what v_cndmask costs
-    "select": ["JR_TUNE_INSIDE_SELECT=1"],                   # dead: inside pixels project only the edge their weights name (fwd +5 %, bwd -0.5 %)
-    "check_select": ["JR_TUNE_INSIDE_SELECT=1", "JR_TUNE_CHECK_INSIDE_SELECT=1"],       # instrumented: tools/ablate/check_select.py
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1"],              # instrumented: tools/ablate/sections.py
 }
