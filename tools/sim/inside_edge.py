@@ -2,9 +2,10 @@
 """Which edge is nearest to an INSIDE pixel?  (CPU; needs the oracle.)
 
 The reference projects an inside pixel onto all three edge LINES and keeps the nearest (SRK:68-105, strict '<',
-first edge wins ties).  The kernels SELECT the edge worth projecting (softras_device.h: inside_edge_select) from
-a geometric model of what the reference's float arithmetic computes, and fall back to all three projections when
-the model cannot separate the edges:
+first edge wins ties).  Round-2 EXPERIMENT (tools/ablate/patches/inside_edge_select_fe5fc2b.patch, not in the
+product: exact but slower, profiles/r02_ab_inside_select.log): SELECT the edge worth projecting from a geometric
+model of what the reference's float arithmetic computes, and fall back to all three projections when the model
+cannot separate the edges:
 
   * the reference measures from pixel' = sum_k w_k P_k (SRK:87-92: u = t - w, offset = sum u_k P_k), and its weights
     do not sum to one (face_inv is star / det with ONE rounded det): with sm1 = ((w0 + w1) + w2) - 1 the weight of
@@ -14,7 +15,7 @@ the model cannot separate the edges:
     face_sym = x x' + y y' + 1 carry ~4 EPS absolute error, the quotient divides by |edge|^2): the reference's
     distance is sqrt(q_k^2 + d^2) with  d <= dl_k = 32 EPS (2 + sqrt(Dmax / Dn_e)) / sqrt(Dn_e)  (second order!);
   * everything else (rounding of w, of the offsets) stays below  eta = 32 EPS (max_k S_k h_k + pos + max_k |c_k| h_k).
-Edge k is a CANDIDATE iff  q_k - eta <= min_j sqrt(q_j^2 + dl_j^2) + eta.  The record stores s_k = h_k / (2 eta) and
+Edge k is a CANDIDATE iff  q_k - eta <= min_j sqrt(q_j^2 + dl_j^2) + eta.  The record stored s_k = h_k / (2 eta) and
 (dl_k / (2 eta))^2, so the test is  q~_k <= min_j sqrt(q~_j^2 + dl~_j^2) + 1  (3 sqrt per pair, no division).
 
 This tool replays the reference's float32 arithmetic (association order of SRK:73-92) on sampled inside pairs:
