@@ -35,6 +35,9 @@
 #ifndef JR_TUNE_FWD_KBUF_SALU    // forward: K-buffer slot masks from 4 bit ballots + scalar logic instead of 16 v_cmp
 #define JR_TUNE_FWD_KBUF_SALU 0
 #endif
+#ifndef JR_TUNE_FWD_IDS_GLOBAL   // forward, K <= 16: K-buffer ids are stored straight into faces_id_buffer at every insert instead of living in registers
+#define JR_TUNE_FWD_IDS_GLOBAL 1
+#endif
 #ifndef JR_TUNE_FWD_OCC4         // forward: ask the register allocator for 4 wavefronts per SIMD at K <= 16 (128 VGPRs)
 #define JR_TUNE_FWD_OCC4 1
 #endif
@@ -71,6 +74,7 @@ constexpr bool fwd_ids_lds_bigk = JR_TUNE_FWD_IDS_LDS_BIGK != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
 constexpr int fwd_tiles_per_wave = JR_TUNE_FWD_TPW;
 constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
+constexpr bool fwd_ids_global = JR_TUNE_FWD_IDS_GLOBAL != 0;
 constexpr bool fwd_kbuf_salu = JR_TUNE_FWD_KBUF_SALU != 0;
 constexpr bool fwd_tile_boxtest = JR_TUNE_FWD_TILE_BOXTEST != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;

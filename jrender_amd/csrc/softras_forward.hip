@@ -37,11 +37,21 @@ namespace jr {
 // ds_write per insert instead of KCAP selects) and only the depths stay in registers (KCAP = 64: 130 VGPRs).
 template <int KCAP>
 constexpr bool ids_in_lds() { return tune::fwd_ids_lds || (KCAP > 16 && tune::fwd_ids_lds_bigk); }
+// K <= 16: the ids do not live in registers at all — every insert stores the face index straight into its slot
+// plane of faces_id_buffer (the output), the slots that were never filled get their -1 at the end.  Same-address
+// stores of one wavefront complete in program order, so the plane ends up with the slot's LAST face, exactly what
+// the register K-buffer held.  (In registers the ids cost 16 v_cndmask per insert AND — being live beyond the
+// divergent raster loop — a second register set with 16 v_mov to copy them back: seen in the ISA.)
+template <int KCAP>
+constexpr bool ids_in_global() { return tune::fwd_ids_global && KCAP == 16 && !ids_in_lds<KCAP>(); }
 
 template <int KCAP>
 struct KBuffer {
     static constexpr bool IDS_LDS = ids_in_lds<KCAP>();
-    int id[IDS_LDS ? 1 : KCAP];
+    static constexpr bool IDS_GLOBAL = ids_in_global<KCAP>();
+    int id[(IDS_LDS || IDS_GLOBAL) ? 1 : KCAP];
+    int32_t* gplane;               // IDS_GLOBAL: slot plane 0 of this pixel's image in faces_id_buffer
+    unsigned goff, gstride;        //             element offset of the pixel, elements per slot plane
     float z[KCAP];
     int size;
     float max_z;
@@ -50,17 +60,19 @@ struct KBuffer {
 
     // Slots >= K are never written; their depth is -inf so that the rescan (which starts from -1) can
     // run over all KCAP registers without a per-slot "k < K" predicate (16 SGPR pairs otherwise).
-    __device__ inline void init(int K, int* ids_column) {
+    __device__ inline void init(int K, int* ids_column, int32_t* plane0 = nullptr, unsigned pixel = 0u, unsigned stride = 0u) {
         lds_ids = ids_column;
+        gplane = plane0; goff = pixel; gstride = stride;
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
-            if (!IDS_LDS) id[k] = -1;
+            if (IDS_GLOBAL) { if (k == 0) id[0] = -1; }
+            else if (!IDS_LDS) id[k] = -1;
             else if (k < K) lds_ids[k * 64] = -1;
             z[k] = k < K ? 0.f : -__builtin_inff();
         }
         size = 0; max_z = -1.f; max_slot = -1;
     }
-    __device__ inline int id_of(int k) const { return IDS_LDS ? lds_ids[k * 64] : id[k]; }
+    __device__ inline int id_of(int k) const { return IDS_LDS ? lds_ids[k * 64] : id[IDS_GLOBAL ? 0 : k]; }
     // K-nearest insert with the reference's slot semantics (SRK:369-385): append while not
     // full (tracking the first largest depth), afterwards overwrite the largest-depth slot
     // when strictly nearer and rescan, first maximum wins.
@@ -69,6 +81,7 @@ struct KBuffer {
         if (!filling && !(zp < max_z)) return;
         const int slot = filling ? size : max_slot;
         if (IDS_LDS) lds_ids[slot * 64] = fn;
+        if (IDS_GLOBAL) gplane[(unsigned)slot * gstride + goff] = fn;
         if (tune::fwd_kbuf_salu && KCAP == 16) {
             // The 16 "slot == k" masks from 4 bit ballots and scalar and / andn2 (SALU, issued beside the vector
             // pipe) instead of 16 v_cmp: v_cmp and v_cndmask are half-rate on gfx950 (tools/ubench/valu_rates2).
@@ -79,14 +92,14 @@ struct KBuffer {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const unsigned long long m = lo[k & 3] & hi[k >> 2];
-                if (!IDS_LDS) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(id[k]) : "v"(fn), "s"(m));
+                if (!IDS_LDS && !IDS_GLOBAL) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(id[k]) : "v"(fn), "s"(m));
                 asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(z[k]) : "v"(zp), "s"(m));
             }
         } else {
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             const bool hit = k == slot;
-            if (!IDS_LDS) id[k] = hit ? fn : id[k];
+            if (!IDS_LDS && !IDS_GLOBAL) id[k] = hit ? fn : id[k];
             z[k] = hit ? zp : z[k];
         }
         }
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     else if (RGB == 1) { s.c0 = p.bg[0] * s.ssum; s.c1 = p.bg[1] * s.ssum; s.c2 = p.bg[2] * s.ssum; }
     s.depth_min = 10000000.f;
     s.face_min = -1;
-    s.q.init(p.K, s_ids + lane);
+    s.q.init(p.K, s_ids + lane, ids + (size_t)b * p.K * p.IS * p.IS, valid ? (unsigned)(row * p.IS + col) : 0u, (unsigned)(p.IS * p.IS));
 
     const unsigned long long* seg = pool + bin_base[bin];
     const FaceGeo* gbase = geo + (size_t)b * p.NF;
@@ -467,7 +480,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     int32_t* io = ids + (size_t)b * p.K * pp + pn;
 #pragma unroll
     for (int k = 0; k < KCAP; k++)
-        if (k < p.K) io[(size_t)k * pp] = s.q.id_of(k);
+        if (k < p.K) {
+            if (!ids_in_global<KCAP>()) io[(size_t)k * pp] = s.q.id_of(k);
+            else if (k >= s.q.size) io[(size_t)k * pp] = -1;         // the filled slots were stored when they were filled
+        }
     clk.lap(4);
     }   // tiles of this wavefront
     clk.flush(counters, 4);

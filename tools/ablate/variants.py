@@ -36,6 +36,8 @@ VARIANTS = {
     "bwd48w5": ["JR_TUNE_BWD_BATCH=48", "JR_TUNE_BWD_WAVES=5"],
     "fwd44w5": ["JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_OCC4=5"],
     "fwd52": ["JR_TUNE_FWD_BATCH=52"],
+    "ids_regs": ["JR_TUNE_FWD_IDS_GLOBAL=0"],                # K-buffer ids in registers (round-2 start)
+    "fwd44w5g": ["JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_OCC4=5"],  # with the ids out of the registers: 96 VGPRs, 20 B of scratch outside the trip loop
     "kbuf_salu": ["JR_TUNE_FWD_KBUF_SALU=1"],
     "bankmask": ["JR_TUNE_BWD_REDUCE_BANKMASK=1"],          # dead (+2 % bwd): bank-masked DPP adds instead of selects — v_add_f32_dpp costs what v_cndmask costs
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
