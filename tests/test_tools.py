@@ -1,0 +1,44 @@
+"""Consistency of the measurement tooling with the sources it drives (CPU only)."""
+import importlib.util
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_ablation_variants_name_existing_switches():
+    """Every -D of tools/ablate/variants.py is a switch csrc/jr_tuning.h declares (a renamed or removed switch
+    would silently build the product again and report a bogus A/B)."""
+    tuning = open(os.path.join(ROOT, "jrender_amd", "csrc", "jr_tuning.h")).read()
+    declared = set(re.findall(r"#ifndef (JR_TUNE_[A-Z0-9_]+)", tuning))
+    variants = _load(os.path.join(ROOT, "tools", "ablate", "variants.py"), "variants").VARIANTS
+    assert "product" in variants and variants["product"] == []
+    for name, defines in variants.items():
+        for d in defines:
+            key, _, val = d.partition("=")
+            assert key in declared, "variant %r uses %s, which jr_tuning.h does not declare" % (name, key)
+            assert val.lstrip("-").isdigit(), d
+    # and every declared switch is used by the kernels (no orphan defaults)
+    csrc = "".join(open(os.path.join(ROOT, "jrender_amd", "csrc", f)).read()
+                   for f in os.listdir(os.path.join(ROOT, "jrender_amd", "csrc")) if f.endswith((".hip", ".h")))
+    for key in declared:
+        assert len(re.findall(key, csrc)) >= 2, "%s is declared but never used" % key
+
+
+def test_profile_jsons_feed_the_bench_line():
+    """profiles/*_latest.json carry the keys bench.py looks up (a missing key prints `null` in the driver's line)."""
+    valu = json.load(open(os.path.join(ROOT, "profiles", "valu_latest.json")))
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    n3 = json.load(open(os.path.join(ROOT, "profiles", "traffic_n3mr_latest.json")))
+    for k in ("fwd_raster", "bwd_raster"):
+        assert {"busy", "lane_util", "valu_insts_per_launch", "source"} <= set(valu[k])
+        assert k in traffic
+    assert traffic["bwd_raster"] > 5e8 and n3["fwd"] > 1e8 and n3["bwd"] > 1e9
