@@ -25,7 +25,12 @@ HIP-event brackets on the context stream in a SECOND pass of K steps (so that th
 inside the headline timing) against the 8 TB/s HBM peak; the line also says what actually binds
 (VALU issue, from the committed PMC pass in profiles/).  `cpu_baseline` times the CPU oracle
 (reference kernels compiled for the host when oracle/_ref exists, else the C port) on a bounded
-sample — the only place the oracle is touched, never the measured path.
+sample — the only place the oracle is touched, never the measured path.  The oracle view rendered for that baseline is
+ALSO the parity check of the line: the GPU renders the same view at the same size with the same upstream gradient and
+`parity` reports the index-buffer match fraction (must be 1.0) and the RGBA / grad_faces / vertex-gradient errors,
+SURVEY.md §8(d)'s element-wise formula next to the max-normalised one.  `latency_ms_b1` is fwd+bwd of ONE 39k-face
+image (BASELINE's "ms @1024^2, 39k faces"); `secondary` carries the NMR workload (configs[4]) and the random-triangle
+scene, all measured AFTER the timed region.
 """
 import argparse
 import json
@@ -66,20 +71,25 @@ def n3mr_algorithmic_bytes(B, NF, TS, IS):
 
 
 def cpu_baseline(NF, K, budget_s=20.0):
-    """Oracle fwd+bwd on a bounded sample of the same workload, all host cores; images/s at 1024^2."""
+    """Oracle fwd+bwd on a bounded sample of the same workload, all host cores; images/s at 1024^2.
+    -> (baseline dict, sample) with sample = the largest oracle view rendered (inputs, outputs, upstream gradient,
+    gradients) for the parity check of the line."""
     from oracle import Oracle, have_ref
     from jrender_amd import synthetic as syn
     kind = "reference" if have_ref() else "port"
     orc = Oracle(kind, nthreads=0)
     cores = orc.num_procs()
     fv, tex = syn.sphere_views(NF, 1)
+    last = {}
 
     def run(IS):
+        g = np.random.default_rng(11).uniform(-1, 1, (1, 4, IS, IS)).astype(np.float32)
         t0 = time.perf_counter()
         a = orc.forward(fv, tex, image_size=IS, max_faces_per_pixel_for_grad=K)
-        g = np.ones_like(a["soft_colors"])
-        orc.backward(a, g, nthreads=cores)
-        return time.perf_counter() - t0
+        gf, gt = orc.backward(a, g, nthreads=cores)
+        t = time.perf_counter() - t0
+        last.update(IS=IS, fv=fv, tex=tex, saved=a, g=g, grad_faces=gf, grad_textures=gt)
+        return t
 
     run(32)                                         # thread-pool / page-cache warm-up, not timed
     IS, t = 128, run(128)                           # cost is O(pixels x faces): grow while 4x still fits
@@ -89,7 +99,48 @@ def cpu_baseline(NF, K, budget_s=20.0):
     ips = 1.0 / (t * (1024.0 / IS) ** 2)
     return {"value": ips, "unit": "images/s", "cores": int(cores), "kind": kind,
             "sample": "1 view of the %d-face sphere at %dx%d fwd+bwd in %.1f s on %d threads, "
-                      "scaled by pixel count to 1024x1024" % (NF, IS, IS, t, cores)}
+                      "scaled by pixel count to 1024x1024" % (NF, IS, IS, t, cores)}, last
+
+
+def err_metrics(ours, ref):
+    """max of |a-b| / (|b| + 1e-6 max|b|) — and, because float atomics make the gradient sums order
+    dependent (in the reference too), the same with a 1e-3 floor and the max-normalised error the tests gate on."""
+    a, b = np.asarray(ours, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    fin = np.isfinite(b)
+    if not fin.any():
+        return {"max_norm": None, "rel_floor_1e-6": None, "rel_floor_1e-3": None}
+    m = float(np.abs(b[fin]).max()) or 1.0
+    d = np.abs(a - b)[fin]
+    bb = np.abs(b[fin])
+    return {"max_norm": float(d.max() / m), "rel_floor_1e-6": float((d / (bb + 1e-6 * m)).max()),
+            "rel_floor_1e-3": float((d / (bb + 1e-3 * m)).max()),
+            "nonfinite_mismatch": int((np.isfinite(np.asarray(ours, np.float64).ravel()) != fin).sum())}
+
+
+def parity_vs_sample(ctx, sample, K, mesh_faces, NV):
+    """The GPU path on the oracle's view: same inputs, same size, same upstream gradient."""
+    from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
+    from jrender_amd.structures.mesh import face_vertices_backward
+    IS, a = sample["IS"], sample["saved"]
+    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+    img = fn.execute(ctx.array(sample["fv"]), ctx.array(sample["tex"]))
+    gf, gt = fn.grad(ctx.array(sample["g"]))
+    ids = fn.save_vars[5].numpy()
+    fb = np.asarray(mesh_faces, np.int64).reshape(1, -1, 3)
+    gv = lambda g: face_vertices_backward(np.asarray(g, np.float32).reshape(1, -1, 3, 3), fb, NV)
+    covered = a["faces_id_buffer"][:, 0] >= 0
+    return {"view": "oracle view 0 at %dx%d (%s), the whole image" % (IS, IS, "same size as the timed batch" if IS == 1024 else "reduced: CPU budget"),
+            "ids_match_frac": float((ids == a["faces_id_buffer"]).all(axis=1).mean()),
+            "ids_mismatching_pixels": int((~(ids == a["faces_id_buffer"]).all(axis=1)).sum()),
+            "covered_pixel_frac": float(covered.mean()),
+            "faces_info_bit_exact": bool((fn.save_vars[3].numpy().view(np.uint32) == a["faces_info"].view(np.uint32)).all()),
+            "rgba_err": err_metrics(img.numpy(), a["soft_colors"]),
+            "aggrs_err": err_metrics(fn.save_vars[4].numpy(), a["aggrs_info"]),
+            "grad_faces_err": err_metrics(gf.numpy(), sample["grad_faces"]),
+            "grad_textures_err": err_metrics(gt.numpy(), sample["grad_textures"]),
+            "vertex_grad_err": err_metrics(gv(gf.numpy()), gv(sample["grad_faces"])),
+            "formula": "max |a-b| / (|b| + floor * max|b|): rel_floor_1e-6 is SURVEY 8(d)'s metric, max_norm = max|a-b| / max|b| "
+                       "is what tests/ gate at 1e-4; gradients are float-atomic sums in the reference too"}
 
 
 def n3mr_cpu_baseline(faces_h, tex_h, IS_full, budget_s=25.0):
@@ -147,13 +198,13 @@ def load_json(name):
         return None
 
 
-def bench_n3mr(args, ctx, comm, rank, world):
-    """Secondary workload (BASELINE.json configs[4]): NMR hard raster + approximate gradients,
-    39k-face sphere with fill_back (78k faces), 1024x1024, B=1, fwd+bwd on one GPU."""
+def measure_n3mr(ctx, comm, nfaces, IS, steps, warmup):
+    """NMR hard raster + approximate gradients (BASELINE.json configs[4]): nfaces-sphere with fill_back (x2 faces),
+    IS x IS, B=1, rgb+alpha+depth, fwd+bwd on one GPU -> dict of timings and the host copies the CPU baseline needs."""
     import jrender_amd as jr
     from jrender_amd.renderer.dr.n3mr import RasterizeFunction
-    IS, B, ts = args.image_size, 1, 2
-    v, f = jr.synthetic.sphere_mesh(args.faces)
+    B, ts = 1, 2
+    v, f = jr.synthetic.sphere_mesh(nfaces)
     eye = np.asarray(jr.get_points_from_angles(2.732, 30., 0.), np.float32)
     ndc = jr.perspective(jr.look_at(v[None], eye), 30.)
     ff = np.concatenate([f, f[:, ::-1]])
@@ -169,37 +220,93 @@ def bench_n3mr(args, ctx, comm, rank, world):
     def step():
         fn.execute(faces, tex)
         fn.grad(g_rgb, g_a, g_d)
-    elapsed, per_step = timed_steps(ctx, comm, step, args.steps, args.warmup)
+    elapsed, per_step = timed_steps(ctx, comm, step, steps, warmup)
     # forward / backward halves with events (second pass)
     e = [ctx.event() for _ in range(3)]
     fwd_ms, bwd_ms = [], []
-    for _ in range(min(args.steps, 20)):
+    for _ in range(min(steps, 20)):
         ctx.record(e[0]); fn.execute(faces, tex); ctx.record(e[1]); fn.grad(g_rgb, g_a, g_d); ctx.record(e[2])
         fwd_ms.append(ctx.elapsed_ms(e[0], e[1])); bwd_ms.append(ctx.elapsed_ms(e[1], e[2]))
-    if rank != 0:
-        return
-    ms = elapsed / args.steps * 1e3
+    ms = elapsed / steps * 1e3
     NF2 = ff.shape[0]
     ab = n3mr_algorithmic_bytes(B, NF2, ts, IS)
     dom, dom_ms = ("bwd", float(np.mean(bwd_ms))) if np.mean(bwd_ms) >= np.mean(fwd_ms) else ("fwd", float(np.mean(fwd_ms)))
     achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
     traffic = (load_json("traffic_n3mr_latest.json") or {}).get(dom) if (NF2, IS) == (78000, 1024) else None
+    return {"ms": ms, "per_step": per_step, "NF2": NF2, "ts": ts, "faces_h": faces_h, "tex_h": tex_h,
+            "roofline": {"bound": "hbm", "kernel": "n3mr %s kernels (events around jr_n3mr_%s)" % (dom, "backward" if dom == "bwd" else "forward"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms,
+                         "step_frac": ab["step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "phase_ms_per_step": {"forward": float(np.mean(fwd_ms)), "backward": float(np.mean(bwd_ms))}}
+
+
+def bench_n3mr(args, ctx, comm, rank, world):
+    """`--workload n3mr`: the NMR line on its own (the headline line carries it under `secondary`)."""
+    IS = args.image_size
+    m = measure_n3mr(ctx, comm, args.faces, IS, args.steps, args.warmup)
+    if rank != 0:
+        return
     out = {"metric": "NMR fwd+bwd ms @%dx%d, %d faces (fill_back x2)" % (IS, IS, args.faces),
-           "value": ms, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": ms, "step_ms": percentiles(per_step), "higher_is_better": False, "scaling": "weak",
+           "value": m["ms"], "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": m["ms"], "step_ms": percentiles(m["per_step"]), "higher_is_better": False, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "n3mr rgb+alpha+depth, %d faces, %dx%d, texture_size %d, batch 1" % (NF2, IS, IS, ts)},
-           "roofline": {"bound": "hbm", "kernel": "n3mr %s kernels (events around jr_n3mr_%s)" % (dom, "backward" if dom == "bwd" else "forward"),
-                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms,
-                        "step_frac": ab["step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "phase_ms_per_step": {"forward": float(np.mean(fwd_ms)), "backward": float(np.mean(bwd_ms))}}
+           "config": {"workload": "n3mr rgb+alpha+depth, %d faces, %dx%d, texture_size %d, batch 1" % (m["NF2"], IS, IS, m["ts"])},
+           "roofline": m["roofline"], "phase_ms_per_step": m["phase_ms_per_step"]}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = n3mr_cpu_baseline(faces_h, tex_h, IS)
+            out["cpu_baseline"] = n3mr_cpu_baseline(m["faces_h"], m["tex_h"], IS)
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     print(json.dumps(out), flush=True)
+
+
+def fwd_bwd_ms(ctx, comm, fv_h, tex_h, IS, K, steps=30, warmup=5, seed=3):
+    """fwd+bwd of one device-resident batch: median ms per step and the per-phase brackets."""
+    from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
+    fv, tex = ctx.array(fv_h), ctx.array(tex_h)
+    grad = ctx.array(np.random.default_rng(seed).uniform(-1, 1, (fv_h.shape[0], 4, IS, IS)).astype(np.float32))
+    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+
+    def step():
+        fn.execute(fv, tex)
+        fn.grad(grad)
+    _elapsed, per_step = timed_steps(ctx, comm, step, steps, warmup)
+    ctx.profile_enable(True)
+    ctx.profile_collect()
+    for _ in range(10):
+        step()
+    ctx.synchronize()
+    phases = ctx.profile_collect()
+    ctx.profile_enable(False)
+    return percentiles(per_step), {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()}
+
+
+def secondary_lines(args, ctx, comm):
+    """What the driver's plain `bench.py` run should also put on the record (measured after the timed region):
+    the single-image latency, larger K, the random-triangle scene and the NMR path."""
+    from jrender_amd import synthetic as syn
+    NF, IS, K = args.faces, args.image_size, args.K
+    out = {}
+    fv1, tex1 = syn.sphere_views(NF, 1)
+    st, ph = fwd_bwd_ms(ctx, comm, fv1, tex1, IS, K)
+    out["b1"] = {"workload": "ONE %d-face sphere view %dx%d fwd+bwd, K=%d" % (NF, IS, IS, K), "ms": st, "phase_ms": ph}
+    fv8, tex8 = syn.sphere_views(NF, args.batch)
+    for k2 in (32, 64):
+        st, ph = fwd_bwd_ms(ctx, comm, fv8, tex8, IS, k2, steps=10, warmup=2)
+        ab = algorithmic_bytes(args.batch, NF, 1, IS, k2)
+        out["K%d" % k2] = {"workload": "the headline batch with max_faces_per_pixel_for_grad=%d" % k2, "ms": st, "phase_ms": ph,
+                           "step_frac": ab["step"] / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    fvs, texs = syn.triangle_soup(NF, args.batch, seed=100)
+    st, ph = fwd_bwd_ms(ctx, comm, fvs, texs, IS, K, steps=20, warmup=3)
+    ab = algorithmic_bytes(args.batch, NF, 1, IS, K)
+    out["soup"] = {"workload": "random-triangle soup %d faces x %d views, %dx%d (north_star's random-triangle batches)" % (NF, args.batch, IS, IS),
+                   "ms": st, "images_per_s": args.batch / (st["median"] * 1e-3), "phase_ms": ph,
+                   "step_frac": ab["step"] / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    m = measure_n3mr(ctx, comm, NF, IS, 20, 3)
+    out["n3mr"] = {"workload": "NMR rgb+alpha+depth fwd+bwd, %d faces (fill_back x2), %dx%d, batch 1 (BASELINE configs[4])" % (m["NF2"], IS, IS),
+                   "ms": percentiles(m["per_step"]), "phase_ms": m["phase_ms_per_step"], "roofline": m["roofline"]}
+    return out
 
 
 def bench_softras(args, ctx, comm, rank, world):
@@ -298,37 +405,104 @@ def bench_softras(args, ctx, comm, rank, world):
         "exchange": {"kind": exchange, "backend": comm.backend, "ms_per_step": percentiles(ex_ms)["median"] if ex_ms else 0.0},
         "tile_stats": ctx.last_stats(),
     }
+    out["rccl_ranks"] = comm.size if comm.backend == "rccl" else None     # what RCCL itself reports (jr_comm_size)
+    if world == 1 and not args.no_secondary:
+        try:
+            sec = secondary_lines(args, ctx, comm)
+            out["latency_ms_b1"] = sec["b1"]["ms"]["median"]
+            out["secondary"] = sec
+        except Exception as e:                      # never break the headline line
+            out["secondary"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(NF, K)
+            out["cpu_baseline"], sample = cpu_baseline(NF, K)
+            if args.scene == "sphere":
+                out["parity"] = parity_vs_sample(ctx, sample, K, mesh_faces, NV)
         except Exception as e:                      # the baseline must never break the bench line
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
     print(json.dumps(out), flush=True)
 
 
-def launch_ranks(n, argv):
-    """`python bench.py --gpus N` outside any launcher: start N ranks of this script (one process per
-    GPU), rendezvous through a private directory, relay rank 0's JSON line."""
+def launch_ranks(n, argv, timeout_s=1500.0):
+    """`python bench.py --gpus N` outside any launcher: start N ranks of this script (one process per GPU, each its
+    own process group), rendezvous through a private 0700 directory, relay rank 0's JSON line.  ALL children are
+    polled: if any rank exits non-zero (or the whole launch exceeds timeout_s) before the others are done, the rest
+    is killed and the launcher exits non-zero with the tail of the failing rank's stderr (every rank's stderr goes
+    to a file in the rendezvous directory) - a rank that dies before ncclCommInitRank completes must not leave rank 0
+    waiting for ever."""
+    import signal
     rdzv = tempfile.mkdtemp(prefix="jrender_bench_")
-    procs = []
+    procs, logs = [], []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the MI355X host driver of this pool only supports dmabuf IPC; RCCL's
+        # cross-process buffer registration fails with `hipIpcGetMemHandle: invalid argument` without it.  An
+        # explicit setting in the caller's environment wins.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    JRENDER_RDZV=os.path.join(rdzv, "rdzv"), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = open(os.path.join(rdzv, "rank%d.out" % r), "w+b")
+        err = open(os.path.join(rdzv, "rank%d.err" % r), "w+b")
+        logs.append((out, err))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+                                      stdout=out, stderr=err, start_new_session=True))
+
+    def tail(f, nbytes=3000):
+        f.flush(); f.seek(0, 2); size = f.tell(); f.seek(max(0, size - nbytes))
+        return f.read().decode(errors="replace")
+
+    def kill_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)       # the rank's own process group (start_new_session)
+                except OSError:
+                    pass
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except Exception:
+                pass
+
+    failure, t0 = None, time.time()
+    while failure is None and any(q.poll() is None for q in procs):
+        for r, q in enumerate(procs):
+            rc = q.poll()
+            if rc not in (None, 0):
+                failure = "rank %d exited with code %d" % (r, rc)
+                break
+        else:
+            if time.time() - t0 > timeout_s:
+                failure = "launch exceeded %.0f s" % timeout_s
+            else:
+                time.sleep(0.05)
+    if failure is None:
+        bad = [(r, q.returncode) for r, q in enumerate(procs) if q.returncode]
+        if bad:
+            failure = "rank %d exited with code %d" % bad[0]
+    if failure is not None:
+        kill_all()
+        sys.stderr.write("bench.py: %s; exit codes %s\n" % (failure, [q.returncode for q in procs]))
+        for r, (_o, e) in enumerate(logs):
+            t = tail(e).strip()
+            if t:
+                sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, t))
+    else:
+        sys.stdout.write(tail(logs[0][0], 1 << 20))
+        sys.stdout.flush()
+        for r, (_o, e) in enumerate(logs):                 # warnings of healthy ranks stay visible
+            t = tail(e).strip()
+            if t:
+                sys.stderr.write("---- rank %d stderr ----\n%s\n" % (r, t))
+    for o, e in logs:
+        o.close(); e.close()
     try:
         for f in os.listdir(rdzv):
             os.unlink(os.path.join(rdzv, f))
         os.rmdir(rdzv)
     except OSError:
         pass
-    if any(rcs):
-        sys.exit("bench.py: rank exit codes %s" % rcs)
+    if failure is not None:
+        sys.exit(1)
 
 
 def main():
@@ -346,7 +520,8 @@ def main():
     ap.add_argument("--K", type=int, default=16)
     ap.add_argument("--exchange", default=None, choices=["none", "allreduce_vertex_grads", "allgather_images"],
                     help="exchange step at the end of every step (default: allreduce_vertex_grads when N > 1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline + parity)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip latency_ms_b1 / secondary (K=32, K=64, soup, NMR)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

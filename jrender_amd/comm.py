@@ -30,16 +30,33 @@ __all__ = ["SingleCommunicator", "RcclCommunicator", "HostCommunicator", "init_f
            "rendezvous_path"]
 
 ID_BYTES = 128
-_AUTH = b"jrender_amd.comm"
 
 
 def rendezvous_path():
-    """File-system rendezvous prefix shared by the ranks of ONE launch on this node."""
+    """File-system rendezvous prefix shared by the ranks of ONE launch on this node.
+
+    ``bench.py --gpus N`` / ``examples/demo2_deform.py --gpus N`` hand every rank a private 0700 directory
+    (JRENDER_RDZV).  Under ``torch.distributed.run`` the prefix is built from what all workers of ONE attempt share
+    and no other attempt does: the agent's pid (their parent), MASTER_PORT, TORCHELASTIC_RUN_ID and
+    TORCHELASTIC_RESTART_COUNT - a restarted worker group gets a fresh name, so a file left by the crashed attempt is
+    never read - inside a per-user 0700 directory."""
     p = os.environ.get("JRENDER_RDZV")
     if p:
         return p
-    # torch.distributed.run: every worker has the same parent (the agent) and the same MASTER_PORT
-    return os.path.join(tempfile.gettempdir(), "jrender_rdzv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+    d = os.path.join(tempfile.gettempdir(), "jrender_rdzv_u%d" % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("rendezvous directory %s is not private to this user" % d)
+    run = "".join(ch if ch.isalnum() else "_" for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none"))[:48]
+    return os.path.join(d, "%s_%s_r%s_%d" % (os.environ.get("MASTER_PORT", "0"), run,
+                                             os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid()))
+
+
+def _authkey(path):
+    """HostCommunicator connections are authenticated with a key derived from the (private) rendezvous path."""
+    import hashlib
+    return hashlib.sha256(b"jrender_amd.comm:" + os.fsencode(path)).digest()
 
 
 def _wait_for(path, timeout):
@@ -59,6 +76,10 @@ def _publish(path, data):
 
 class _Base:
     rank, world = 0, 1
+
+    @property
+    def size(self):
+        return self.world
 
     def bounds(self, batch):
         from .parallel import shard_bounds
@@ -113,12 +134,20 @@ class RcclCommunicator(_Base):
         h = C.c_void_p()
         _ffi._check(lib.jr_comm_create(ctx.handle, buf, self.world, self.rank, C.byref(h)))   # collective
         self.handle = h
+        if int(lib.jr_comm_size(h)) != self.world or int(lib.jr_comm_rank(h)) != self.rank:
+            raise RuntimeError("RCCL reports rank %d of %d, expected %d of %d"
+                               % (lib.jr_comm_rank(h), lib.jr_comm_size(h), self.rank, self.world))
         if self.rank == 0:
             # ncclCommInitRank returned => every rank has read the id
             try:
                 os.unlink(idfile)
             except OSError:
                 pass
+
+    @property
+    def size(self):
+        """number of ranks RCCL itself reports for this communicator (ncclCommCount via jr_comm_size)"""
+        return int(_ffi.load().jr_comm_size(self.handle)) if self.handle else 0
 
     def _dev(self, x):
         if not isinstance(x, _ffi.DeviceArray):
@@ -188,7 +217,7 @@ class HostCommunicator(_Base):
         if self.rank == 0:
             if os.path.exists(addr):
                 os.unlink(addr)
-            self._listener = Listener(addr, family="AF_UNIX", authkey=_AUTH)
+            self._listener = Listener(addr, family="AF_UNIX", authkey=_authkey(addr))
             conns = {}
             for _ in range(self.world - 1):
                 c = self._listener.accept()
@@ -199,7 +228,7 @@ class HostCommunicator(_Base):
             t0 = time.time()
             while True:
                 try:
-                    self._hub = Client(addr, family="AF_UNIX", authkey=_AUTH)
+                    self._hub = Client(addr, family="AF_UNIX", authkey=_authkey(addr))
                     break
                 except (ConnectionRefusedError, FileNotFoundError):
                     if time.time() - t0 > timeout:

@@ -1,45 +1,39 @@
 // Tuning switches of the raster kernels.  The product is built with the defaults below; tools/ablate/
 // builds variants with -DJR_TUNE_<X>=0|1 (python -m jrender_amd._build --variant NAME -D...) to reproduce
 // the A/B tables of DESIGN.md on one GPU box.  Every switch selects between two EXACTNESS-EQUIVALENT
-// implementations (same face-index buffer bits, colours / gradients within tolerance).
+// implementations (same face-index buffer bits, colours / gradients within tolerance; tools/ablate/run.py runs the
+// parity tests on every variant) - except JR_TUNE_BWD_TV_RCP, kept to reproduce the measurement that rules it out.
+// Switches that were measured dead in round 2 (K-buffer ids in LDS, SALU slot masks, tile box test, several tiles
+// per wavefront, refinement quotient for the projection parameter, bank-masked DPP reduction) left the kernels:
+// tools/ablate/patches/dead_switches_r03.patch restores them.
 #pragma once
 
-#ifndef JR_TUNE_TV_DIVKNOWN      // edge-projection parameter: refinement quotient with the record's RN(1/Dn) instead of IEEE '/' (same bits).
-                                 // DEAD twice: +3 % with the reciprocal formed on the fly, +0.5 % / +1.2 % with it stored in the record
-#define JR_TUNE_TV_DIVKNOWN 0
-#endif
 #ifndef JR_TUNE_FWD_DIS_ONLY     // forward: carry only (sign, dis) out of the distance machinery
 #define JR_TUNE_FWD_DIS_ONLY 1
 #endif
 #ifndef JR_TUNE_FWD_PREPASS      // forward: conservative half-plane pre-cull of (pixel, face) pairs, lane = face
 #define JR_TUNE_FWD_PREPASS 1
 #endif
-#ifndef JR_TUNE_FWD_IDS_LDS      // forward: K-buffer ids live in LDS (one ds_write per insert), depths stay in VGPRs
-#define JR_TUNE_FWD_IDS_LDS 0
-#endif
-#ifndef JR_TUNE_FWD_IDS_LDS_BIGK // forward: the same for K > 16 only (where the registers no longer hold ids + depths)
-#define JR_TUNE_FWD_IDS_LDS_BIGK 1
-#endif
 #ifndef JR_TUNE_FWD_INSIDE_RCP   // forward: 2nd / 3rd edge projection of INSIDE pixels (colour path only) by reciprocal multiply
 #define JR_TUNE_FWD_INSIDE_RCP 1
-#endif
-#ifndef JR_TUNE_FWD_TPW          // forward: tiles of a bin rendered by one wavefront, one after the other (1, 2, 4, 8, 16)
-#define JR_TUNE_FWD_TPW 1
-#endif
-#ifndef JR_TUNE_FWD_TILE_BOXTEST // forward: load every listed face's box and test it against the tile before staging (round 1)
-#define JR_TUNE_FWD_TILE_BOXTEST 0
 #endif
 #ifndef JR_TUNE_FWD_BATCH        // forward: faces per batch (LDS record slots per wavefront), <= 64; 56 x 176 B = 9.6 KB -> 16 wavefronts per CU
 #define JR_TUNE_FWD_BATCH 56
 #endif
-#ifndef JR_TUNE_FWD_KBUF_SALU    // forward: K-buffer slot masks from 4 bit ballots + scalar logic instead of 16 v_cmp
-#define JR_TUNE_FWD_KBUF_SALU 0
-#endif
-#ifndef JR_TUNE_FWD_IDS_GLOBAL   // forward, K <= 16: K-buffer ids are stored straight into faces_id_buffer at every insert instead of living in registers
+#ifndef JR_TUNE_FWD_IDS_GLOBAL   // forward: K-buffer ids are stored straight into faces_id_buffer at every insert instead of living in registers
 #define JR_TUNE_FWD_IDS_GLOBAL 1
 #endif
-#ifndef JR_TUNE_FWD_OCC4         // forward: ask the register allocator for 4 wavefronts per SIMD at K <= 16 (128 VGPRs)
+#ifndef JR_TUNE_FWD_OCC4         // forward: wavefronts per SIMD asked of the register allocator (1 = 4 at K <= 32 and 3 at K <= 64; > 1 = that many; 0 = none)
 #define JR_TUNE_FWD_OCC4 1
+#endif
+#ifndef JR_TUNE_FWD_FILL_SHIFT   // forward: K-buffer appends shift the depth registers (KCAP v_mov) instead of writing a per-lane slot (KCAP v_cmp + v_cndmask)
+#define JR_TUNE_FWD_FILL_SHIFT 1
+#endif
+#ifndef JR_TUNE_FWD_DEFER_INSIDE // forward: inside pairs do their coverage-dependent part (3 edge projections, alpha, softmax) in a second loop per batch
+#define JR_TUNE_FWD_DEFER_INSIDE 1
+#endif
+#ifndef JR_TUNE_FWD_EXP1         // forward: one v_exp per softmax update instead of two (the other one is exp(0))
+#define JR_TUNE_FWD_EXP1 1
 #endif
 #ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
 #define JR_TUNE_BWD_TV_RCP 0
@@ -53,9 +47,6 @@
 #define JR_TUNE_BWD_WAVES 5
 #endif
 
-#ifndef JR_TUNE_BWD_REDUCE_BANKMASK // backward: row transpose-reduction with bank-masked DPP adds instead of selects
-#define JR_TUNE_BWD_REDUCE_BANKMASK 0
-#endif
 
 #ifndef JR_TUNE_PROFILE_SECTIONS  // instrumented build: per-section shader-clock totals of the raster kernels (tools/ablate)
 #define JR_TUNE_PROFILE_SECTIONS 0
@@ -64,19 +55,15 @@
 namespace jr {
 namespace tune {
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
-constexpr bool bwd_reduce_bankmask = JR_TUNE_BWD_REDUCE_BANKMASK != 0;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
-constexpr bool tv_divknown = JR_TUNE_TV_DIVKNOWN != 0;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
-constexpr bool fwd_ids_lds = JR_TUNE_FWD_IDS_LDS != 0;
-constexpr bool fwd_ids_lds_bigk = JR_TUNE_FWD_IDS_LDS_BIGK != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
-constexpr int fwd_tiles_per_wave = JR_TUNE_FWD_TPW;
 constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
 constexpr bool fwd_ids_global = JR_TUNE_FWD_IDS_GLOBAL != 0;
-constexpr bool fwd_kbuf_salu = JR_TUNE_FWD_KBUF_SALU != 0;
-constexpr bool fwd_tile_boxtest = JR_TUNE_FWD_TILE_BOXTEST != 0;
+constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
+constexpr bool fwd_defer_inside = JR_TUNE_FWD_DEFER_INSIDE != 0;
+constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 }  // namespace tune
 }  // namespace jr

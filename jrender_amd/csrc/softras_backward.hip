@@ -40,38 +40,14 @@ __device__ inline unsigned dpp_u(unsigned v) {
 // Sum of 16 per-lane values over the 16 lanes of a row, "transposed": lane i of the row ends up
 // with the row total of v[i].  Butterfly with halving payload (8+4+2+1 exchanges instead of
 // 16 x 4): partners are row_mirror, row_half_mirror, quad_perm[3,2,1,0], quad_perm[1,0,3,2].
-//
-// tune::bwd_reduce_bankmask: the two upper halvings (lane bits 3 and 2 = the four DPP banks of a row) need no
-// selects at all — v_add_f32_dpp only writes the lanes its bank_mask names, so "lanes 0..7 keep component j,
-// lanes 8..15 keep component j+8" is two masked adds into the same register (27 DPP adds + 6 selects instead of
-// 15 + 30).  The caller's components 12..15 are always zero (9 vertex + 3 colour components).
+// (Bank-masked v_add_f32_dpp instead of the selects: +3 %, tools/ablate/patches/dead_switches_r03.patch.)
 __device__ inline float row_transpose_reduce(const float (&v)[16], int li) {
     float a[8], b[4], c[2];
     const bool h8 = li & 8, h4 = li & 4, h2 = li & 2, h1 = li & 1;
-    if (tune::bwd_reduce_bankmask) {
-        // s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states, and the
-        // compiler's hazard recogniser does not look into inline assembly
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-                "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xc"
-                : "=&v"(a[j]) : "v"(v[j]), "v"(v[j + 8]));
-#pragma unroll
-        for (int j = 4; j < 8; j++) {
-            a[j] = 0.f;                                  // lanes 8..15 would keep component j + 8 >= 12: zero
-            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0x3" : "+v"(a[j]) : "v"(v[j]));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa"
-                : "=&v"(b[j]) : "v"(a[j]), "v"(a[j + 4]));
-    } else {
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = (h8 ? v[j + 8] : v[j]) + dpp_f<0x140>(h8 ? v[j] : v[j + 8]);
 #pragma unroll
     for (int j = 0; j < 4; j++) b[j] = (h4 ? a[j + 4] : a[j]) + dpp_f<0x141>(h4 ? a[j] : a[j + 4]);
-    }
 #pragma unroll
     for (int j = 0; j < 2; j++) c[j] = (h2 ? b[j + 2] : b[j]) + dpp_f<0x1B>(h2 ? b[j] : b[j + 2]);
     return (h1 ? c[1] : c[0]) + dpp_f<0xB1>(h1 ? c[0] : c[1]);
@@ -165,7 +141,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_fast(-dis, p); }
     else {
         // nothing is decided from the projection parameter here (sign and region come from the exact w)
-        dd = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE)>(r, meta, w, xp, yp);
+        dd = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : TV_IEEE>(r, meta, w, xp, yp);
         dis = dd.dx * dd.dx + dd.dy * dd.dy;
         D = coverage_fast(-dd.sign * dis, p);
     }

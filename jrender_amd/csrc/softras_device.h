@@ -63,7 +63,7 @@ struct FaceGeo {
     float x0, y0, x1, y1, x2, y2;
     float A[9];                    // A[e] = sym[e] - sym[e+1]            (SRK:77-79)
     float Dn[3];                   // A[e][e] - A[e][e+1]                 (SRK:81 denominator)
-    float rDn[3];                  // RN(1/Dn[e]): the projection parameter is a refinement quotient (edge_candidate)
+    float spare[3];                // (kept: 11 x 16 B is an odd number of 16-byte lanes; was RN(1/Dn), tools/ablate/patches/)
     float rz[3];                   // RN(1/z[k])
     int meta;                      // face index inside its image | FLAG_* << 28 | (obtuse vertex + 1) << 30 (SRK:227-235)
     float col[3];                  // surface colour when T == 1
@@ -144,7 +144,7 @@ __device__ inline void build_face_geo(FaceGeo& r, const float* __restrict__ f,
             safe = safe && zero_or_in_fast_range(r.A[3 * e + c]);
         }
         r.Dn[e] = r.A[3 * e + e] - r.A[3 * e + e1];
-        r.rDn[e] = 1.0f / r.Dn[e];
+        r.spare[e] = 0.f;
         r.rz[e] = 1.0f / r.z[e];
         safe = safe && in_fast_range(r.Dn[e]) && in_fast_range(r.z[e]);
     }
@@ -241,21 +241,13 @@ struct Dist {
 struct EdgeCand { float u0, u1, u2, ex, ey, dd; };
 
 // TV selects how the quotient of SRK:81 / :132 is formed:
-//   TV_IEEE   plain IEEE division (~50 cycles)
-//   TV_EXACT  the same bits from the reciprocal-refinement quotient: the divisor's correctly rounded
-//             reciprocal travels with the record (FLAG_SAFE faces have Dn in the proven range), the numerator
-//             — which can be a rounding crumb when the pixel projects exactly onto a vertex — is checked
-//             against the refinement's guarantee domain (0 or 2^-80 <= |a| <= 2^60) and takes the IEEE
-//             division otherwise
+//   TV_IEEE   plain IEEE division (~50 cycles).  (The same bits from a reciprocal-refinement quotient with RN(1/Dn)
+//             stored in the record were built twice and cost what the hardware's v_div_scale / v_div_fmas /
+//             v_div_fixup sequence costs: tools/ablate/patches/dead_switches_r03.patch.)
 //   TV_RCP    reciprocal multiply (<= 2 ulp off): only where nothing is decided from the result
-constexpr int TV_IEEE = 0, TV_EXACT = 1, TV_RCP = 2;
+constexpr int TV_IEEE = 0, TV_RCP = 2;
 
-__device__ inline bool in_refinement_domain(float a) {
-    const float m = fabsf(a);
-    return a == 0.f || (m >= 8.271806125530277e-25f && m <= 1.152921504606847e18f);
-}
-
-template <bool FAST, int TV = (tune::tv_divknown ? TV_EXACT : TV_IEEE)>
+template <bool FAST, int TV = TV_IEEE>
 __device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e, bool clamp) {
     const int e1 = e == 2 ? 0 : e + 1;
     const float a0 = r.A[3 * e], a1 = r.A[3 * e + 1], a2 = r.A[3 * e + 2];
@@ -264,10 +256,7 @@ __device__ inline EdgeCand edge_candidate(const FaceGeo& r, const Bary& b, int e
     const float num = ((b.w0 * a0 + b.w1 * a1) + b.w2 * a2) - av1;                       // SRK:81 / :132
     float tv;
     if (FAST && TV == TV_RCP) tv = num * __builtin_amdgcn_rcpf(dn);
-    else if (FAST && TV == TV_EXACT) {
-        tv = div_known<true>(num, dn, r.rDn[e]);
-        if (__builtin_expect(!in_refinement_domain(num), 0)) tv = num / dn;
-    } else tv = num / dn;
+    else tv = num / dn;
     const float tn = 1 - tv;
     // t[e] = tv, t[e+1] = 1 - tv, t[e+2] = 0 (indices mod 3)
     float u0 = e == 0 ? tv : (e == 2 ? tn : 0.f);
@@ -323,7 +312,7 @@ __device__ inline bool strictly_inside_t(const Bary& b) {
 // execute two separate code paths; the two further projections run only if some lane is inside.
 // (Projecting only the edge the weights name as nearest was built, proven exact and measured slower:
 // tools/ablate/patches/, profiles/r02_ab_inside_select.log.)
-template <bool FAST, int TV = (tune::tv_divknown ? TV_EXACT : TV_IEEE)>
+template <bool FAST, int TV = TV_IEEE>
 __device__ inline Dist euclidean_p2f(const FaceGeo& r, int meta, const Bary& b, float xp, float yp) {
     const bool inside = strictly_inside_t<FAST>(b);
     const int v0 = outside_edge(r, face_obtuse(meta), b, xp, yp);
@@ -363,7 +352,7 @@ __device__ inline void euclidean_sign_dis(const FaceGeo& r, int meta, const Bary
     if (inside) {
         float best = 100000000.f;                    // SRK:68: candidates that are not < 1e8 (NaN) leave dis = 0
         if (c.dd < best) best = c.dd;
-        constexpr int TVI = tune::fwd_inside_rcp ? TV_RCP : (tune::tv_divknown ? TV_EXACT : TV_IEEE);
+        constexpr int TVI = tune::fwd_inside_rcp ? TV_RCP : TV_IEEE;
         const float d1 = edge_candidate<FAST, TVI>(r, b, 1, false).dd;
         const float d2 = edge_candidate<FAST, TVI>(r, b, 2, false).dd;
         if (d1 < best) best = d1;
@@ -374,6 +363,29 @@ __device__ inline void euclidean_sign_dis(const FaceGeo& r, int meta, const Bary
         sign = -1.f;
         dis = v0 < 0 ? 0.f : c.dd;
     }
+}
+
+// The two halves of euclidean_sign_dis for callers that know the class of the pair (tune::fwd_defer_inside):
+// an OUTSIDE pixel's squared distance (SRK:107-146; sign = -1), decided from exactly ...
+template <bool FAST>
+__device__ inline float euclidean_outside_dis(const FaceGeo& r, int meta, const Bary& b, float xp, float yp) {
+    const int v0 = outside_edge(r, face_obtuse(meta), b, xp, yp);
+    const float dd = edge_candidate<FAST>(r, b, v0 < 0 ? 0 : v0, true).dd;
+    return v0 < 0 ? 0.f : dd;
+}
+// ... and an INSIDE pixel's (SRK:68-105; sign = +1): nearest of the three edge projections, strict '<' from 1e8.
+// Only the coverage sigmoid reads it (colour path): the 2nd / 3rd projection use the reciprocal multiply.
+template <bool FAST>
+__device__ inline float euclidean_inside_dis(const FaceGeo& r, const Bary& b) {
+    float best = 100000000.f;                        // SRK:68: candidates that are not < 1e8 (NaN) leave dis = 0
+    const float d0 = edge_candidate<FAST>(r, b, 0, false).dd;
+    if (d0 < best) best = d0;
+    constexpr int TVI = tune::fwd_inside_rcp ? TV_RCP : TV_IEEE;
+    const float d1 = edge_candidate<FAST, TVI>(r, b, 1, false).dd;
+    const float d2 = edge_candidate<FAST, TVI>(r, b, 2, false).dd;
+    if (d1 < best) best = d1;
+    if (d2 < best) best = d2;
+    return best < 100000000.f ? best : 0.f;
 }
 
 __device__ inline float barycentric_dist(const Bary& b) {                             // SRK:150-154

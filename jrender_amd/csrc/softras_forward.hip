@@ -31,48 +31,74 @@
 
 namespace jr {
 
-// ids never feed a decision.  For K <= 16 they sit in registers next to the depths (measured: moving them to
-// LDS costs 18 % — the [K][64] table caps a CU at 10 wavefronts).  Above that the registers do not fit any
-// more (KCAP = 64: 256 VGPRs, one wavefront per SIMD), so the ids live in LDS ([slot][lane] words, one
-// ds_write per insert instead of KCAP selects) and only the depths stay in registers (KCAP = 64: 130 VGPRs).
+// The K-buffer's face indices never feed a decision, so they do not live in registers: every insert stores the face
+// index straight into its slot plane of faces_id_buffer (the output), the slots that were never filled get their -1
+// at the end.  Same-address stores of one wavefront complete in program order, so the plane ends up with the slot's
+// LAST face, exactly what a register K-buffer would have held.  (In registers the ids cost KCAP v_cndmask per insert
+// AND - being live beyond the divergent raster loop - a second register set with KCAP v_mov to copy them back: seen
+// in the ISA.  tune::fwd_ids_global = 0 rebuilds that form for the A/B.)
 template <int KCAP>
-constexpr bool ids_in_lds() { return tune::fwd_ids_lds || (KCAP > 16 && tune::fwd_ids_lds_bigk); }
-// K <= 16: the ids do not live in registers at all — every insert stores the face index straight into its slot
-// plane of faces_id_buffer (the output), the slots that were never filled get their -1 at the end.  Same-address
-// stores of one wavefront complete in program order, so the plane ends up with the slot's LAST face, exactly what
-// the register K-buffer held.  (In registers the ids cost 16 v_cndmask per insert AND — being live beyond the
-// divergent raster loop — a second register set with 16 v_mov to copy them back: seen in the ISA.)
-template <int KCAP>
-constexpr bool ids_in_global() { return tune::fwd_ids_global && KCAP == 16 && !ids_in_lds<KCAP>(); }
+constexpr bool ids_in_global() { return tune::fwd_ids_global; }
 
 template <int KCAP>
 struct KBuffer {
-    static constexpr bool IDS_LDS = ids_in_lds<KCAP>();
     static constexpr bool IDS_GLOBAL = ids_in_global<KCAP>();
-    int id[(IDS_LDS || IDS_GLOBAL) ? 1 : KCAP];
+    // tune::fwd_fill_shift.  71 % of the pairs that reach the K-buffer are APPENDS (slot = size, a per-lane index:
+    // KCAP v_cmp + KCAP v_cndmask at 4.3 cycles each), 7.5 % replace the largest depth (oracle statistics of the
+    // headline scene).  Appends therefore shift: z[k] = z[k-1], z[0] = zp - KCAP v_mov at 2.7 cycles, no compares -
+    // and slot s lives in register size-1-s; once the buffer is full the map is the constant K-1-s, which is all
+    // the replace path needs.  (The ids are not in registers, so nothing else has to follow the shift.)
+    static constexpr bool SHIFT = tune::fwd_fill_shift && IDS_GLOBAL;
+    int id[IDS_GLOBAL ? 1 : KCAP];
     int32_t* gplane;               // IDS_GLOBAL: slot plane 0 of this pixel's image in faces_id_buffer
     unsigned goff, gstride;        //             element offset of the pixel, elements per slot plane
     float z[KCAP];
     int size;
     float max_z;
     int max_slot;
-    int* lds_ids;                  // this lane's column of the [K][64] id table (tune::fwd_ids_lds)
 
     // Slots >= K are never written; their depth is -inf so that the rescan (which starts from -1) can
     // run over all KCAP registers without a per-slot "k < K" predicate (16 SGPR pairs otherwise).
-    __device__ inline void init(int K, int* ids_column, int32_t* plane0 = nullptr, unsigned pixel = 0u, unsigned stride = 0u) {
-        lds_ids = ids_column;
+    __device__ inline void init(int K, int32_t* plane0, unsigned pixel, unsigned stride) {
         gplane = plane0; goff = pixel; gstride = stride;
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             if (IDS_GLOBAL) { if (k == 0) id[0] = -1; }
-            else if (!IDS_LDS) id[k] = -1;
-            else if (k < K) lds_ids[k * 64] = -1;
-            z[k] = k < K ? 0.f : -__builtin_inff();
+            else id[k] = -1;
+            z[k] = (k < K && !SHIFT) ? 0.f : -__builtin_inff();   // SHIFT: K appends move the first K initial values beyond register K-1
         }
         size = 0; max_z = -1.f; max_slot = -1;
     }
-    __device__ inline int id_of(int k) const { return IDS_LDS ? lds_ids[k * 64] : id[IDS_GLOBAL ? 0 : k]; }
+    __device__ inline int id_of(int k) const { return id[IDS_GLOBAL ? 0 : k]; }
+    // largest depth by a v_max3 tree, then the FIRST slot that holds it; equals the reference's strict '>'
+    // scan from -1 (SRK:379-385), NaN depths are skipped by both.  No serial compare-select chain.
+    __device__ inline void rescan(int K) {
+        float t[KCAP];
+#pragma unroll
+        for (int k = 0; k < KCAP; k++) t[k] = z[k];
+#pragma unroll
+        for (int w = KCAP; w > 1; w = (w + 2) / 3) {
+#pragma unroll
+            for (int i = 0; i * 3 < w; i++) {
+                const float a = t[3 * i], b = 3 * i + 1 < w ? t[3 * i + 1] : a, c = 3 * i + 2 < w ? t[3 * i + 2] : a;
+                t[i] = fmaxf(fmaxf(a, b), c);
+            }
+        }
+        const float m = fmaxf(t[0], -1.f);
+        int ms = max_slot;
+        if (m > -1.f) {
+            if (SHIFT) {           // slot s sits in register K-1-s: the first slot is the LAST register that holds m
+                int mr = 0;
+#pragma unroll
+                for (int k = 0; k < KCAP; k++) mr = z[k] == m ? k : mr;
+                ms = K - 1 - mr;
+            } else {               // descending selects, so the smallest k is written last
+#pragma unroll
+                for (int k = KCAP - 1; k >= 0; k--) ms = z[k] == m ? k : ms;
+            }
+        }
+        max_z = m; max_slot = ms;
+    }
     // K-nearest insert with the reference's slot semantics (SRK:369-385): append while not
     // full (tracking the first largest depth), afterwards overwrite the largest-depth slot
     // when strictly nearer and rescan, first maximum wins.
@@ -80,55 +106,32 @@ struct KBuffer {
         const bool filling = size < K;
         if (!filling && !(zp < max_z)) return;
         const int slot = filling ? size : max_slot;
-        if (IDS_LDS) lds_ids[slot * 64] = fn;
         if (IDS_GLOBAL) gplane[(unsigned)slot * gstride + goff] = fn;
-        if (tune::fwd_kbuf_salu && KCAP == 16) {
-            // The 16 "slot == k" masks from 4 bit ballots and scalar and / andn2 (SALU, issued beside the vector
-            // pipe) instead of 16 v_cmp: v_cmp and v_cndmask are half-rate on gfx950 (tools/ubench/valu_rates2).
-            const unsigned long long b0 = ballot((slot & 1) != 0), b1 = ballot((slot & 2) != 0),
-                                     b2 = ballot((slot & 4) != 0), b3 = ballot((slot & 8) != 0);
-            const unsigned long long lo[4] = {~b0 & ~b1, b0 & ~b1, ~b0 & b1, b0 & b1};
-            const unsigned long long hi[4] = {~b2 & ~b3, b2 & ~b3, ~b2 & b3, b2 & b3};
+        if (SHIFT) {
+            if (filling) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const unsigned long long m = lo[k & 3] & hi[k >> 2];
-                if (!IDS_LDS && !IDS_GLOBAL) asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(id[k]) : "v"(fn), "s"(m));
-                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(z[k]) : "v"(zp), "s"(m));
+                for (int k = KCAP - 1; k > 0; k--) z[k] = z[k - 1];
+                z[0] = zp;
+                if (zp > max_z) { max_z = zp; max_slot = size; }
+                size++;
+            } else {
+                const int reg = K - 1 - slot;
+#pragma unroll
+                for (int k = 0; k < KCAP; k++) z[k] = k == reg ? zp : z[k];
+                rescan(K);
             }
-        } else {
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             const bool hit = k == slot;
-            if (!IDS_LDS && !IDS_GLOBAL) id[k] = hit ? fn : id[k];
+            if (!IDS_GLOBAL) id[k] = hit ? fn : id[k];
             z[k] = hit ? zp : z[k];
-        }
         }
         if (filling) {
             if (zp > max_z) { max_z = zp; max_slot = size; }
             size++;
-        } else {
-            // largest depth by a v_max3 tree, then the FIRST slot that holds it (descending selects, so
-            // the smallest k is written last); equals the reference's strict '>' scan from -1 (SRK:379-385),
-            // NaN depths are skipped by both.  No serial compare-select chain.
-            float t[KCAP];
-#pragma unroll
-            for (int k = 0; k < KCAP; k++) t[k] = z[k];
-#pragma unroll
-            for (int w = KCAP; w > 1; w = (w + 2) / 3) {
-#pragma unroll
-                for (int i = 0; i * 3 < w; i++) {
-                    const float a = t[3 * i], b = 3 * i + 1 < w ? t[3 * i + 1] : a, c = 3 * i + 2 < w ? t[3 * i + 2] : a;
-                    t[i] = fmaxf(fmaxf(a, b), c);
-                }
-            }
-            const float m = fmaxf(t[0], -1.f);
-            int ms = max_slot;
-            if (m > -1.f) {
-#pragma unroll
-                for (int k = KCAP - 1; k >= 0; k--) ms = z[k] == m ? k : ms;
-            }
-            max_z = m; max_slot = ms;
-        }
+        } else rescan(K);
     }
 };
 
@@ -157,34 +160,39 @@ __device__ inline void sample_colour(const RasterParams& p, const FaceRec& r, co
     }
 }
 
-template <int DIST, int RGB, bool FAST, int KCAP>
-__device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
-                                    const float* __restrict__ tbase, float xp, float yp,
-                                    PixelState<KCAP>& s) {
-    const Bary w = barycentric(r, xp, yp);
-    const int meta = r.meta;
-    float D, neg_num = -1.f;            // neg_num = the sigmoid's numerator, -sign*dis (any negative value for 'hard')
-    if (DIST == 0) {                                                           // SRK:331-333
-        if (!pixel_inside(w)) return;
-        D = 1.f;
-    } else if (DIST == 1) {                                                    // SRK:335-338
-        const float dis = barycentric_dist(w);
-        if (-dis >= p.thr) return;
-        neg_num = -dis;
-        D = coverage_fast(neg_num, p);
-    } else {                                                                   // SRK:340-344
-        float sign, dis;
-        if (tune::fwd_dis_only) euclidean_sign_dis<FAST>(r, meta, w, xp, yp, sign, dis);
-        else {
-            const Dist dd = euclidean_p2f<FAST>(r, meta, w, xp, yp);
-            sign = dd.sign;
-            dis = dd.dx * dd.dx + dd.dy * dd.dy;
-        }
-        if (sign < 0 && dis >= p.thr) return;
-        neg_num = -sign * dis;
-        D = coverage_fast(neg_num, p);
+// online softmax over the normalised depth (SRK:399-419) and the colour sums it weights
+template <bool FAST, int KCAP>
+__device__ inline void softmax_accumulate(const RasterParams& p, const FaceRec& r, const float* vc,
+                                          const float* __restrict__ tbase, const Bary& wc, float zp, float D,
+                                          PixelState<KCAP>& s) {
+    // zn must carry the reference's exact bits: the softmax divides differences of it by gamma
+    const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
+    float ed, ez;
+    if (tune::fwd_exp1) {
+        // one of the reference's two exponentials is always exp(0) = 1 (after "smax = zn" the second argument is 0):
+        // ONE v_exp of -|zn - smax| and two selects give the same two values, bit for bit
+        const float x = zn - s.smax;
+        const bool up = x > 0.f;                       // zn > smax (NaN: false, like the reference's compare)
+        const float e = exp_over_gamma(up ? -x : x, p);
+        ed = up ? e : 1.f;
+        ez = up ? 1.f : e;
+        s.smax = up ? zn : s.smax;
+    } else {
+        ed = 1.f;
+        if (zn > s.smax) { ed = exp_over_gamma(s.smax - zn, p); s.smax = zn; }
+        ez = exp_over_gamma(zn - s.smax, p);
     }
-    // alpha aggregation happens before the depth cull (SRK:350-358)
+    s.ssum = ed * s.ssum + ez * D;
+    float k0, k1, k2;
+    sample_colour<FAST>(p, r, vc, tbase, wc, zp, k0, k1, k2);
+    s.c0 = ed * s.c0 + ez * D * k0;
+    s.c1 = ed * s.c1 + ez * D * k1;
+    s.c2 = ed * s.c2 + ez * D * k2;
+}
+
+// alpha aggregation (SRK:350-358); neg_num = the sigmoid's numerator -sign*dis (any negative value for 'hard' distance)
+template <int DIST, bool FAST, int KCAP>
+__device__ inline void alpha_accumulate(const RasterParams& p, float neg_num, float D, PixelState<KCAP>& s) {
     if (p.alpha == 0) {
         // 'hard' alpha is a DECISION (D > 0.5), so it must not ride on the approximate sigmoid.  With the
         // reference's arithmetic, D = (float)(1/(1 + (double)expf(x))), x = neg_num/sigma (float division),
@@ -201,10 +209,57 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
         // the reference; alpha only has to meet 1e-4.
         s.alpha = __builtin_fmaf(-s.alpha, D, s.alpha);
     }
+}
+
+// One (pixel, face) pair of the raster loop.  Returns true when the pair was DEFERRED (tune::fwd_defer_inside,
+// euclidean distance only): the pixel lies strictly inside the face.  Such a pair is never culled by distance and its
+// coverage needs three edge projections instead of one; 8 % of the pairs are inside, but with 64 lanes on 64
+// different faces nearly every trip of the loop had one, so the whole wavefront paid the 60 extra instructions
+// at 8 % lane use.  Everything that is ORDER dependent (depth cull, K-buffer insert, 'hard' rgb) does not
+// depend on the coverage and happens here, in face order; what depends on it — the alpha product and the softmax
+// sums — commutes (1e-4 colour path) and is added by forward_pair_inside in a second loop over the batch's
+// deferred pairs, where all active lanes are inside.
+template <int DIST, int RGB, bool FAST, int KCAP>
+__device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
+                                    const float* __restrict__ tbase, float xp, float yp,
+                                    PixelState<KCAP>& s) {
+    const Bary w = barycentric(r, xp, yp);
+    const int meta = r.meta;
+    float D = 1.f, neg_num = -1.f;
+    bool deferred = false;
+    if (DIST == 0) {                                                           // SRK:331-333
+        if (!pixel_inside(w)) return false;
+    } else if (DIST == 1) {                                                    // SRK:335-338
+        const float dis = barycentric_dist(w);
+        if (-dis >= p.thr) return false;
+        neg_num = -dis;
+        D = coverage_fast(neg_num, p);
+    } else if (tune::fwd_defer_inside) {                                       // SRK:340-344
+        deferred = strictly_inside_t<FAST>(w);
+        if (!deferred) {
+            const float dis = euclidean_outside_dis<FAST>(r, meta, w, xp, yp);
+            if (dis >= p.thr) return false;
+            neg_num = dis;
+            D = coverage_fast(neg_num, p);
+        }
+    } else {
+        float sign, dis;
+        if (tune::fwd_dis_only) euclidean_sign_dis<FAST>(r, meta, w, xp, yp, sign, dis);
+        else {
+            const Dist dd = euclidean_p2f<FAST>(r, meta, w, xp, yp);
+            sign = dd.sign;
+            dis = dd.dx * dd.dx + dd.dy * dd.dy;
+        }
+        if (sign < 0 && dis >= p.thr) return false;
+        neg_num = -sign * dis;
+        D = coverage_fast(neg_num, p);
+    }
+    // alpha aggregation happens before the depth cull (SRK:350-358)
+    if (!deferred) alpha_accumulate<DIST, FAST>(p, neg_num, D, s);
 
     const Bary wc = barycentric_clip<FAST>(w);
     const float zp = depth_of<FAST>(r, wc);
-    if (zp < p.near_ || zp > p.far_) return;                                  // SRK:365
+    if (zp < p.near_ || zp > p.far_) return deferred;                         // SRK:365
     const int fn = face_id(meta);
     s.q.insert(fn, zp, p.K);
 
@@ -214,24 +269,32 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
             sample_colour<FAST>(p, r, vc, tbase, wc, zp, s.c0, s.c1, s.c2);
         }
     } else if (RGB == 1) {                                                     // SRK:399-419
-        if (face_front(meta) || p.double_side) {
-            // zn must carry the reference's exact bits: the softmax divides differences of it by gamma
-            const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
-            float ed = 1.f;
-            if (zn > s.smax) { ed = exp_over_gamma(s.smax - zn, p); s.smax = zn; }
-            const float ez = exp_over_gamma(zn - s.smax, p);
-            s.ssum = ed * s.ssum + ez * D;
-            float k0, k1, k2;
-            sample_colour<FAST>(p, r, vc, tbase, wc, zp, k0, k1, k2);
-            s.c0 = ed * s.c0 + ez * D * k0;
-            s.c1 = ed * s.c1 + ez * D * k1;
-            s.c2 = ed * s.c2 + ez * D * k2;
-        }
+        if (!deferred && (face_front(meta) || p.double_side)) softmax_accumulate<FAST>(p, r, vc, tbase, wc, zp, D, s);
+    }
+    return deferred;
+}
+
+// The coverage-dependent part of a deferred inside pair: three edge projections -> coverage -> alpha, softmax.
+template <int RGB, bool FAST, int KCAP>
+__device__ inline void forward_pair_inside(const RasterParams& p, const FaceRec& r, const float* vc,
+                                           const float* __restrict__ tbase, float xp, float yp,
+                                           PixelState<KCAP>& s) {
+    const Bary w = barycentric(r, xp, yp);
+    const float neg_num = -euclidean_inside_dis<FAST>(r, w);
+    const float D = coverage_fast(neg_num, p);
+    alpha_accumulate<2, FAST>(p, neg_num, D, s);
+    if (RGB == 1 && (face_front(r.meta) || p.double_side)) {
+        const Bary wc = barycentric_clip<FAST>(w);
+        const float zp = depth_of<FAST>(r, wc);
+        if (zp < p.near_ || zp > p.far_) return;                              // SRK:365
+        softmax_accumulate<FAST>(p, r, vc, tbase, wc, zp, D, s);
     }
 }
 
+// wavefronts per SIMD asked of the register allocator: K <= 16 and K <= 32 fit 128 VGPRs (4), K <= 64 fits 168 (3)
+constexpr int fwd_waves(int kcap) { return JR_TUNE_FWD_OCC4 > 1 ? JR_TUNE_FWD_OCC4 : (JR_TUNE_FWD_OCC4 ? (kcap <= 32 ? 4 : 3) : 1); }
 template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? (JR_TUNE_FWD_OCC4 ? (JR_TUNE_FWD_OCC4 > 1 ? JR_TUNE_FWD_OCC4 : 4) : 1) : (KCAP <= 32 ? 2 : 1)))) void k_softras_forward(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP)))) void k_softras_forward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
@@ -242,17 +305,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     constexpr int BATCH = tune::fwd_batch;       // record slots per wavefront (64 x 176 B cap a CU at 14 wavefronts)
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
     float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
-    int* s_ids = reinterpret_cast<int*>(s_vcol + (p.tex == 1 ? 9 * BATCH : 0)); // [K][64] iff ids_in_lds<KCAP>()
 
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
     // bin (same list, same records) go to ONE XCD so that they share its L2.
-    // A wavefront renders TPW tiles of its bin one after the other (a run of horizontally adjacent tiles):
-    // the store tail of one tile overlaps with the list walk of the next, and the bin look-ups are paid once.
-    constexpr int TPW = tune::fwd_tiles_per_wave, WPB = 16 / TPW;      // tiles per wavefront, wavefronts per bin
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
-    const int brank = (k / WPB) * 8 + (blockIdx.x & 7);  // bins are dealt round-robin to the XCDs ...
+    const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
     if (brank * 16 >= ntiles_total) return;
     const int bin = bin_order[brank];                    // ... heaviest first (k_bin_schedule)
+    const int sub = k & 15;                              // tile of the bin
     const int bins_per_img = p.bins_x * p.bins_y;
     const int b = bin / bins_per_img;
     const int bb = bin - b * bins_per_img;
@@ -261,11 +321,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     const int lane = threadIdx.x, lx = lane & 7, ly = lane >> 3;
     SectionClock clk;            // instrumented builds only: 0 set-up, 1 cull + stage, 2 ballots + pre-cull, 3 raster loop, 4 stores
     clk.start();
-#pragma nounroll
-    for (int tw = 0; tw < TPW; tw++) {
-    const int sub = (k % WPB) * TPW + tw;
     const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
-    if (col0 >= p.IS || row0 >= p.IS) continue;          // tile lies outside the image
+    if (col0 >= p.IS || row0 >= p.IS) return;            // tile lies outside the image
     const int col = col0 + lx, row = row0 + ly;
     const bool valid = col < p.IS && row < p.IS;
     const float xp = pixel_centre(col, p.IS);
@@ -283,7 +340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     else if (RGB == 1) { s.c0 = p.bg[0] * s.ssum; s.c1 = p.bg[1] * s.ssum; s.c2 = p.bg[2] * s.ssum; }
     s.depth_min = 10000000.f;
     s.face_min = -1;
-    s.q.init(p.K, s_ids + lane, ids + (size_t)b * p.K * p.IS * p.IS, valid ? (unsigned)(row * p.IS + col) : 0u, (unsigned)(p.IS * p.IS));
+    s.q.init(p.K, ids + (size_t)b * p.K * p.IS * p.IS, valid ? (unsigned)(row * p.IS + col) : 0u, (unsigned)(p.IS * p.IS));
 
     const unsigned long long* seg = pool + bin_base[bin];
     const FaceGeo* gbase = geo + (size_t)b * p.NF;
@@ -313,11 +370,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 keep = (e >> sub) & 1ull;
                 if (!ballot(keep)) continue;        // no face of this chunk touches this tile
                 gp = gbase + (int)(e >> 32);
-                if (tune::fwd_tile_boxtest) {       // round-1 form: conservative float test of the box against the tile
-                    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (keep) box = *reinterpret_cast<const float4*>(gp);         // xlo xhi ylo yhi
-                    keep = keep && !(xc(0) > box.y) && !(xc(7) < box.x) && !(yc(7) > box.w) && !(yc(0) < box.z);
-                }
                 const unsigned long long surv = ballot(keep);
                 if (!surv) continue;
                 cnt = __builtin_popcountll(surv);
@@ -440,15 +492,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 M = valid ? (select8(cx, lx) & select8(ry, ly)) : 0ull;
             }
             clk.lap(2);
+            unsigned long long Mdef = 0ull;        // this pixel's deferred (inside) pairs of the batch
             while (M) {
                 const int j = __builtin_ctzll(M);
-                M &= M - 1;
+                const unsigned long long rest = M & (M - 1);
                 const FaceRec& r = s_rec[j];
                 const float* vc = s_vcol + j * 9;
+                bool deferred;
                 if (face_safe(r.meta) && p.consts_safe)
-                    forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
+                    deferred = forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
                 else
-                    forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
+                    deferred = forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
+                if (DIST == 2 && tune::fwd_defer_inside && deferred) Mdef |= M ^ rest;
+                M = rest;
+            }
+            if (DIST == 2 && tune::fwd_defer_inside) {
+                while (Mdef) {
+                    const int j = __builtin_ctzll(Mdef);
+                    Mdef &= Mdef - 1;
+                    const FaceRec& r = s_rec[j];
+                    const float* vc = s_vcol + j * 9;
+                    if (face_safe(r.meta) && p.consts_safe)
+                        forward_pair_inside<RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
+                    else
+                        forward_pair_inside<RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
+                }
             }
         }
         fill = 0;
@@ -457,7 +525,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     }
     clk.lap(1);
 
-    if (!valid) continue;
+    if (!valid) return;
     // ---- finalise (SRK:426-455) ----
     const size_t pp = (size_t)p.IS * p.IS;
     const size_t pn = (size_t)row * p.IS + col;
@@ -485,18 +553,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             else if (k >= s.q.size) io[(size_t)k * pp] = -1;         // the filled slots were stored when they were filled
         }
     clk.lap(4);
-    }   // tiles of this wavefront
     clk.flush(counters, 4);
 }
 
 template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
-    const int grid = ((ntiles + 127) / 128) * 128 / tune::fwd_tiles_per_wave;   // whole bins (16 tiles) per XCD slot
-    const bool ids_lds = p.K <= 16 ? ids_in_lds<16>() : ids_in_lds<64>();
-    const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0) +
-                        (ids_lds ? sizeof(int) * 64 * (size_t)p.K : 0);
-    // K-buffer capacity: 16 (the default K), 32 (K = 17..32: 2 wavefronts per SIMD), 64 (1 wavefront per SIMD)
+    const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
+    const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0);
+    // K-buffer capacity: 16 (the default K), 32 (K = 17..32), 64
     if (p.K <= 16)
         k_softras_forward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);

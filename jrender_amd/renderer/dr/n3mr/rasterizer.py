@@ -1,7 +1,7 @@
 """N3mrRasterizer — host-side mirror of jrender/renderer/dr/n3mr/rasterizer.py (N3R:9-105)."""
 import numpy as np
 
-from .n3mr import RasterizeRGBAD
+from .n3mr import DEFAULT_EPS, DEFAULT_FAR, DEFAULT_NEAR, RasterizeRGBAD
 from ....structures.mesh import face_vertices as vertices_to_faces
 
 __all__ = ["N3mrRasterizer", "vertices_to_faces"]
@@ -41,7 +41,16 @@ class N3mrRasterizer:
 
     def _run(self, vertices, faces, textures, rgb, alpha, depth):
         faces, textures = self._fill_back(faces, textures if rgb else None)
-        self._op = RasterizeRGBAD(self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
+        # The reference's render_silhouettes / render_depth call rasterize_silhouettes / rasterize_depth with
+        # (faces, image_size, anti_aliasing) only (N3R:61-80): those modes run with the module defaults near=0.1,
+        # far=100, eps=1e-4 whatever the rasterizer was constructed with; self.near / self.far /
+        # self.rasterizer_eps (1e-3) only reach render_rgb and render (N3R:82-105).  eps enters the backward as
+        # dist +/- eps, so the silhouette / depth gradients depend on it.
+        if rgb:
+            near, far, eps = self.near, self.far, self.rasterizer_eps
+        else:
+            near, far, eps = DEFAULT_NEAR, DEFAULT_FAR, DEFAULT_EPS
+        self._op = RasterizeRGBAD(self.image_size, self.anti_aliasing, near, far, eps,
                                   self.background_color if rgb else None, rgb, alpha, depth)
         return self._op(vertices_to_faces(vertices, faces), textures)
 

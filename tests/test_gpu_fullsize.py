@@ -15,7 +15,7 @@ import pytest
 from oracle import Oracle
 from jrender_amd import _ffi, synthetic as syn
 from jrender_amd.renderer.dr.softras import SoftRasterizeFunction
-from tests.util import RGBA_ATOL, bits_equal, grad_err, rel_err
+from tests.util import RGBA_ATOL, bits_equal, grad_err, grad_err_elementwise, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -164,3 +164,31 @@ def test_whole_image_one_view_vs_oracle(scene):
     assert rel_err(saved[2][view:view + 1], ref["soft_colors"], RGBA_ATOL) <= 1.0
     assert rel_err(saved[4][view:view + 1], ref["aggrs_info"], RGBA_ATOL) <= 1.0
     assert bits_equal(saved[3][view:view + 1], ref["faces_info"])
+
+
+def test_whole_view_dense_backward_vs_oracle(scene):
+    """VERDICT r2 (weak 2): the sampled backward checks cover a few thousand pixels.  Here the upstream gradient is
+    dense over ONE whole 1024^2 view (view 5, the one whose forward is compared pixel by pixel above) and zero on the
+    other seven; the oracle's backward runs on the GPU's saved tensors of that view.  grad_faces / grad_textures of
+    the view within 1e-4 of the largest gradient (the bar of every gradient test), the element-wise error
+    |a-b| / (|b| + 1e-3 max|b|) reported and held to 1e-3, and exactly zero gradients for the other views."""
+    ctx, fv, tex, fn, saved = scene
+    port = Oracle("port", nthreads=0)
+    view = 5
+    g = np.zeros((B, 4, IS, IS), np.float32)
+    g[view] = np.random.default_rng(17).uniform(-1, 1, (4, IS, IS))
+    gf, gt = fn.grad(g)
+    gf, gt = gf.numpy().reshape(B, NF, 9), gt.numpy()
+    s = dict(face_vertices=saved[0].reshape(B, NF, 9)[view:view + 1], textures=saved[1][view:view + 1],
+             soft_colors=saved[2][view:view + 1], faces_info=saved[3][view:view + 1], aggrs_info=saved[4][view:view + 1],
+             faces_id_buffer=saved[5][view:view + 1], params=dict(image_size=IS, max_faces_per_pixel_for_grad=K))
+    gfo, gto = port.backward(s, g[view:view + 1], nthreads=port.num_procs())
+    e_max, e_el = grad_err(gf[view:view + 1], gfo.reshape(1, NF, 9)), grad_err_elementwise(gf[view:view + 1], gfo.reshape(1, NF, 9))
+    t_max, t_el = grad_err(gt[view:view + 1], gto), grad_err_elementwise(gt[view:view + 1], gto)
+    print("dense backward, view %d: grad_faces max-norm %.3g element-wise(1e-3 floor) %.3g | grad_textures %.3g %.3g"
+          % (view, e_max, e_el, t_max, t_el))
+    assert e_max <= 1e-4 and t_max <= 1e-4
+    assert e_el <= 1e-3 and t_el <= 1e-3
+    others = [v for v in range(B) if v != view]
+    assert np.abs(gf[others]).max() == 0 and np.abs(gt[others]).max() == 0
+    assert (np.abs(gfo) > 0).mean() > 0.2            # the view's gradient is dense, not a corner case

@@ -229,3 +229,38 @@ def test_n3mr_renderer_gradients_textures_and_vertices():
     rgf = rgf[:, :nf] + rgf[:, nf:, ::-1]
     want = r.transform.transformer.backward(face_vertices_backward(rgf, f[None], v.shape[0]), v[None])
     assert grad_err(gv, want) <= 1e-4
+
+
+def test_n3mr_silhouette_and_depth_modes_use_the_module_defaults():
+    """the reference's render_silhouettes / render_depth call rasterize_silhouettes / rasterize_depth
+    with (faces, image_size, anti_aliasing) only (N3R:61-80), i.e. near=0.1, far=100, eps=1e-4 whatever the
+    rasterizer was built with.  A rasterizer with OTHER near / far must give the oracle's default-parameter maps,
+    and its silhouette gradient must be the oracle's at eps=1e-4 (eps enters the backward as dist +/- eps)."""
+    from oracle import N3mrOracle
+    from jrender_amd.renderer.dr.n3mr.rasterizer import N3mrRasterizer
+    from jrender_amd.structures.mesh import face_vertices as v2f
+    v, f = jr.synthetic.sphere_mesh(280)
+    eye = np.asarray(jr.get_points_from_angles(2.732, 25., 30.), np.float32)
+    ndc = jr.perspective(jr.look_at((v * 0.7).astype(np.float32)[None], eye), 30.)
+    S = 32
+    ras = N3mrRasterizer(image_size=S, anti_aliasing=False, near=2.4, far=2.9, fill_back=True)   # would clip half the sphere
+    alpha = ras.render_silhouettes(ndc, f[None])
+    ff = np.concatenate([f, f[:, ::-1]])
+    faces = np.ascontiguousarray(v2f(ndc, ff[None]))
+    o = N3mrOracle()
+    ref = o.forward(faces, None, image_size=S, near=0.1, far=100, eps=1e-4, return_rgb=False, return_alpha=True, return_depth=False)
+    a = alpha.numpy() if hasattr(alpha, "numpy") else np.asarray(alpha)
+    assert np.array_equal(a.reshape(S, S), ref["alpha_map"].reshape(S, S)[::-1])       # functional API flips rows (N3F:243-247)
+    G = np.random.default_rng(5).uniform(-1, 1, a.shape).astype(np.float32)
+    gf, _ = ras.backward(grad_silhouettes=G)
+    ga = np.ascontiguousarray(G.reshape(1, S, S)[:, ::-1])
+    rgf, _ = o.backward(ref, None, ga, None)
+    assert grad_err(gf.numpy().reshape(rgf.shape), rgf) <= 1e-4
+    # eps = 1e-3 (the rasterizer's own) gives a measurably different gradient: the test can tell the two apart
+    ref3 = o.forward(faces, None, image_size=S, near=0.1, far=100, eps=1e-3, return_rgb=False, return_alpha=True, return_depth=False)
+    rgf3, _ = o.backward(ref3, None, ga, None)
+    assert grad_err(rgf3, rgf) > 1e-3
+    depth = ras.render_depth(ndc, f[None])
+    d = depth.numpy() if hasattr(depth, "numpy") else np.asarray(depth)
+    refd = o.forward(faces, None, image_size=S, near=0.1, far=100, eps=1e-4, return_rgb=False, return_alpha=False, return_depth=True)
+    assert np.array_equal(d.reshape(S, S), refd["depth_map"].reshape(S, S)[::-1])

@@ -12,7 +12,7 @@ for v in "$@"; do
   i=0
   for g in "$G1" "$G2"; do
     i=$((i+1))
-    JRENDER_LIB=$lib rocprofv3 --pmc $g -d "$out/${v}_g$i" -o pmc --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$out/${v}_g$i.log" 2>&1
+    JRENDER_LIB=$lib rocprofv3 --pmc $g -d "$out/${v}_g$i" -o pmc --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$out/${v}_g$i.log" 2>&1
     f=$(find "$out/${v}_g$i" -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -A9 "k_softras_forward\|k_softras_backward" > "$out/${v}_g$i.txt"
   done

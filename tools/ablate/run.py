@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: parity + timing of ablation variants, interleaved `rounds` times.
-usage: python tools/ablate/run.py [--rounds 2] [--no-parity] [names...]   -> table on stdout (+ JSON lines)"""
+usage: python tools/ablate/run.py [--rounds 2] [--no-parity | --quick-parity] [names...]   -> table on stdout (+ JSON lines)"""
 import json
 import os
 import subprocess
@@ -29,7 +29,10 @@ for n in names:
         status[n] = "missing"
         continue
     if parity:
-        p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_fullsize.py", "-x", "-q", "-m", "gpu"],
+        # every variant is claimed exactness-equivalent (csrc/jr_tuning.h): the curated parity suite on each, plus the
+        # full-size suite unless --quick-parity (the product build gets the whole `pytest -m gpu` run anyway)
+        files = ["tests/test_gpu_parity.py"] + ([] if "--quick-parity" in args else ["tests/test_gpu_fullsize.py"])
+        p = subprocess.run([sys.executable, "-m", "pytest", *files, "-x", "-q", "-m", "gpu"],
                            cwd=ROOT, env=dict(os.environ, JRENDER_LIB=lib(n)), capture_output=True, text=True)
         status[n] = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "no output"
         if p.returncode:
@@ -40,7 +43,7 @@ for r in range(rounds):
     for n in names:
         if status.get(n) == "missing":
             continue
-        p = subprocess.run([sys.executable, "bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"] + extra, cwd=ROOT,
+        p = subprocess.run([sys.executable, "bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-secondary"] + extra, cwd=ROOT,
                            env=dict(os.environ, JRENDER_LIB=lib(n)), capture_output=True, text=True)
         try:
             d = json.loads(p.stdout.strip().splitlines()[-1])

@@ -2,21 +2,16 @@
 `python tools/ablate/build.py [names...]` builds them next to the product library (CPU box, hipcc);
 `python tools/ablate/run.py [names...]` (GPU box) checks parity and times each one in ONE process
 sequence on ONE box (boxes differ by a few per cent: only numbers from one call are comparable)."""
-OFF = ["JR_TUNE_FWD_BATCH=64", "JR_TUNE_BWD_BATCH=64", "JR_TUNE_FWD_TILE_BOXTEST=1", "JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_IDS_LDS_BIGK=0", "JR_TUNE_FWD_INSIDE_RCP=0"]
+# (the round-1 kernels also tested every listed face's box against the tile: that switch left the tree, patches/dead_switches_r03.patch)
+OFF = ["JR_TUNE_FWD_BATCH=64", "JR_TUNE_BWD_BATCH=64", "JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_INSIDE_RCP=0", "JR_TUNE_FWD_IDS_GLOBAL=0"]
 VARIANTS = {
     "product": [],                                           # the defaults of jr_tuning.h
     "r1": OFF,                                               # every switch off = round-1 kernels
-    "r1_occ4": OFF[:5] + OFF[6:],                            # + the 4-waves-per-SIMD request alone
+    "r1_occ4": OFF[:4] + OFF[5:],                            # + the 4-waves-per-SIMD request alone
     "no_prepass": ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_OCC4=0"],
     "no_dis": ["JR_TUNE_FWD_DIS_ONLY=0"],
-    "tv": ["JR_TUNE_TV_DIVKNOWN=1"],                         # dead: refinement quotient with the stored reciprocal for tv (fwd +0.5 %, bwd +1.2 %)
-    "ids_lds": ["JR_TUNE_FWD_IDS_LDS=1"],                    # dead at K <= 16: K-buffer ids in LDS
-    "bigk_regs": ["JR_TUNE_FWD_IDS_LDS_BIGK=0"],             # K > 16 with ids in registers (round 1)
     "bwd_rcp": ["JR_TUNE_BWD_TV_RCP=1"],                     # dead: breaks the 1e-4 gradient bar
     "no_inside_rcp": ["JR_TUNE_FWD_INSIDE_RCP=0"],
-    "boxtest": ["JR_TUNE_FWD_TILE_BOXTEST=1"],
-    "tpw2": ["JR_TUNE_FWD_TPW=2"],
-    "tpw4": ["JR_TUNE_FWD_TPW=4"],
     "fwd64": ["JR_TUNE_FWD_BATCH=64"],                       # 64 record slots: 14 wavefronts per CU (round 1)
     "fwd48": ["JR_TUNE_FWD_BATCH=48"],
     "bwd64": ["JR_TUNE_BWD_BATCH=64"],                       # 13 wavefronts per CU (round 1)
@@ -38,8 +33,10 @@ VARIANTS = {
     "fwd52": ["JR_TUNE_FWD_BATCH=52"],
     "ids_regs": ["JR_TUNE_FWD_IDS_GLOBAL=0"],                # K-buffer ids in registers (round-2 start)
     "fwd44w5g": ["JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_OCC4=5"],  # with the ids out of the registers: 96 VGPRs, 20 B of scratch outside the trip loop
-    "kbuf_salu": ["JR_TUNE_FWD_KBUF_SALU=1"],
-    "bankmask": ["JR_TUNE_BWD_REDUCE_BANKMASK=1"],          # dead (+2 % bwd): bank-masked DPP adds instead of selects — v_add_f32_dpp costs what v_cndmask costs
+    "no_shift": ["JR_TUNE_FWD_FILL_SHIFT=0"],                # round 3: K-buffer appends by per-lane slot select instead of the register shift
+    "no_defer": ["JR_TUNE_FWD_DEFER_INSIDE=0"],              # round 3: inside pairs evaluated in the main raster loop
+    "no_exp1": ["JR_TUNE_FWD_EXP1=0"],                       # round 3: two v_exp per softmax update
+    "r2fwd": ["JR_TUNE_FWD_FILL_SHIFT=0", "JR_TUNE_FWD_DEFER_INSIDE=0", "JR_TUNE_FWD_EXP1=0"],   # the round-2 forward
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1"],              # instrumented: tools/ablate/sections.py
 }
