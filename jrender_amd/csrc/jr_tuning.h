@@ -35,6 +35,9 @@
 #ifndef JR_TUNE_FWD_EXP1         // forward: one v_exp per softmax update instead of two (the other one is exp(0))
 #define JR_TUNE_FWD_EXP1 1
 #endif
+#ifndef JR_TUNE_FWD_PRIO         // forward: s_setprio(3) for the wavefronts of bins with more than this many listed faces (0 = off)
+#define JR_TUNE_FWD_PRIO 0
+#endif
 #ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
@@ -64,6 +67,7 @@ constexpr bool fwd_ids_global = JR_TUNE_FWD_IDS_GLOBAL != 0;
 constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
 constexpr bool fwd_defer_inside = JR_TUNE_FWD_DEFER_INSIDE != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
+constexpr int fwd_prio = JR_TUNE_FWD_PRIO;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 }  // namespace tune
 }  // namespace jr

@@ -97,6 +97,32 @@ def directional_lighting(diffuseLight, specularLight, normals, light_intensity=0
     return [diffuseLight.astype(F32), specularLight.astype(F32)]
 
 
+def lighting(faces, textures, intensity_ambient=0.5, intensity_directional=0.5, color_ambient=(1, 1, 1),
+             color_directional=(1, 1, 1), direction=(0, 1, 0)):
+    """The legacy functional lighting of NMR cube textures (lighting.py:14-54): faces [B,NF,3,3], textures
+    [B,NF,t,t,t,3] scaled in place by ambient + Lambert light of the face normal (v0-v1) x (v2-v1)."""
+    faces = np.asarray(faces, F32)
+    bs, nf = faces.shape[:2]
+    color_ambient, color_directional = np.asarray(color_ambient, F32), np.asarray(color_directional, F32)
+    direction = np.asarray(direction, F32)
+    if color_ambient.ndim == 1:
+        color_ambient = color_ambient[None]
+    if color_directional.ndim == 1:
+        color_directional = color_directional[None]
+    if direction.ndim == 1:
+        direction = direction[None]
+    light = np.zeros((bs, nf, 3), F32)
+    if intensity_ambient != 0:
+        light = light + F32(intensity_ambient) * color_ambient[:, None]
+    if intensity_directional != 0:
+        f = faces.reshape(bs * nf, 3, 3)
+        normals = _normalize(np.cross(f[:, 0] - f[:, 1], f[:, 2] - f[:, 1]), 1, eps=1e-5).reshape(bs, nf, 3)
+        cos = _relu(np.sum(normals * direction[:, None], axis=2))
+        light = light + F32(intensity_directional) * (color_directional[:, None] * cos[:, :, None])
+    textures *= light[:, :, None, None, None].astype(F32)
+    return textures
+
+
 class AmbientLighting:
     def __init__(self, light_intensity=0.5, light_color=(1, 1, 1)):
         self.light_intensity = light_intensity

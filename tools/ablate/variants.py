@@ -37,6 +37,10 @@ VARIANTS = {
     "no_defer": ["JR_TUNE_FWD_DEFER_INSIDE=0"],              # round 3: inside pairs evaluated in the main raster loop
     "no_exp1": ["JR_TUNE_FWD_EXP1=0"],                       # round 3: two v_exp per softmax update
     "r2fwd": ["JR_TUNE_FWD_FILL_SHIFT=0", "JR_TUNE_FWD_DEFER_INSIDE=0", "JR_TUNE_FWD_EXP1=0"],   # the round-2 forward
+    "prio256": ["JR_TUNE_FWD_PRIO=256", "JR_TUNE_FWD_DEFER_INSIDE=0"],
+    "prio600": ["JR_TUNE_FWD_PRIO=600", "JR_TUNE_FWD_DEFER_INSIDE=0"],
+    "occ3": ["JR_TUNE_FWD_OCC4=3", "JR_TUNE_FWD_DEFER_INSIDE=0"],       # diagnostic: 3 / 2 wavefronts per SIMD in the forward
+    "occ2": ["JR_TUNE_FWD_OCC4=2", "JR_TUNE_FWD_DEFER_INSIDE=0"],
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
-    "sections": ["JR_TUNE_PROFILE_SECTIONS=1"],              # instrumented: tools/ablate/sections.py
+    "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_DEFER_INSIDE=0"],              # instrumented: tools/ablate/sections.py
 }
