@@ -147,7 +147,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     }
 }
 
-// counters: [0] = total pairs (bump pointer), [1] = non-empty bins, [2] = max bin count
+// counters: [0] = total pairs (bump pointer), [1] = non-empty bins, [2] = max bin count, [3] = heavy bins (k_bin_schedule)
 __global__ __launch_bounds__(256) void k_bin_alloc(int nbins_total, const int* __restrict__ bin_count,
                                                    int* __restrict__ bin_base,
                                                    int* __restrict__ bin_cursor,
@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void k_bin_order(int NF, const int* __restrict
 // keeps the tail of the launch short: the list length of a bin varies from 1 to >1000 faces), empty bins
 // last.  One workgroup: histogram over ~12 buckets per octave of the count, descending prefix, scatter.
 __global__ __launch_bounds__(1024) void k_bin_schedule(int nbins_total, const int* __restrict__ bin_count,
-                                                       int* __restrict__ bin_order) {
+                                                       int* __restrict__ bin_order,
+                                                       unsigned long long* __restrict__ counters, int heavy_bucket) {
     __shared__ int s_hist[256], s_start[256];
     auto bucket = [](int n) { return n <= 0 ? 0 : min(255, 1 + (int)(__log2f((float)n) * 12.f)); };
     if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
@@ -276,6 +277,8 @@ __global__ __launch_bounds__(1024) void k_bin_schedule(int nbins_total, const in
         int run = 0;
         for (int b = 255; b > (int)threadIdx.x; b--) run += s_hist[b];
         s_start[threadIdx.x] = run;
+        // the bins of buckets >= heavy_bucket are the first `run + own` ranks of the order: counters[3]
+        if ((int)threadIdx.x == min(heavy_bucket, 255)) counters[3] = heavy_bucket > 255 ? 0ull : (unsigned long long)(run + s_hist[threadIdx.x]);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < nbins_total; t += 1024)
@@ -346,7 +349,7 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, c
     (void)hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * 4, st);
     k_face_setup<<<(nfaces + SETUP_WG - 1) / SETUP_WG, SETUP_WG, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_count);
     k_bin_alloc<<<(nbins + 255) / 256, 256, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.counters);
-    k_bin_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_order);
+    k_bin_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_order, ws.counters, heavy_bucket());
 }
 
 // Every kernel here is guarded by "total pairs <= pool capacity" read from device memory, so that the

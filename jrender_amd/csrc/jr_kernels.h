@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libjrender_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "softras_device.h"
@@ -15,11 +16,20 @@ struct BinWorkspace {
     int* bin_base = nullptr;                   // [B*bins] segment start in pool
     int* bin_cursor = nullptr;                 // [B*bins]
     int* bin_order = nullptr;                  // [B*bins] launch rank -> bin, heaviest list first
-    unsigned long long* counters = nullptr;    // [4] device: total pairs, non-empty bins, max count
+    unsigned long long* counters = nullptr;    // [4] device: total pairs, non-empty bins, max count, heavy bins (a prefix of bin_order)
     unsigned long long* pool = nullptr;        // [pool_cap] (face id << 32 | tile mask), per bin ascending
     unsigned long long* pool_scratch = nullptr;// [pool_cap] the same segments as filled (unordered)
     size_t faces_cap = 0, bins_cap = 0, pool_cap = 0;
 };
+
+// Launch order of the bins (k_bin_schedule): ~12 buckets per octave of the list length, heaviest first.  Bins in
+// buckets >= heavy_bucket() are the "heavy" prefix of the order (counters[3]) that the forward gives four
+// wavefronts per tile; every one of them lists at least fwd_heavy_floor() faces.
+inline int heavy_bucket() { return tune::fwd_heavy > 0 ? 1 + (int)(log2f((float)tune::fwd_heavy) * 12.f) : 1 << 30; }
+inline int fwd_heavy_floor() {
+    const int f = (int)(exp2f((float)(heavy_bucket() - 1) / 12.f) * 0.98f);
+    return f > 1 ? f : 1;
+}
 
 void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, const float* textures,
                     float* faces_info, BinWorkspace& ws);

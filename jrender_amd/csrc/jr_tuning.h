@@ -17,26 +17,42 @@
 #ifndef JR_TUNE_FWD_INSIDE_RCP   // forward: 2nd / 3rd edge projection of INSIDE pixels (colour path only) by reciprocal multiply
 #define JR_TUNE_FWD_INSIDE_RCP 1
 #endif
-#ifndef JR_TUNE_FWD_BATCH        // forward: faces per batch (LDS record slots per wavefront), <= 64; 56 x 176 B = 9.6 KB -> 16 wavefronts per CU
-#define JR_TUNE_FWD_BATCH 56
+#ifndef JR_TUNE_FWD_BATCH        // forward, one wavefront per tile: faces per batch (LDS record slots per wavefront), <= 64; 46 x 176 B = 8 KB -> 20 wavefronts per CU
+#define JR_TUNE_FWD_BATCH 46
+#endif
+#ifndef JR_TUNE_FWD_BATCH_MIXED  // forward, four-wavefront workgroups: record slots per tile (56 x 176 B x 4 = 38.5 KB per workgroup -> 16 wavefronts per CU)
+#define JR_TUNE_FWD_BATCH_MIXED 56
 #endif
 #ifndef JR_TUNE_FWD_IDS_GLOBAL   // forward: K-buffer ids are stored straight into faces_id_buffer at every insert instead of living in registers
 #define JR_TUNE_FWD_IDS_GLOBAL 1
 #endif
-#ifndef JR_TUNE_FWD_OCC4         // forward: wavefronts per SIMD asked of the register allocator (1 = 4 at K <= 32 and 3 at K <= 64; > 1 = that many; 0 = none)
-#define JR_TUNE_FWD_OCC4 1
+#ifndef JR_TUNE_FWD_WAVES16      // forward, one wavefront per tile, K <= 16: wavefronts per SIMD asked of the register allocator (5 -> 96 VGPRs, no scratch)
+#define JR_TUNE_FWD_WAVES16 5
 #endif
 #ifndef JR_TUNE_FWD_FILL_SHIFT   // forward: K-buffer appends shift the depth registers (KCAP v_mov) instead of writing a per-lane slot (KCAP v_cmp + v_cndmask)
 #define JR_TUNE_FWD_FILL_SHIFT 1
 #endif
-#ifndef JR_TUNE_FWD_DEFER_INSIDE // forward: inside pairs do their coverage-dependent part (3 edge projections, alpha, softmax) in a second loop per batch
-#define JR_TUNE_FWD_DEFER_INSIDE 1
+#ifndef JR_TUNE_FWD_DEFER_INSIDE // single-wavefront tiles: inside pairs do their coverage-dependent part (3 edge projections, alpha, softmax) in a second loop per batch
+                                 // (measured r03: VALU instructions -6.7 %, time +2.6 % at B = 8 and +0.6 % at B = 32: off)
+#define JR_TUNE_FWD_DEFER_INSIDE 0
 #endif
 #ifndef JR_TUNE_FWD_EXP1         // forward: one v_exp per softmax update instead of two (the other one is exp(0))
 #define JR_TUNE_FWD_EXP1 1
 #endif
+#ifndef JR_TUNE_FWD_HEAVY        // forward: bins whose list is longer than this get FOUR wavefronts per tile (evaluate / apply split); 0 = one wavefront per tile everywhere
+#define JR_TUNE_FWD_HEAVY 512
+#endif
+#ifndef JR_TUNE_FWD_HEAVY_PIXELS // forward: launches of up to this many pixels (B x IS x IS) use the four-wavefront kernel, larger ones one wavefront per tile
+#define JR_TUNE_FWD_HEAVY_PIXELS 4194304
+#endif
+#ifndef JR_TUNE_FWD_HEAVY_SORTED // forward, heavy tiles, K <= 16: K-buffer kept in depth order (v_med3 insertion, slot labels in 16 nibbles) instead of slot order
+#define JR_TUNE_FWD_HEAVY_SORTED 1
+#endif
 #ifndef JR_TUNE_FWD_PRIO         // forward: s_setprio(3) for the wavefronts of bins with more than this many listed faces (0 = off)
 #define JR_TUNE_FWD_PRIO 0
+#endif
+#ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert
+#define JR_TUNE_DIAG 0
 #endif
 #ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
 #define JR_TUNE_BWD_TV_RCP 0
@@ -63,11 +79,16 @@ constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
 constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
+constexpr int fwd_batch_mixed = JR_TUNE_FWD_BATCH_MIXED;
+constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
+constexpr long fwd_heavy_pixels = JR_TUNE_FWD_HEAVY_PIXELS;
 constexpr bool fwd_ids_global = JR_TUNE_FWD_IDS_GLOBAL != 0;
 constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
 constexpr bool fwd_defer_inside = JR_TUNE_FWD_DEFER_INSIDE != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_prio = JR_TUNE_FWD_PRIO;
+constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY;
+constexpr bool fwd_heavy_sorted = JR_TUNE_FWD_HEAVY_SORTED != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 }  // namespace tune
 }  // namespace jr

@@ -27,6 +27,8 @@
 // distance cull, clipped depth, depth cull, K-buffer) reproduces the reference bit for bit.  The
 // colour path (coverage sigmoid, softmax weights) only has to stay within 1e-4 and uses
 // reciprocal multiplies where the reference divides by sigma / gamma (error <= 1-2 ulp).
+#include <stdlib.h>
+
 #include "jr_kernels.h"
 
 namespace jr {
@@ -103,6 +105,7 @@ struct KBuffer {
     // full (tracking the first largest depth), afterwards overwrite the largest-depth slot
     // when strictly nearer and rescan, first maximum wins.
     __device__ inline void insert(int fn, float zp, int K) {
+        if (JR_TUNE_DIAG & 2) return;      // diagnostic builds only (empty index buffer): what does the K-buffer cost?
         const bool filling = size < K;
         if (!filling && !(zp < max_z)) return;
         const int slot = filling ? size : max_slot;
@@ -165,6 +168,7 @@ template <bool FAST, int KCAP>
 __device__ inline void softmax_accumulate(const RasterParams& p, const FaceRec& r, const float* vc,
                                           const float* __restrict__ tbase, const Bary& wc, float zp, float D,
                                           PixelState<KCAP>& s) {
+    if (JR_TUNE_DIAG & 1) return;          // diagnostic builds only (wrong colours): what does the softmax update cost?
     // zn must carry the reference's exact bits: the softmax divides differences of it by gamma
     const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
     float ed, ez;
@@ -291,78 +295,134 @@ __device__ inline void forward_pair_inside(const RasterParams& p, const FaceRec&
     }
 }
 
-// wavefronts per SIMD asked of the register allocator: K <= 16 and K <= 32 fit 128 VGPRs (4), K <= 64 fits 168 (3)
-constexpr int fwd_waves(int kcap) { return JR_TUNE_FWD_OCC4 > 1 ? JR_TUNE_FWD_OCC4 : (JR_TUNE_FWD_OCC4 ? (kcap <= 32 ? 4 : 3) : 1); }
-template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP)))) void k_softras_forward(
-    RasterParams p, int ntiles_total, const float* __restrict__ textures,
-    const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
-    const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
-    unsigned long long* __restrict__ counters, unsigned long long pool_cap,
-    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
-    extern __shared__ float4 s_dyn[];
-    if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
-    constexpr int BATCH = tune::fwd_batch;       // record slots per wavefront (64 x 176 B cap a CU at 14 wavefronts)
-    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
-    float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
+// wavefronts per SIMD asked of the register allocator: K <= 16: the single-wavefront kernel fits 96 VGPRs (5), the
+// four-wavefront one 128 (4); K <= 32: 168 (3); K <= 64: 256 (2) - all without scratch
+constexpr int fwd_waves(int kcap, bool mixed) {
+    return kcap <= 16 ? (mixed ? 4 : tune::fwd_waves16) : (kcap <= 32 ? 3 : 2);
+}
 
-    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
-    // bin (same list, same records) go to ONE XCD so that they share its L2.
-    const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
-    const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
-    if (brank * 16 >= ntiles_total) return;
-    const int bin = bin_order[brank];                    // ... heaviest first (k_bin_schedule)
-    const int sub = k & 15;                              // tile of the bin
+// LDS hand-over inside ONE wavefront (writes by some lanes, reads by others): LDS instructions of a wavefront
+// execute in order, so only the compiler has to be kept from moving accesses across this point.  WAVE_IS_WG: the
+// workgroup is a single wavefront and __syncthreads() is the same thing (the round-2 kernel).
+template <bool WAVE_IS_WG>
+__device__ inline void wave_sync() {
+    if (WAVE_IS_WG) __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// What a tile's wavefront knows about its place: the bin, the image, the pixel of this lane.
+struct TileGeom {
+    int b, bin, sub, n;                 // image, bin, tile of the bin (0..15), listed faces of the bin
+    int col, row; bool valid;           // this lane's pixel
+    float xp, yp;                       // its centre in NDC (SRK:280-283)
+};
+
+__device__ inline bool tile_geom(const RasterParams& p, int bin, int sub, int n, int lane, TileGeom& t) {
     const int bins_per_img = p.bins_x * p.bins_y;
-    const int b = bin / bins_per_img;
-    const int bb = bin - b * bins_per_img;
+    t.bin = bin; t.sub = sub; t.n = n;
+    t.b = bin / bins_per_img;
+    const int bb = bin - t.b * bins_per_img;
     const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
-    const int n = bin_count[bin];
-    // tune::fwd_prio: the wavefronts of the heaviest bins are the kernel's critical path (one 39k-face view alone takes
-    // 0.70 ms, eight take 0.88): they get issue priority over the lighter wavefronts they share a SIMD with
-    if (tune::fwd_prio > 0 && n > tune::fwd_prio) __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x, lx = lane & 7, ly = lane >> 3;
-    SectionClock clk;            // instrumented builds only: 0 set-up, 1 cull + stage, 2 ballots + pre-cull, 3 raster loop, 4 stores
-    clk.start();
     const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
-    if (col0 >= p.IS || row0 >= p.IS) return;            // tile lies outside the image
-    const int col = col0 + lx, row = row0 + ly;
-    const bool valid = col < p.IS && row < p.IS;
-    const float xp = pixel_centre(col, p.IS);
-    const float yp = pixel_centre(p.IS - 1 - row, p.IS);                      // SRK:280-283
-    // the tile's 8 column / 8 row centres are the xp of lanes 0..7 and the yp of lanes 0,8,..,56:
-    // read them with v_readlane where they are used instead of pinning 16 SGPRs over the raster loop
-    auto xc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xp), c)); };
-    auto yc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yp), 8 * c)); };
+    if (col0 >= p.IS || row0 >= p.IS) return false;      // tile lies outside the image
+    t.col = col0 + (lane & 7); t.row = row0 + (lane >> 3);
+    t.valid = t.col < p.IS && t.row < p.IS;
+    t.xp = pixel_centre(t.col, p.IS);
+    t.yp = pixel_centre(p.IS - 1 - t.row, p.IS);
+    return true;
+}
 
-    PixelState<KCAP> s;
-    s.c0 = 1.f; s.c1 = 1.f; s.c2 = 1.f;
+template <int RGB, int KCAP>
+__device__ inline void init_colour_state(const RasterParams& p, PixelState<KCAP>& s) {
+    s.c0 = 1.f; s.c1 = 1.f; s.c2 = 1.f;                                       // SRK:291-309
     s.alpha = p.alpha == 2 ? 1.f : 0.f;
     s.ssum = expf(p.eps / p.gamma); s.smax = p.eps;
     if (RGB == 0) { s.c0 = p.bg[0]; s.c1 = p.bg[1]; s.c2 = p.bg[2]; }
     else if (RGB == 1) { s.c0 = p.bg[0] * s.ssum; s.c1 = p.bg[1] * s.ssum; s.c2 = p.bg[2] * s.ssum; }
     s.depth_min = 10000000.f;
     s.face_min = -1;
-    s.q.init(p.K, ids + (size_t)b * p.K * p.IS * p.IS, valid ? (unsigned)(row * p.IS + col) : 0u, (unsigned)(p.IS * p.IS));
+}
+template <class KB>
+__device__ inline void init_kbuffer(const RasterParams& p, const TileGeom& t, int32_t* __restrict__ ids, KB& q) {
+    q.init(p.K, ids + (size_t)t.b * p.K * p.IS * p.IS, t.valid ? (unsigned)(t.row * p.IS + t.col) : 0u, (unsigned)(p.IS * p.IS));
+}
+template <int RGB, int KCAP>
+__device__ inline void init_pixel_state(const RasterParams& p, const TileGeom& t, int32_t* __restrict__ ids, PixelState<KCAP>& s) {
+    init_colour_state<RGB>(p, s);
+    init_kbuffer(p, t, ids, s.q);
+}
 
-    const unsigned long long* seg = pool + bin_base[bin];
-    const FaceGeo* gbase = geo + (size_t)b * p.NF;
-    const float* tbase = textures + (size_t)b * p.NF * p.T * 3;
+// ---- finalise (SRK:426-455): colour planes / K-buffer planes (two wavefronts hold the two halves of a heavy tile's state) ----
+template <int RGB, int KCAP>
+__device__ inline void store_colour(const RasterParams& p, const TileGeom& t, const PixelState<KCAP>& s,
+                                    float* __restrict__ aggrs, float* __restrict__ rgba) {
+    if (!t.valid) return;
+    const size_t pp = (size_t)p.IS * p.IS;
+    const size_t pn = (size_t)t.row * p.IS + t.col;
+    float a_out;
+    if (p.alpha == 0) a_out = s.alpha;
+    else if (p.alpha == 1) a_out = s.alpha / p.NF;
+    else a_out = (float)(1. - (double)s.alpha);
+    float o0 = p.bg[0], o1 = p.bg[1], o2 = p.bg[2], g0 = 0.f, g1 = 0.f;
+    if (RGB == 0) {
+        if (s.face_min != -1) { o0 = s.c0; o1 = s.c1; o2 = s.c2; }
+        g0 = s.depth_min; g1 = (float)s.face_min;
+    } else if (RGB == 1) {
+        o0 = s.c0 / s.ssum; o1 = s.c1 / s.ssum; o2 = s.c2 / s.ssum;
+        g0 = s.ssum; g1 = s.smax;
+    }
+    float* out = rgba + (size_t)t.b * 4 * pp + pn;
+    out[0] = o0; out[pp] = o1; out[2 * pp] = o2; out[3 * pp] = a_out;
+    float* ag = aggrs + (size_t)t.b * 2 * pp + pn;
+    ag[0] = g0; ag[pp] = g1;
+}
+template <int KCAP, bool WRITTEN_THROUGH, class KB>
+__device__ inline void store_ids(const RasterParams& p, const TileGeom& t, const KB& q, int32_t* __restrict__ ids) {
+    if (!t.valid) return;
+    const size_t pp = (size_t)p.IS * p.IS;
+    int32_t* io = ids + (size_t)t.b * p.K * pp + (size_t)t.row * p.IS + t.col;
+#pragma unroll
+    for (int k = 0; k < KCAP; k++)
+        if (k < p.K) {
+            if (!WRITTEN_THROUGH) io[(size_t)k * pp] = q.id_of(k);
+            else if (k >= q.size) io[(size_t)k * pp] = -1;           // the filled slots were stored when they were filled
+        }
+}
+template <int RGB, int KCAP>
+__device__ inline void store_pixel(const RasterParams& p, const TileGeom& t, const PixelState<KCAP>& s,
+                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    store_colour<RGB>(p, t, s, aggrs, rgba);
+    store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+}
 
-    // The bin's list is walked 64 entries at a time, but only a fraction of them concerns THIS tile.
-    // Survivors are compacted (ascending order kept) into the 64 LDS slots across list chunks and the
-    // raster loop only runs on a full batch: its trip count is the MAXIMUM number of faces any pixel
-    // needs, and max/mean over 64 lanes shrinks with the batch (measured: 17 survivors per list chunk
-    // -> 64 per batch), and the per-batch ballots are paid 4x less often.
-    clk.lap(0);
-    int s0 = 0, fill = 0, cnt = 0;
-    bool pending = false, keep = false;
-    const FaceGeo* gp = gbase;
-    int rank = 0;                                   // of this lane's entry among the chunk's survivors
-    // the list is read one chunk AHEAD of its use (the entry load is the head of a chain of dependent loads)
-    unsigned long long e_next = lane < n ? seg[lane] : 0ull;
-    for (;;) {
-        // ---- cull + stage: lane = list entry ----
+// ---- cull + stage: lane = list entry ------------------------------------------------------------------------
+// The bin's list is walked 64 entries at a time, but only a fraction of them concerns THIS tile.
+// Survivors are compacted (ascending order kept) into the LDS record slots across list chunks and the
+// raster only runs on a full batch: its trip count is the MAXIMUM number of faces any pixel
+// needs, and max/mean over 64 lanes shrinks with the batch (measured: 17 survivors per list chunk
+// -> 56 per batch), and the per-batch ballots are paid 4x less often.
+struct ListWalker {
+    const unsigned long long* seg;
+    const FaceGeo* gbase;
+    const float* tbase;
+    int n, sub, s0, cnt, rank;
+    bool pending, keep;
+    const FaceGeo* gp;
+    unsigned long long e_next;          // the list is read one chunk AHEAD of its use (head of a chain of dependent loads)
+
+    __device__ inline void start(const unsigned long long* seg_, const FaceGeo* gbase_, const float* tbase_, int n_, int sub_, int lane) {
+        seg = seg_; gbase = gbase_; tbase = tbase_; n = n_; sub = sub_;
+        s0 = 0; cnt = 0; rank = 0; pending = false; keep = false; gp = gbase_;
+        e_next = lane < n ? seg[lane] : 0ull;
+    }
+    // fills record slots [0, fill) of the next batch; 0 = the list is exhausted
+    template <int BATCH>
+    __device__ inline int stage(const RasterParams& p, FaceRec* s_rec, float* s_vcol, int lane) {
+        int fill = 0;
         while (pending || s0 < n) {
             if (!pending) {
                 const unsigned long long e = e_next;
@@ -371,10 +431,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
                 // The entry's tile mask is exact per axis (binning.hip: pixel_range), i.e. the face's border box
                 // reaches a pixel column AND a pixel row of this tile: no box load, no second test here.
                 keep = (e >> sub) & 1ull;
-                if (!ballot(keep)) continue;        // no face of this chunk touches this tile
-                gp = gbase + (int)(e >> 32);
                 const unsigned long long surv = ballot(keep);
-                if (!surv) continue;
+                if (!surv) continue;                // no face of this chunk touches this tile
+                gp = gbase + (int)(e >> 32);
                 cnt = __builtin_popcountll(surv);
                 rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(surv >> 32),
                                                       __builtin_amdgcn_mbcnt_lo((unsigned)surv, 0u));
@@ -403,183 +462,638 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
                 break;
             }
         }
-        if (fill == 0) break;
-        __syncthreads();
-        clk.lap(1);
+        return fill;
+    }
+};
 
+// ---- ballots + pre-cull: lane = slot -> per-pixel masks of the batch's faces ---------------------------------
+// Rows [R0, R1) of the tile: the lanes of those rows get the mask of THEIR pixel (the other lanes' result is
+// meaningless when the pre-cull runs); a single wavefront asks for all 8 rows, the wavefronts of a heavy tile
+// for two rows each.
+template <int DIST, int R0, int R1>
+__device__ inline unsigned long long pixel_masks(const RasterParams& p, const FaceRec* s_rec, int fill, int lane,
+                                                 float xp, float yp) {
+    // the tile's 8 column / 8 row centres are the xp of lanes 0..7 and the yp of lanes 0,8,..,56:
+    // read them with v_readlane where they are used instead of pinning 16 SGPRs over the raster loop
+    auto xc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xp), c)); };
+    auto yc = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yp), 8 * c)); };
+    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool have = lane < fill;
+    if (have) box = *reinterpret_cast<const float4*>(&s_rec[lane]);
+    constexpr bool PRE = DIST == 2 && tune::fwd_prepass;
+    unsigned long long cx[8], ry[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        // check_border (SRK:28-34, :316): a pixel is culled when strictly outside the grown box
+        cx[c] = ballot(have && !(xc(c) > box.y) && !(xc(c) < box.x));
+        if (!PRE || (c >= R0 && c < R1)) ry[c] = ballot(have && !(yc(c) > box.w) && !(yc(c) < box.z));
+    }
+    if (!PRE) return select8(cx, lane & 7) & select8(ry, lane >> 3);
+    // Conservative pre-cull, lane = slot.  A pixel that lies more than the cull radius beyond the
+    // LINE of one edge (on its outer side) is farther than the radius from the triangle, and the
+    // reference culls that pair by distance (SRK:341-342) before it touches any state.  With w_k
+    // the barycentric of vertex k (affine in the pixel, |grad w_k| = g_k = 1 / altitude_k) the test is
+    //     w_k(pixel) < -g_k * (rad + margin)     for some k,
+    // evaluated for the face of this lane at the pixel centres: 5 VALU per pixel, and the v_cmp
+    // result IS the 64-face reject mask of that pixel.
+    // The margin covers what the reference's float arithmetic can make of the distance, which this
+    // test does not reproduce ("pre-cull margin"; measured with tools/sim/precull_noise.py
+    // on 10^7 kept pairs: the reference's distance falls short of the geometric one by at most 0.91 E):
+    //   E1: face_inv is star/det with ONE rounded det, so the three w_k sum to 1 + delta instead of 1 and
+    //       the reference effectively measures from the pixel displaced by (a x + b y + c - 1) * position,
+    //       a, b, c = column sums of face_inv;
+    //   E2: rounding of w_k itself (3 eps S_k per weight, S_k = |inv0| X + |inv1| Y + |inv2|) times the
+    //       vertex positions, and of the three products that form the offset vector.
+    // margin = 2.5 (E1 + E2) + 1e-4 rad; a face whose margin would exceed rad / 2, or that is outside the
+    // fast-arithmetic range, never rejects.  Survivors run the exact arithmetic as before: the pre-cull
+    // can only remove work, never change a result.
+    float gx[3], gy[3], cc[3];
+    {
+        const FaceRec& me = s_rec[have ? lane : 0];
+        constexpr float EPS = 5.9604645e-08f;     // 2^-24
+        const float X = fmaxf(fabsf(box.x), fabsf(box.y)), Y = fmaxf(fabsf(box.z), fabsf(box.w));
+        const float pos = __builtin_sqrtf(__builtin_fmaf(X, X, Y * Y));
+        const float ext = (box.y - box.x) + (box.w - box.z);
+        const float* vx = &me.x0;
+        float g[3], gmax = 0.f, ssum = 0.f, sv = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            gx[q] = me.inv[3 * q]; gy[q] = me.inv[3 * q + 1];
+            g[q] = __builtin_sqrtf(__builtin_fmaf(gx[q], gx[q], gy[q] * gy[q]));
+            gmax = fmaxf(gmax, g[q]);
+            const float S = __builtin_fmaf(fabsf(gx[q]), X, __builtin_fmaf(fabsf(gy[q]), Y, fabsf(me.inv[3 * q + 2])));
+            ssum += S;
+            sv = __builtin_fmaf(S, __builtin_sqrtf(__builtin_fmaf(vx[2 * q], vx[2 * q], vx[2 * q + 1] * vx[2 * q + 1])), sv);
+        }
+        const float ca = fabsf((gx[0] + gx[1]) + gx[2]), cb = fabsf((gy[0] + gy[1]) + gy[2]);
+        const float cd = fabsf(((me.inv[2] + me.inv[5]) + me.inv[8]) - 1.f);
+        const float e1 = (__builtin_fmaf(ca, X, __builtin_fmaf(cb, Y, cd)) + 4.f * EPS * ssum) * pos;
+        const float e2 = 3.f * EPS * sv + 4.f * EPS * __builtin_fmaf(gmax, ext, 1.f) * pos;
+        const float margin = __builtin_fmaf(2.5f, e1 + e2, 1.0001f * p.rad);
+        // NaN anywhere makes the comparison false -> never rejects
+        const bool ok = have && face_safe(me.meta) && p.consts_safe && (margin <= 1.5f * p.rad);
+#pragma unroll
+        for (int q = 0; q < 3; q++) cc[q] = __builtin_fmaf(margin, g[q], me.inv[3 * q + 2]);
+        if (!ok) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) { gx[q] = 0.f; gy[q] = 0.f; cc[q] = 1.f; }
+        }
+    }
+    int mlo = 0, mhi = 0;
+#pragma unroll
+    for (int rr = R0; rr < R1; rr++) {
+        const float yq = yc(rr);
+        const float b0 = __builtin_fmaf(gy[0], yq, cc[0]), b1 = __builtin_fmaf(gy[1], yq, cc[1]),
+                    b2 = __builtin_fmaf(gy[2], yq, cc[2]);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float xq = xc(c);
+            const float smin = __builtin_fminf(__builtin_fminf(__builtin_fmaf(gx[0], xq, b0), __builtin_fmaf(gx[1], xq, b1)),
+                                               __builtin_fmaf(gx[2], xq, b2));
+            const unsigned long long keep = cx[c] & ry[rr] & ~ballot(smin < 0.f);
+            // v_writelane_b32: the wave-uniform mask goes into lane (rr, c) of the mask registers
+            // (clang has no builtin for it)
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((int)(unsigned)keep), "n"(rr * 8 + c));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((int)(unsigned)(keep >> 32)), "n"(rr * 8 + c));
+        }
+    }
+    return ((unsigned long long)(unsigned)mhi << 32) | (unsigned)mlo;
+}
+
+// ---- one tile by ONE wavefront: lane = pixel pops the bits of its private face mask (round 1 / 2 organisation) ----
+template <int DIST, int RGB, int KCAP, int BATCH, bool WAVE_IS_WG>
+__device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int lane, float4* s_mem,
+                                   const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
+                                   const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
+                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                        // [BATCH] record slots of this wavefront
+    float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
+    SectionClock clk;            // instrumented builds only: 0 set-up, 1 cull + stage, 2 ballots + pre-cull, 3 raster loop, 4 stores
+    clk.start();
+    const float xp = t.xp, yp = t.yp;
+    PixelState<KCAP> s;
+    init_pixel_state<RGB>(p, t, ids, s);
+    const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
+    ListWalker lw;
+    lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
+    clk.lap(0);
+    for (;;) {
+        const int fill = lw.stage<BATCH>(p, s_rec, s_vcol, lane);
+        if (fill == 0) break;
+        wave_sync<WAVE_IS_WG>();
+        clk.lap(1);
         // ---- raster: lane = slot for the ballots, then lane = pixel ----
-        {
-            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool have = lane < fill;
-            if (have) box = *reinterpret_cast<const float4*>(&s_rec[lane]);
-            unsigned long long cx[8], ry[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                // check_border (SRK:28-34, :316): a pixel is culled when strictly outside the grown box
-                cx[c] = ballot(have && !(xc(c) > box.y) && !(xc(c) < box.x));
-                ry[c] = ballot(have && !(yc(c) > box.w) && !(yc(c) < box.z));
-            }
-            // private mask of the faces that pass this pixel's border test
-            unsigned long long M;
-            if (DIST == 2 && tune::fwd_prepass) {
-                // Conservative pre-cull, lane = slot.  A pixel that lies more than the cull radius beyond the
-                // LINE of one edge (on its outer side) is farther than the radius from the triangle, and the
-                // reference culls that pair by distance (SRK:341-342) before it touches any state.  With w_k
-                // the barycentric of vertex k (affine in the pixel, |grad w_k| = g_k = 1 / altitude_k) the test is
-                //     w_k(pixel) < -g_k * (rad + margin)     for some k,
-                // evaluated for the face of this lane at all 64 pixel centres: 5 VALU per pixel, and the v_cmp
-                // result IS the 64-face reject mask of that pixel.
-                // The margin covers what the reference's float arithmetic can make of the distance, which this
-                // test does not reproduce ("pre-cull margin"; measured with tools/sim/precull_noise.py
-                // on 10^7 kept pairs: the reference's distance falls short of the geometric one by at most 0.91 E):
-                //   E1: face_inv is star/det with ONE rounded det, so the three w_k sum to 1 + delta instead of 1 and
-                //       the reference effectively measures from the pixel displaced by (a x + b y + c - 1) * position,
-                //       a, b, c = column sums of face_inv;
-                //   E2: rounding of w_k itself (3 eps S_k per weight, S_k = |inv0| X + |inv1| Y + |inv2|) times the
-                //       vertex positions, and of the three products that form the offset vector.
-                // margin = 2.5 (E1 + E2) + 1e-4 rad; a face whose margin would exceed rad / 2, or that is outside the
-                // fast-arithmetic range, never rejects.  Survivors run the exact arithmetic as before: the pre-cull
-                // can only remove work, never change a result.
-                float gx[3], gy[3], cc[3];
-                {
-                    const FaceRec& me = s_rec[have ? lane : 0];
-                    constexpr float EPS = 5.9604645e-08f;     // 2^-24
-                    const float X = fmaxf(fabsf(box.x), fabsf(box.y)), Y = fmaxf(fabsf(box.z), fabsf(box.w));
-                    const float pos = __builtin_sqrtf(__builtin_fmaf(X, X, Y * Y));
-                    const float ext = (box.y - box.x) + (box.w - box.z);
-                    const float* vx = &me.x0;
-                    float g[3], gmax = 0.f, ssum = 0.f, sv = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        gx[q] = me.inv[3 * q]; gy[q] = me.inv[3 * q + 1];
-                        g[q] = __builtin_sqrtf(__builtin_fmaf(gx[q], gx[q], gy[q] * gy[q]));
-                        gmax = fmaxf(gmax, g[q]);
-                        const float S = __builtin_fmaf(fabsf(gx[q]), X, __builtin_fmaf(fabsf(gy[q]), Y, fabsf(me.inv[3 * q + 2])));
-                        ssum += S;
-                        sv = __builtin_fmaf(S, __builtin_sqrtf(__builtin_fmaf(vx[2 * q], vx[2 * q], vx[2 * q + 1] * vx[2 * q + 1])), sv);
-                    }
-                    const float ca = fabsf((gx[0] + gx[1]) + gx[2]), cb = fabsf((gy[0] + gy[1]) + gy[2]);
-                    const float cd = fabsf(((me.inv[2] + me.inv[5]) + me.inv[8]) - 1.f);
-                    const float e1 = (__builtin_fmaf(ca, X, __builtin_fmaf(cb, Y, cd)) + 4.f * EPS * ssum) * pos;
-                    const float e2 = 3.f * EPS * sv + 4.f * EPS * __builtin_fmaf(gmax, ext, 1.f) * pos;
-                    const float margin = __builtin_fmaf(2.5f, e1 + e2, 1.0001f * p.rad);
-                    // NaN anywhere makes the comparison false -> never rejects
-                    const bool ok = have && face_safe(me.meta) && p.consts_safe && (margin <= 1.5f * p.rad);
-#pragma unroll
-                    for (int q = 0; q < 3; q++) cc[q] = __builtin_fmaf(margin, g[q], me.inv[3 * q + 2]);
-                    if (!ok) {
-#pragma unroll
-                        for (int q = 0; q < 3; q++) { gx[q] = 0.f; gy[q] = 0.f; cc[q] = 1.f; }
-                    }
-                }
-                int mlo = 0, mhi = 0;
-#pragma unroll
-                for (int rr = 0; rr < 8; rr++) {
-                    const float yq = yc(rr);
-                    const float b0 = __builtin_fmaf(gy[0], yq, cc[0]), b1 = __builtin_fmaf(gy[1], yq, cc[1]),
-                                b2 = __builtin_fmaf(gy[2], yq, cc[2]);
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const float xq = xc(c);
-                        const float smin = __builtin_fminf(__builtin_fminf(__builtin_fmaf(gx[0], xq, b0), __builtin_fmaf(gx[1], xq, b1)),
-                                                           __builtin_fmaf(gx[2], xq, b2));
-                        const unsigned long long keep = cx[c] & ry[rr] & ~ballot(smin < 0.f);
-                        // v_writelane_b32: the wave-uniform mask goes into lane (rr, c) of the mask registers
-                        // (clang has no builtin for it)
-                        asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((int)(unsigned)keep), "n"(rr * 8 + c));
-                        asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((int)(unsigned)(keep >> 32)), "n"(rr * 8 + c));
-                    }
-                }
-                M = valid ? (((unsigned long long)(unsigned)mhi << 32) | (unsigned)mlo) : 0ull;
-            } else {
-                M = valid ? (select8(cx, lx) & select8(ry, ly)) : 0ull;
-            }
-            clk.lap(2);
-            unsigned long long Mdef = 0ull;        // this pixel's deferred (inside) pairs of the batch
-            while (M) {
-                const int j = __builtin_ctzll(M);
-                const unsigned long long rest = M & (M - 1);
+        unsigned long long M = pixel_masks<DIST, 0, 8>(p, s_rec, fill, lane, xp, yp);   // the faces that pass this pixel's border test (and pre-cull)
+        if (!t.valid) M = 0ull;
+        clk.lap(2);
+        unsigned long long Mdef = 0ull;        // this pixel's deferred (inside) pairs of the batch
+        while (M) {
+            const int j = __builtin_ctzll(M);
+            const unsigned long long rest = M & (M - 1);
+            const FaceRec& r = s_rec[j];
+            const float* vc = s_vcol + j * 9;
+            bool deferred;
+            if (face_safe(r.meta) && p.consts_safe)
+                deferred = forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
+            else
+                deferred = forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
+            if (DIST == 2 && tune::fwd_defer_inside && deferred) Mdef |= M ^ rest;
+            M = rest;
+        }
+        if (DIST == 2 && tune::fwd_defer_inside) {
+            while (Mdef) {
+                const int j = __builtin_ctzll(Mdef);
+                Mdef &= Mdef - 1;
                 const FaceRec& r = s_rec[j];
                 const float* vc = s_vcol + j * 9;
-                bool deferred;
                 if (face_safe(r.meta) && p.consts_safe)
-                    deferred = forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
+                    forward_pair_inside<RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
                 else
-                    deferred = forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
-                if (DIST == 2 && tune::fwd_defer_inside && deferred) Mdef |= M ^ rest;
-                M = rest;
-            }
-            if (DIST == 2 && tune::fwd_defer_inside) {
-                while (Mdef) {
-                    const int j = __builtin_ctzll(Mdef);
-                    Mdef &= Mdef - 1;
-                    const FaceRec& r = s_rec[j];
-                    const float* vc = s_vcol + j * 9;
-                    if (face_safe(r.meta) && p.consts_safe)
-                        forward_pair_inside<RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
-                    else
-                        forward_pair_inside<RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
-                }
+                    forward_pair_inside<RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
             }
         }
-        fill = 0;
-        __syncthreads();                        // readers are done with s_rec before it is refilled
+        wave_sync<WAVE_IS_WG>();                // readers are done with s_rec before it is refilled
         clk.lap(3);
     }
     clk.lap(1);
-
-    if (!valid) return;
-    // ---- finalise (SRK:426-455) ----
-    const size_t pp = (size_t)p.IS * p.IS;
-    const size_t pn = (size_t)row * p.IS + col;
-    float a_out;
-    if (p.alpha == 0) a_out = s.alpha;
-    else if (p.alpha == 1) a_out = s.alpha / p.NF;
-    else a_out = (float)(1. - (double)s.alpha);
-    float o0 = p.bg[0], o1 = p.bg[1], o2 = p.bg[2], g0 = 0.f, g1 = 0.f;
-    if (RGB == 0) {
-        if (s.face_min != -1) { o0 = s.c0; o1 = s.c1; o2 = s.c2; }
-        g0 = s.depth_min; g1 = (float)s.face_min;
-    } else if (RGB == 1) {
-        o0 = s.c0 / s.ssum; o1 = s.c1 / s.ssum; o2 = s.c2 / s.ssum;
-        g0 = s.ssum; g1 = s.smax;
-    }
-    float* out = rgba + (size_t)b * 4 * pp + pn;
-    out[0] = o0; out[pp] = o1; out[2 * pp] = o2; out[3 * pp] = a_out;
-    float* ag = aggrs + (size_t)b * 2 * pp + pn;
-    ag[0] = g0; ag[pp] = g1;
-    int32_t* io = ids + (size_t)b * p.K * pp + pn;
-#pragma unroll
-    for (int k = 0; k < KCAP; k++)
-        if (k < p.K) {
-            if (!ids_in_global<KCAP>()) io[(size_t)k * pp] = s.q.id_of(k);
-            else if (k >= s.q.size) io[(size_t)k * pp] = -1;         // the filled slots were stored when they were filled
-        }
+    store_pixel<RGB>(p, t, s, aggrs, rgba, ids);
     clk.lap(4);
-    clk.flush(counters, 4);
+    if (JR_TUNE_PROFILE_SECTIONS == 1) clk.flush(counters, 4);
+}
+
+// =====================================================================================================================
+// A HEAVY tile by FOUR wavefronts (round 3).  The per-pixel state machine (alpha, online softmax, K-buffer) is
+// sequential in face order, and a tile at the sphere's limb has pixels that need > 300 faces: one wavefront walking
+// them pinned the whole kernel (one 39k-face view alone 0.70 ms, eight views 0.88 ms).  But only alpha / softmax /
+// K-buffer carry state; barycentrics -> distance -> cull -> coverage -> clip -> depth -> zn are STATELESS per pair.  So:
+//
+//   stage     wavefront 0 walks the bin list and stages a batch of records (as above)
+//   masks     every wavefront runs the ballots + pre-cull for two of the tile's eight pixel rows
+//   list      wavefront 0 (lane = pixel): prefix sum of the pixels' pair counts, then every lane writes ITS pairs
+//             (slot, pixel) into a compact list, pixel-major, ascending face inside a pixel
+//   evaluate  ALL wavefronts, lane = any pair of the list, 64 per trip at full lanes: the stateless arithmetic
+//             -> one 16-byte cell {zp, meta, D, slot | flags} per pair; pairs that lie strictly INSIDE their face
+//             (three edge projections instead of one) are pushed to a second list ...
+//   inside    ... and get their coverage in dense trips of their own
+//   apply     lane = pixel walks ITS contiguous cells in order, in TWO wavefronts at once: wavefront 0 owns the
+//             K-buffer (it needs zp and the face id only), wavefront 1 the colour state (alpha, online softmax /
+//             hard rgb: D, the depth, the colour) - the two halves of the state machine do not talk to each other,
+//             and a lone wavefront issues a dependent instruction stream at ~9 clocks per instruction (measured:
+//             apply was 60 % of the heaviest tile's time with one wavefront doing both)
+//
+// A batch whose pairs do not fit the cell buffer is cut into rounds of face-slot ranges (halved until they fit).
+// Results are those of the single-wavefront path: the same device functions on the same operands, the order
+// dependent steps in the same order; only the commutative alpha / softmax sums of inside pairs are unaffected here
+// (they stay in face order).
+// =====================================================================================================================
+constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHARD = 256u, CELL_INCLOSED = 512u;
+constexpr int CELL_TEXEL_SHIFT = 12;
+constexpr int HEAVY_BATCH = tune::fwd_batch_mixed;                                              // record slots of a heavy tile = of each of the four tiles of a lighter workgroup
+constexpr int HEAVY_LDS_BYTES = 4 * (int)sizeof(FaceRec) * HEAVY_BATCH;                         // = what four single-wavefront tiles use
+constexpr int HEAVY_FIXED_BYTES = (int)sizeof(FaceRec) * HEAVY_BATCH + 64 * 8 + 64 * 8 + 64 + 2 * 64 * 8 + 16 * 64 * 4;   // records, pixel centres, masks, scalars, per-pixel (first cell, cells) of two rounds, K-buffer ids
+constexpr int HEAVY_CAP = ((HEAVY_LDS_BYTES - HEAVY_FIXED_BYTES) / 20) & ~63;                   // 16 B cell + 2 B pair + 2 B inside entry per pair
+static_assert(HEAVY_CAP >= 256 && HEAVY_CAP <= 4096, "cell buffer of the heavy-tile path");
+
+// stateless arithmetic of one pair -> cell (zp, meta, D, aux); `deferred`: coverage still to come (inside pair)
+template <int DIST, int RGB, bool FAST>
+__device__ inline float4 evaluate_pair(const RasterParams& p, const FaceRec& r, float xp, float yp, unsigned slot, bool& deferred) {
+    const Bary w = barycentric(r, xp, yp);
+    const int meta = r.meta;
+    float D = 1.f, neg_num = -1.f, zp = 0.f;
+    bool live;
+    deferred = false;
+    if (DIST == 0) live = pixel_inside(w);                                     // SRK:331-333
+    else if (DIST == 1) {                                                      // SRK:335-338
+        const float dis = barycentric_dist(w);
+        live = !(-dis >= p.thr);
+        neg_num = -dis;
+        D = coverage_fast(neg_num, p);
+    } else {                                                                   // SRK:340-344
+        deferred = strictly_inside_t<FAST>(w);
+        live = true;
+        if (!deferred) {
+            const float dis = euclidean_outside_dis<FAST>(r, meta, w, xp, yp);
+            live = !(dis >= p.thr);
+            neg_num = dis;
+            D = coverage_fast(neg_num, p);
+        }
+    }
+    unsigned aux = slot;
+    if (live) {
+        aux |= CELL_LIVE;
+        if (p.alpha == 0 && !deferred) {           // 'hard' alpha: the decision of alpha_accumulate, taken here
+            const float x = (DIST == 0) ? -1.f
+                          : ((neg_num == 0.f || in_fast_range(neg_num)) ? div_known<FAST>(neg_num, p.sigma, p.r_sigma)
+                                                                         : neg_num / p.sigma);
+            if (x < -8.940696716308594e-08f) aux |= CELL_AHARD;
+        }
+        const Bary wc = barycentric_clip<FAST>(w);
+        zp = depth_of<FAST>(r, wc);
+        if (!(zp < p.near_ || zp > p.far_)) {                                  // SRK:365
+            aux |= CELL_DEPTH;
+            if (RGB == 0 && pixel_inside(w)) aux |= CELL_INCLOSED;
+            if (RGB != 2 && p.T != 1) aux |= (unsigned)surface_texel(wc, p.R) << CELL_TEXEL_SHIFT;
+        }
+    } else deferred = false;
+    return make_float4(zp, __builtin_bit_cast(float, meta), D, __builtin_bit_cast(float, aux));
+}
+
+// coverage of a deferred (inside) pair -> (D, aux) of its cell
+template <bool FAST>
+__device__ inline float2 evaluate_inside(const RasterParams& p, const FaceRec& r, float xp, float yp, unsigned aux) {
+    const Bary w = barycentric(r, xp, yp);
+    const float neg_num = -euclidean_inside_dis<FAST>(r, w);
+    const float D = coverage_fast(neg_num, p);
+    if (p.alpha == 0) {
+        const float x = (neg_num == 0.f || in_fast_range(neg_num)) ? div_known<FAST>(neg_num, p.sigma, p.r_sigma) : neg_num / p.sigma;
+        if (x < -8.940696716308594e-08f) aux |= CELL_AHARD;
+    }
+    return make_float2(D, __builtin_bit_cast(float, aux));
+}
+
+// The K-buffer of a heavy tile's wavefront 0 (K <= 16).  In the tiles that need it, most apply trips have SOME lane that
+// replaces the largest depth, and KBuffer's replace path (per-lane slot write + rescan for the first maximum: ~130
+// instructions) then runs for the whole wavefront at one or two live lanes.  Here every insert is the same ~55
+// instructions, whatever mix of appends and replacements the lanes hold:
+//   S[0..15]  the buffered depths in ASCENDING order (free slots +inf at the top, registers beyond K -inf at the bottom):
+//             "is zp nearer than the largest" is zp < S[15]; dropping the largest and inserting zp is one v_med3 per
+//             register, S[k] = med3(S[k-1], S[k], zp);
+//   L         16 nibbles: the PHYSICAL slot (what SRK:369-385 indexes, what faces_id_buffer is laid out by) of the depth
+//             at each sorted position.  The evicted depth's slot is the top nibble; it passes to the new depth, inserted
+//             at its sorted position (binary search over the registers with selects).
+// Appends are evictions of a free slot: the nibbles start as 15 - k, so that free slots are handed out as 0, 1, 2, ...
+// The reference evicts the FIRST slot that holds the maximum (strict '>' rescan); equal depths sit next to each other in
+// S in no particular order, so a tie at the top is resolved when it matters: the smallest slot of the tied group is
+// swapped to the top before the eviction (oracle statistics of the headline scene: 0.5 % of the evictions).
+// A NaN depth (degenerate faces only) takes a slot while the buffer fills and never leaves it, as in the reference: it is
+// kept as -inf.
+// The face indices go to an LDS table [slot][lane] (one conflict-free ds_write per insert) and leave for
+// faces_id_buffer at the end of the tile: the per-insert global stores of the single-wavefront path scatter over up to 64
+// cache lines each, and a heavy tile's lone wavefront waited for them (apply: 600 clocks per trip).
+struct SortedKBuffer16 {
+    float S[16];
+    unsigned long long L;
+    int size;
+    int* lds_ids;                  // this lane's column of the [16][64] table
+
+    __device__ inline int id_of(int k) const { return k < size ? lds_ids[k * 64] : -1; }
+    __device__ inline void init(int K, int* ids_column) {
+        lds_ids = ids_column;
+#pragma unroll
+        for (int k = 0; k < 16; k++) S[k] = k >= 16 - K ? __builtin_inff() : -__builtin_inff();
+        L = 0x0123456789ABCDEFull;          // nibble k = 15 - k
+        size = 0;
+    }
+    __device__ inline void insert(int fn, float zp, int K) {
+        const float inf = __builtin_inff();
+        const bool filling = S[15] == inf;
+        const float z = (zp != zp) ? (filling ? -inf : inf) : zp;
+        if (!(z < S[15])) return;
+        if (S[14] == S[15] && !filling) {
+            // tie at the top: the reference evicts the smallest slot of the group
+            unsigned bl = (unsigned)(L >> 60);
+            int best = 15;
+            bool run = true;
+#pragma unroll
+            for (int k = 14; k >= 0; k--) {
+                run = run && (S[k] == S[15]);
+                const unsigned lab = (unsigned)(L >> (4 * k)) & 15u;
+                if (run && lab < bl) { bl = lab; best = k; }
+            }
+            if (best != 15) {
+                const unsigned top = (unsigned)(L >> 60);
+                const int sh = 4 * best;
+                L = (L & ~((15ull << 60) | (15ull << sh))) | ((unsigned long long)bl << 60) | ((unsigned long long)top << sh);
+            }
+        }
+        const unsigned slot = (unsigned)(L >> 60);
+        lds_ids[slot * 64] = fn;
+        // sorted position among S[0..14]: the number of depths below z (binary search with selects; z goes in front of its equals)
+        // (values first, selects second: a conditional expression over S[i] / S[j] would become ONE load through a selected
+        // address and push the whole array into scratch memory)
+        const float s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3], s4 = S[4], s5 = S[5], s6 = S[6], s7 = S[7], s8 = S[8],
+                    s9 = S[9], s10 = S[10], s11 = S[11], s12 = S[12], s13 = S[13], s14 = S[14];
+        const bool c3 = s7 < z;
+        const float a = c3 ? s11 : s3;
+        const bool c2 = a < z;
+        const float b1 = c2 ? s13 : s9, b0 = c2 ? s5 : s1;
+        const float b = c3 ? b1 : b0;
+        const bool c1 = b < z;
+        const float d3 = c1 ? s14 : s12, d2 = c1 ? s10 : s8, d1 = c1 ? s6 : s4, d0 = c1 ? s2 : s0;
+        const float dh = c2 ? d3 : d2, dl = c2 ? d1 : d0;
+        const float d = c3 ? dh : dl;
+        const bool c0 = d < z;
+        const int sh = 4 * ((c3 ? 8 : 0) + (c2 ? 4 : 0) + (c1 ? 2 : 0) + (c0 ? 1 : 0));
+        const unsigned long long low = (1ull << sh) - 1ull;
+        L = (L & low) | ((unsigned long long)slot << sh) | ((L & ~low) << 4);      // the old top nibble (= slot) falls off
+#pragma unroll
+        for (int k = 15; k > 0; k--) S[k] = __builtin_amdgcn_fmed3f(S[k - 1], S[k], z);
+        S[0] = fminf(S[0], z);
+        if (filling) size++;
+    }
+};
+
+// the K-buffer half of the state machine of one cell (lane = pixel, wavefront 0)
+template <class KB>
+__device__ inline void apply_kbuf(const RasterParams& p, const float4 cell, KB& q) {
+    const unsigned aux = __builtin_bit_cast(unsigned, cell.w);
+    if ((aux & (CELL_LIVE | CELL_DEPTH)) != (CELL_LIVE | CELL_DEPTH)) return;
+    q.insert(face_id(__builtin_bit_cast(int, cell.y)), cell.x, p.K);
+}
+
+// the colour half (lane = pixel, wavefront 1): alpha (SRK:350-358), hard rgb (SRK:390-397) or online softmax (SRK:399-419)
+template <int RGB, int KCAP>
+__device__ inline void apply_colour(const RasterParams& p, const float4 cell, const FaceRec* s_rec,
+                                    const float* __restrict__ tbase, PixelState<KCAP>& s) {
+    const unsigned aux = __builtin_bit_cast(unsigned, cell.w);
+    if (!(aux & CELL_LIVE)) return;
+    const float zp = cell.x, D = cell.z;
+    const int meta = __builtin_bit_cast(int, cell.y);
+    if (p.alpha == 0) { if (aux & CELL_AHARD) s.alpha = 1.f; }
+    else if (p.alpha == 1) s.alpha += D;
+    else s.alpha = __builtin_fmaf(-s.alpha, D, s.alpha);
+    if (RGB == 2 || !(aux & CELL_DEPTH)) return;
+    const bool facing = face_front(meta) || p.double_side;
+    if (RGB == 0) { if (!(zp < s.depth_min && (aux & CELL_INCLOSED) && facing)) return; }
+    else if (!facing) return;
+    const int fn = face_id(meta);
+    float k0, k1, k2;
+    if (p.T == 1) { const float* col = s_rec[aux & CELL_SLOT].col; k0 = col[0]; k1 = col[1]; k2 = col[2]; }
+    else {
+        const float* tx_ = tbase + ((size_t)fn * p.T + (aux >> CELL_TEXEL_SHIFT)) * 3;
+        k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
+    }
+    if (RGB == 0) { s.depth_min = zp; s.face_min = fn; s.c0 = k0; s.c1 = k1; s.c2 = k2; }
+    else {
+        // zn must carry the reference's exact bits (see softmax_accumulate); FAST as in the evaluate pass
+        const float zn = (face_safe(meta) && p.consts_safe) ? div_known<true>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near)
+                                                            : div_known<false>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
+        const float x = zn - s.smax;
+        const bool up = x > 0.f;
+        const float e = exp_over_gamma(up ? -x : x, p);
+        const float ed = up ? e : 1.f, ez = up ? 1.f : e;
+        s.smax = up ? zn : s.smax;
+        s.ssum = ed * s.ssum + ez * D;
+        s.c0 = ed * s.c0 + ez * D * k0;
+        s.c1 = ed * s.c1 + ez * D * k1;
+        s.c2 = ed * s.c2 + ez * D * k2;
+    }
+}
+
+template <int DIST, int RGB, int KCAP>
+__device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int wid, int lane, float4* s_mem,
+                                  const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
+                                  const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
+                                  float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    constexpr int BATCH = HEAVY_BATCH, CAP = HEAVY_CAP;
+    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                                        // [BATCH]
+    float4* s_cell = reinterpret_cast<float4*>(s_rec + BATCH);                                 // [CAP]
+    float2* s_pix = reinterpret_cast<float2*>(s_cell + CAP);                                   // [64] pixel centres
+    unsigned long long* s_M = reinterpret_cast<unsigned long long*>(s_pix + 64);               // [64] face masks of the batch
+    int* s_misc = reinterpret_cast<int*>(s_M + 64);                                            // [16] fill, total, j1, inside count
+    int2* s_span = reinterpret_cast<int2*>(s_misc + 16);                                       // [2][64] a pixel's first cell, number of cells (by round parity)
+    int* s_kids = reinterpret_cast<int*>(s_span + 128);                                        // [16][64] face indices of the sorted K-buffer
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_kids + 16 * 64);                   // [CAP] slot | pixel << 6
+    unsigned short* s_in = s_pair + CAP;                                                       // [CAP] cells of inside pairs
+    const float xp = t.xp, yp = t.yp;
+    const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
+    PixelState<KCAP> s;                                  // the K-buffer lives in wavefront 0, the colour state in wavefront 1
+    constexpr bool SORTED = KCAP == 16 && tune::fwd_heavy_sorted && ids_in_global<KCAP>();
+    SortedKBuffer16 sk;                                  // wavefront 0's K-buffer when K <= 16
+    ListWalker lw;
+    SectionClock clk;            // instrumented builds only (wavefront 0): 0 stage, 1 masks, 2 pair list, 3 evaluate, 5 inside, 6 apply, 7 stores
+    clk.start();
+    if (wid == 1) init_colour_state<RGB>(p, s);
+    if (wid == 0) {
+        if (SORTED) sk.init(p.K, s_kids + lane); else init_kbuffer(p, t, ids, s.q);
+        lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
+        s_pix[lane] = make_float2(xp, yp);
+    }
+    for (;;) {
+        if (wid == 0) {
+            const int f = lw.stage<BATCH>(p, s_rec, nullptr, lane);
+            if (lane == 0) s_misc[0] = f;
+        }
+        __syncthreads();                                                       // A: records staged
+        const int fill = s_misc[0];
+        if (wid == 0) clk.lap(0);
+        if (fill == 0) break;
+        {   // masks: two pixel rows per wavefront
+            unsigned long long Mw;
+            switch (wid) {
+                case 0: Mw = pixel_masks<DIST, 0, 2>(p, s_rec, fill, lane, xp, yp); break;
+                case 1: Mw = pixel_masks<DIST, 2, 4>(p, s_rec, fill, lane, xp, yp); break;
+                case 2: Mw = pixel_masks<DIST, 4, 6>(p, s_rec, fill, lane, xp, yp); break;
+                default: Mw = pixel_masks<DIST, 6, 8>(p, s_rec, fill, lane, xp, yp); break;
+            }
+            if ((lane >> 4) == wid) s_M[lane] = t.valid ? Mw : 0ull;
+        }
+        __syncthreads();                                                       // B: masks of all 64 pixels
+        if (wid == 0) clk.lap(1);
+        unsigned long long M = 0ull;
+        if (wid == 0) M = s_M[lane];
+        int j0 = 0;
+        for (int round = 0;; round++) {                                        // rounds of the batch
+            int cnt = 0, base = 0;
+            if (wid == 0) {
+                // the widest slot range [j0, j1) whose pairs fit the cell buffer (a face has <= 64 pairs)
+                int j1 = fill, total;
+                unsigned long long Mr;
+                for (;;) {
+                    const unsigned long long range = (j1 >= 64 ? ~0ull : ((1ull << j1) - 1ull)) & ~((1ull << j0) - 1ull);
+                    Mr = M & range;
+                    cnt = __builtin_popcountll(Mr);
+                    int incl = cnt;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int o = __shfl_up(incl, d);
+                        if (lane >= d) incl += o;
+                    }
+                    total = __builtin_amdgcn_readlane(incl, 63);
+                    base = incl - cnt;
+                    if (total <= CAP || j1 - j0 <= 1) break;
+                    j1 = j0 + ((j1 - j0 + 1) >> 1);
+                }
+                if (lane == 0) { s_misc[1] = total; s_misc[2] = j1; s_misc[3] = 0; }
+                s_span[(round & 1) * 64 + lane] = make_int2(base, cnt);   // (wavefront 1 may still be reading the previous round's)
+                int a = base;                                                  // this pixel's pairs, ascending face
+                while (Mr) {
+                    const int j = __builtin_ctzll(Mr);
+                    Mr &= Mr - 1;
+                    s_pair[a++] = (unsigned short)(j | (lane << 6));
+                }
+            }
+            if (wid == 0) clk.lap(2);
+            __syncthreads();                                                   // C: pair list
+            const int total = s_misc[1], j1 = s_misc[2];
+            for (int q0 = wid * 64; q0 < total; q0 += 256) {                   // ---- evaluate: lane = pair ----
+                const int q = q0 + lane;
+                const bool act = q < total;
+                bool deferred = false;
+                if (act) {
+                    const unsigned pr = s_pair[q];
+                    const FaceRec& r = s_rec[pr & 63u];
+                    const float2 c = s_pix[pr >> 6];
+                    float4 cell;
+                    if (face_safe(r.meta) && p.consts_safe) cell = evaluate_pair<DIST, RGB, true>(p, r, c.x, c.y, pr & 63u, deferred);
+                    else cell = evaluate_pair<DIST, RGB, false>(p, r, c.x, c.y, pr & 63u, deferred);
+                    s_cell[q] = cell;
+                }
+                if (DIST == 2) {
+                    const unsigned long long im = ballot(deferred);
+                    if (im) {
+                        int at = 0;
+                        if (lane == __builtin_ctzll(im)) at = atomicAdd(&s_misc[3], __builtin_popcountll(im));
+                        at = __builtin_amdgcn_readlane(at, __builtin_ctzll(im));
+                        const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(im >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)im, 0u));
+                        if (deferred) s_in[at + rk] = (unsigned short)q;
+                    }
+                }
+            }
+            __syncthreads();                                                   // D: cells, inside list
+            if (wid == 0) clk.lap(3);
+            if (DIST == 2) {
+                const int nin = s_misc[3];
+                for (int i0 = wid * 64; i0 < nin; i0 += 256) {                 // ---- inside pairs: lane = pair ----
+                    const int i = i0 + lane;
+                    if (i < nin) {
+                        const int q = s_in[i];
+                        const unsigned pr = s_pair[q];
+                        const FaceRec& r = s_rec[pr & 63u];
+                        const float2 c = s_pix[pr >> 6];
+                        const unsigned aux = __builtin_bit_cast(unsigned, s_cell[q].w);
+                        float2 da;
+                        if (face_safe(r.meta) && p.consts_safe) da = evaluate_inside<true>(p, r, c.x, c.y, aux);
+                        else da = evaluate_inside<false>(p, r, c.x, c.y, aux);
+                        *reinterpret_cast<float2*>(&s_cell[q].z) = da;
+                    }
+                }
+                __syncthreads();                                               // E: coverage of the inside pairs
+                if (wid == 0) clk.lap(5);
+            }
+            if (wid <= 1) {                                                    // ---- apply: lane = pixel, K-buffer | colour ----
+                const int2 span = s_span[(round & 1) * 64 + lane];
+                // (cells are read one ahead of their use; beyond the pixel's last cell: cell 0 with aux = 0, "not live")
+                float4 cur = s_cell[span.y > 0 ? span.x : 0];
+                if (!(span.y > 0)) cur.w = 0.f;
+                for (int k = 0; ballot(k < span.y) != 0ull; k++) {
+                    float4 nxt = s_cell[k + 1 < span.y ? span.x + k + 1 : 0];
+                    if (!(k + 1 < span.y)) nxt.w = 0.f;
+                    if (wid == 0) { if (SORTED) apply_kbuf(p, cur, sk); else apply_kbuf(p, cur, s.q); }
+                    else apply_colour<RGB, KCAP>(p, cur, s_rec, tbase, s);
+                    cur = nxt;
+                }
+                if (wid == 0) clk.lap(6);
+            }
+            j0 = j1;
+            if (j0 >= fill) break;
+        }
+        __syncthreads();                // F: wavefront 1 reads colours from the records until its apply ends; then they may be restaged
+    }
+    if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
+    if (wid == 0) {
+        if (SORTED) store_ids<KCAP, false>(p, t, sk, ids); else store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+        clk.lap(7);
+        if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2]) clk.flush(counters, 4);   // the 16 tiles of the heaviest bin
+    }
+}
+
+// ---- kernels -----------------------------------------------------------------------------------------------------------
+// One wavefront per workgroup, one tile per wavefront (rounds 1-2; tune::fwd_heavy = 0, and vertex colours).
+template <int DIST, int RGB, int KCAP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP, false)))) void k_softras_forward(
+    RasterParams p, int ntiles_total, const float* __restrict__ textures,
+    const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
+    const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
+    unsigned long long* __restrict__ counters, unsigned long long pool_cap,
+    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    extern __shared__ float4 s_dyn[];
+    if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
+    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
+    // bin (same list, same records) go to ONE XCD so that they share its L2.
+    const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
+    const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
+    if (brank * 16 >= ntiles_total) return;
+    const int bin = bin_order[brank];                    // ... heaviest first (k_bin_schedule)
+    const int n = bin_count[bin];
+    // tune::fwd_prio: issue priority for the wavefronts of the heaviest bins (measured: no effect)
+    if (tune::fwd_prio > 0 && n > tune::fwd_prio) __builtin_amdgcn_s_setprio(3);
+    TileGeom t;
+    if (!tile_geom(p, bin, k & 15, n, threadIdx.x, t)) return;
+    tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
+}
+
+// Four wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first (k_bin_schedule) and its
+// first counters[3] bins are HEAVY (list longer than tune::fwd_heavy): a workgroup takes ONE tile of a heavy bin with
+// its four wavefronts together (tile_heavy), or FOUR tiles (one row of tiles) of a lighter bin, one per wavefront
+// (tile_single, each with a quarter of the workgroup's LDS).  Per XCD (workgroup id % 8) the heavy tiles come first.
+template <int DIST, int RGB, int KCAP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP, true)))) void k_softras_forward_mixed(
+    RasterParams p, int nbins, int heavy_cap, const float* __restrict__ textures,
+    const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
+    const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
+    unsigned long long* __restrict__ counters, unsigned long long pool_cap,
+    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    extern __shared__ float4 s_dyn[];
+    if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nheavy = min((int)counters[3], heavy_cap);
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int hx = (nheavy - xcd + 7) >> 3;              // heavy bins dealt to this XCD (launch ranks xcd, xcd + 8, ...)
+    const bool heavy = k < hx * 16;
+    int brank, sub;
+    if (heavy) { brank = (k >> 4) * 8 + xcd; sub = k & 15; }
+    else { const int k2 = k - hx * 16; brank = (hx + (k2 >> 2)) * 8 + xcd; sub = (k2 & 3) * 4 + wid; }
+    if (brank >= nbins) return;
+    const int bin = bin_order[brank];
+    const int n = bin_count[bin];
+    TileGeom t;
+    if (!tile_geom(p, bin, sub, n, lane, t)) return;     // (a heavy tile: uniform for the workgroup)
+    const unsigned long long* seg = pool + bin_base[bin];
+    if (heavy) tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
+    else tile_single<DIST, RGB, KCAP, HEAVY_BATCH, false>(p, t, lane, s_dyn + wid * (sizeof(FaceRec) * HEAVY_BATCH / sizeof(float4)),
+                                             textures, geo, seg, counters, aggrs, rgba, ids);
+}
+
+template <int DIST, int RGB, int KCAP>
+static void launch_kk(hipStream_t st, const RasterParams& p, const float* textures,
+                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
+    const int nbins = p.B * p.bins_x * p.bins_y;
+    const int ntiles = nbins * SUBS * SUBS;
+    // Four wavefronts per heavy tile cut the critical path of a launch (one 39k-face view: 0.69 -> 0.38 ms), but the
+    // waiting wavefronts hold slots that a full GPU has better uses for (eight views: 0.89 -> 0.98 ms even when only the
+    // bins above 1024 faces are heavy): the four-wavefront kernel takes launches of up to fwd_heavy_pixels pixels.
+    // Heavy tiles need single-texel or per-texel surface colours (the cell has no room for three vertex colours).
+    const bool small = (long)p.B * p.IS * p.IS <= (long)tune::fwd_heavy_pixels;
+    if (tune::fwd_heavy > 0 && p.tex == 0 && small) {
+        // upper bound of the heavy bins the device will find: their lists hold more than fwd_heavy_floor() entries each
+        const long hcap = (long)(ws.pool_cap / (unsigned long long)fwd_heavy_floor()) + 8;
+        const int heavy_cap = (int)(hcap < nbins ? hcap : nbins);
+        const int per_xcd = 16 * ((heavy_cap + 7) / 8) + 4 * ((nbins + 7) / 8);
+        k_softras_forward_mixed<DIST, RGB, KCAP><<<8 * per_xcd, 256, HEAVY_LDS_BYTES, st>>>(
+            p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+        return;
+    }
+    const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
+    // JR_FWD_LDS_PAD (bytes, diagnostics only): more dynamic LDS per wavefront = fewer wavefronts per CU
+    static const size_t pad = getenv("JR_FWD_LDS_PAD") ? (size_t)atol(getenv("JR_FWD_LDS_PAD")) : 0;
+    const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0) + pad;
+    k_softras_forward<DIST, RGB, KCAP><<<grid, 64, smem, st>>>(
+        p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
 }
 
 template <int DIST, int RGB>
-static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
+static void launch_k(hipStream_t st, const RasterParams& p, const float* textures,
                      const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
-    const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
-    const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0);
     // K-buffer capacity: 16 (the default K), 32 (K = 17..32), 64
-    if (p.K <= 16)
-        k_softras_forward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
-    else if (p.K <= 32)
-        k_softras_forward<DIST, RGB, 32><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
-    else
-        k_softras_forward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+    if (p.K <= 16) launch_kk<DIST, RGB, 16>(st, p, textures, ws, aggrs, rgba, ids);
+    else if (p.K <= 32) launch_kk<DIST, RGB, 32>(st, p, textures, ws, aggrs, rgba, ids);
+    else launch_kk<DIST, RGB, 64>(st, p, textures, ws, aggrs, rgba, ids);
 }
 
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
                             const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
-    const int ntiles = p.B * p.bins_x * p.bins_y * SUBS * SUBS;
-#define JR_FWD(D, R) launch_k<D, R>(st, p, ntiles, textures, ws, aggrs, rgba, ids)
+#define JR_FWD(D, R) launch_k<D, R>(st, p, textures, ws, aggrs, rgba, ids)
     const int rgb = p.rgb == 0 ? 0 : (p.rgb == 1 ? 1 : 2);
     switch (p.dist * 3 + rgb) {
         case 0: JR_FWD(0, 0); break;

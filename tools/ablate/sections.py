@@ -8,15 +8,17 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("JRENDER_LIB", os.path.join(ROOT, "jrender_amd", "csrc", "libjrender_hip_sections.so"))
+HEAVY = "--heavy" in sys.argv          # wavefront 0 of the heaviest bin's 16 tiles in the four-wavefront path, ONE view
+os.environ.setdefault("JRENDER_LIB", os.path.join(ROOT, "jrender_amd", "csrc", "libjrender_hip_sections%s.so" % ("_heavy" if HEAVY else "")))
 sys.path.insert(0, ROOT)
 from jrender_amd import _ffi, synthetic as syn                                     # noqa: E402
 from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction   # noqa: E402
 
 ctx = _ffi.Context(0)
-fv, tex = syn.sphere_views(39000, 8)
+NB = 1 if HEAVY else 8
+fv, tex = syn.sphere_views(39000, NB)
 fv, tex = ctx.array(fv), ctx.array(tex)
-g = ctx.array(np.random.default_rng(7).uniform(-1, 1, (8, 4, 1024, 1024)).astype(np.float32))
+g = ctx.array(np.random.default_rng(7).uniform(-1, 1, (NB, 4, 1024, 1024)).astype(np.float32))
 fn = SoftRasterizeFunction(image_size=1024, ctx=ctx)
 for _ in range(2):
     fn.execute(fv, tex); fn.grad(g)
@@ -24,6 +26,12 @@ ctx.section_clocks()
 for _ in range(5):
     fn.execute(fv, tex); fn.grad(g)
 c = np.asarray(ctx.section_clocks(), np.float64)
+if HEAVY:
+    tot = c[0:8].sum()
+    print("heaviest bin, wavefront 0 of its 16 tiles, %d launches: %.3g clocks per tile and launch" % (5, tot / 16 / 5))
+    for i, lab in enumerate(["stage (+ wait)", "masks", "pair list", "evaluate (+ barriers)", "-", "inside pairs", "apply", "stores"]):
+        print("   %-24s %5.1f %%   %9.0f clocks per tile" % (lab, 100 * c[i] / max(tot, 1), c[i] / 16 / 5))
+    sys.exit(0)
 for name, lo, labels in (("forward", 0, ["set-up", "cull + stage", "ballots + pre-cull", "raster loop", "stores"]),
                          ("backward", 8, ["tile state + sort", "extraction", "staging + items", "gather", "pair arithmetic", "reduce + atomics"])):
     tot = c[lo:lo + 8].sum()

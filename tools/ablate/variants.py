@@ -3,17 +3,16 @@
 `python tools/ablate/run.py [names...]` (GPU box) checks parity and times each one in ONE process
 sequence on ONE box (boxes differ by a few per cent: only numbers from one call are comparable)."""
 # (the round-1 kernels also tested every listed face's box against the tile: that switch left the tree, patches/dead_switches_r03.patch)
-OFF = ["JR_TUNE_FWD_BATCH=64", "JR_TUNE_BWD_BATCH=64", "JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_OCC4=0", "JR_TUNE_FWD_INSIDE_RCP=0", "JR_TUNE_FWD_IDS_GLOBAL=0"]
+OFF = ["JR_TUNE_FWD_BATCH=64", "JR_TUNE_BWD_BATCH=64", "JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_DIS_ONLY=0", "JR_TUNE_FWD_WAVES16=1", "JR_TUNE_FWD_INSIDE_RCP=0", "JR_TUNE_FWD_IDS_GLOBAL=0",
+       "JR_TUNE_FWD_FILL_SHIFT=0", "JR_TUNE_FWD_EXP1=0", "JR_TUNE_FWD_HEAVY=0"]
 VARIANTS = {
     "product": [],                                           # the defaults of jr_tuning.h
     "r1": OFF,                                               # every switch off = round-1 kernels
-    "r1_occ4": OFF[:4] + OFF[5:],                            # + the 4-waves-per-SIMD request alone
-    "no_prepass": ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_OCC4=0"],
+    "r1_occ4": OFF[:4] + ["JR_TUNE_FWD_WAVES16=4"] + OFF[5:],      # + the 4-waves-per-SIMD request alone
+    "no_prepass": ["JR_TUNE_FWD_PREPASS=0", "JR_TUNE_FWD_HEAVY=0"],
     "no_dis": ["JR_TUNE_FWD_DIS_ONLY=0"],
     "bwd_rcp": ["JR_TUNE_BWD_TV_RCP=1"],                     # dead: breaks the 1e-4 gradient bar
     "no_inside_rcp": ["JR_TUNE_FWD_INSIDE_RCP=0"],
-    "fwd64": ["JR_TUNE_FWD_BATCH=64"],                       # 64 record slots: 14 wavefronts per CU (round 1)
-    "fwd48": ["JR_TUNE_FWD_BATCH=48"],
     "bwd64": ["JR_TUNE_BWD_BATCH=64"],                       # 13 wavefronts per CU (round 1)
     "bwd48": ["JR_TUNE_BWD_BATCH=48"],
     "bwd56": ["JR_TUNE_BWD_BATCH=56"],
@@ -29,18 +28,26 @@ VARIANTS = {
     "bwd52w4": ["JR_TUNE_BWD_BATCH=52", "JR_TUNE_BWD_WAVES=4"],   # round-2 start
     "bwd34w6": ["JR_TUNE_BWD_BATCH=34", "JR_TUNE_BWD_WAVES=6"],
     "bwd48w5": ["JR_TUNE_BWD_BATCH=48", "JR_TUNE_BWD_WAVES=5"],
-    "fwd44w5": ["JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_OCC4=5"],
-    "fwd52": ["JR_TUNE_FWD_BATCH=52"],
     "ids_regs": ["JR_TUNE_FWD_IDS_GLOBAL=0"],                # K-buffer ids in registers (round-2 start)
-    "fwd44w5g": ["JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_OCC4=5"],  # with the ids out of the registers: 96 VGPRs, 20 B of scratch outside the trip loop
     "no_shift": ["JR_TUNE_FWD_FILL_SHIFT=0"],                # round 3: K-buffer appends by per-lane slot select instead of the register shift
-    "no_defer": ["JR_TUNE_FWD_DEFER_INSIDE=0"],              # round 3: inside pairs evaluated in the main raster loop
     "no_exp1": ["JR_TUNE_FWD_EXP1=0"],                       # round 3: two v_exp per softmax update
-    "r2fwd": ["JR_TUNE_FWD_FILL_SHIFT=0", "JR_TUNE_FWD_DEFER_INSIDE=0", "JR_TUNE_FWD_EXP1=0"],   # the round-2 forward
-    "prio256": ["JR_TUNE_FWD_PRIO=256", "JR_TUNE_FWD_DEFER_INSIDE=0"],
-    "prio600": ["JR_TUNE_FWD_PRIO=600", "JR_TUNE_FWD_DEFER_INSIDE=0"],
-    "occ3": ["JR_TUNE_FWD_OCC4=3", "JR_TUNE_FWD_DEFER_INSIDE=0"],       # diagnostic: 3 / 2 wavefronts per SIMD in the forward
-    "occ2": ["JR_TUNE_FWD_OCC4=2", "JR_TUNE_FWD_DEFER_INSIDE=0"],
+    "defer": ["JR_TUNE_FWD_DEFER_INSIDE=1"],                 # round 3, dead: inside pairs of single-wavefront tiles in a second loop per batch
+    "h128": ["JR_TUNE_FWD_HEAVY=128"], "h256": ["JR_TUNE_FWD_HEAVY=256"], "h384": ["JR_TUNE_FWD_HEAVY=384"],
+    "h64": ["JR_TUNE_FWD_HEAVY=64"], "h768": ["JR_TUNE_FWD_HEAVY=768"], "h1024": ["JR_TUNE_FWD_HEAVY=1024"],
+    "h1024all": ["JR_TUNE_FWD_HEAVY=1024", "JR_TUNE_FWD_HEAVY_PIXELS=1000000000"],
+    "prio256": ["JR_TUNE_FWD_PRIO=256", "JR_TUNE_FWD_HEAVY=0"],     # dead: s_setprio(3) for the wavefronts of heavy bins (no effect)
+    "diag_nosoftmax": ["JR_TUNE_DIAG=1", "JR_TUNE_FWD_HEAVY=0"],   # WRONG results: cost probes of the single-wavefront path
+    "diag_nokbuf": ["JR_TUNE_DIAG=2", "JR_TUNE_FWD_HEAVY=0"],
+    "diag_neither": ["JR_TUNE_DIAG=3", "JR_TUNE_FWD_HEAVY=0"],
+    "sections_heavy": ["JR_TUNE_PROFILE_SECTIONS=2"],       # instrumented: wavefront 0 of the heaviest bin's tiles (tools/ablate/sections.py --heavy)
+    "r2fwd": ["JR_TUNE_FWD_FILL_SHIFT=0", "JR_TUNE_FWD_EXP1=0", "JR_TUNE_FWD_HEAVY=0", "JR_TUNE_FWD_BATCH=56", "JR_TUNE_FWD_WAVES16=4"],   # the round-2 forward
+    "h0": ["JR_TUNE_FWD_HEAVY=0"],                           # round 3: one wavefront per tile whatever the size of the launch
+    "hall": ["JR_TUNE_FWD_HEAVY_PIXELS=1000000000"],         # round 3: the four-wavefront kernel whatever the size of the launch
+    "hnone": ["JR_TUNE_FWD_HEAVY=1000000", "JR_TUNE_FWD_HEAVY_PIXELS=1000000000"],   # four tiles per workgroup, no heavy bin at all: what does that organisation cost?
+    "w4b56": ["JR_TUNE_FWD_WAVES16=4", "JR_TUNE_FWD_BATCH=56", "JR_TUNE_FWD_HEAVY=0"],   # single-wavefront forward at 4 wavefronts per SIMD (round 2) / 5 with other batch sizes / 6
+    "w5b44": ["JR_TUNE_FWD_WAVES16=5", "JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_HEAVY=0"],
+    "w6b36": ["JR_TUNE_FWD_WAVES16=6", "JR_TUNE_FWD_BATCH=36", "JR_TUNE_FWD_HEAVY=0"],
+    "unsorted": ["JR_TUNE_FWD_HEAVY_SORTED=0"],              # heavy tiles with the slot-order K-buffer of the single-wavefront path
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
-    "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_DEFER_INSIDE=0"],              # instrumented: tools/ablate/sections.py
+    "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
