@@ -104,10 +104,11 @@ struct KBuffer {
     // K-nearest insert with the reference's slot semantics (SRK:369-385): append while not
     // full (tracking the first largest depth), afterwards overwrite the largest-depth slot
     // when strictly nearer and rescan, first maximum wins.
-    __device__ inline void insert(int fn, float zp, int K) {
-        if (JR_TUNE_DIAG & 2) return;      // diagnostic builds only (empty index buffer): what does the K-buffer cost?
+    // -> the slot the face went to, -1 when it was not nearer than the largest buffered depth
+    __device__ inline int insert(int fn, float zp, int K) {
+        if (JR_TUNE_DIAG & 2) return -1;   // diagnostic builds only (empty index buffer): what does the K-buffer cost?
         const bool filling = size < K;
-        if (!filling && !(zp < max_z)) return;
+        if (!filling && !(zp < max_z)) return -1;
         const int slot = filling ? size : max_slot;
         if (IDS_GLOBAL) gplane[(unsigned)slot * gstride + goff] = fn;
         if (SHIFT) {
@@ -123,7 +124,7 @@ struct KBuffer {
                 for (int k = 0; k < KCAP; k++) z[k] = k == reg ? zp : z[k];
                 rescan(K);
             }
-            return;
+            return slot;
         }
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
@@ -135,6 +136,7 @@ struct KBuffer {
             if (zp > max_z) { max_z = zp; max_slot = size; }
             size++;
         } else rescan(K);
+        return slot;
     }
 };
 
@@ -142,6 +144,7 @@ template <int KCAP>
 struct PixelState {                 // SRK:291-309
     float c0, c1, c2, alpha, ssum, smax, depth_min;
     int face_min;
+    unsigned inbits;                // bit k: the pixel lies strictly inside the face of K-buffer slot k (a hint for the backward's schedule)
     KBuffer<KCAP> q;
 };
 
@@ -230,7 +233,7 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
     const Bary w = barycentric(r, xp, yp);
     const int meta = r.meta;
     float D = 1.f, neg_num = -1.f;
-    bool deferred = false;
+    bool deferred = false, inside = false;
     if (DIST == 0) {                                                           // SRK:331-333
         if (!pixel_inside(w)) return false;
     } else if (DIST == 1) {                                                    // SRK:335-338
@@ -240,6 +243,7 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
         D = coverage_fast(neg_num, p);
     } else if (tune::fwd_defer_inside) {                                       // SRK:340-344
         deferred = strictly_inside_t<FAST>(w);
+        inside = deferred;
         if (!deferred) {
             const float dis = euclidean_outside_dis<FAST>(r, meta, w, xp, yp);
             if (dis >= p.thr) return false;
@@ -255,6 +259,7 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
             dis = dd.dx * dd.dx + dd.dy * dd.dy;
         }
         if (sign < 0 && dis >= p.thr) return false;
+        inside = sign > 0.f;
         neg_num = -sign * dis;
         D = coverage_fast(neg_num, p);
     }
@@ -265,7 +270,9 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
     const float zp = depth_of<FAST>(r, wc);
     if (zp < p.near_ || zp > p.far_) return deferred;                         // SRK:365
     const int fn = face_id(meta);
-    s.q.insert(fn, zp, p.K);
+    const int slot = s.q.insert(fn, zp, p.K);
+    if (DIST == 2 && KCAP == 16 && tune::inside_hint && slot >= 0)
+        s.inbits = (s.inbits & ~(1u << slot)) | ((inside ? 1u : 0u) << slot);
 
     if (RGB == 0) {                                                            // SRK:390-397
         if (zp < s.depth_min && pixel_inside(w) && (p.double_side || face_front(meta))) {
@@ -345,6 +352,7 @@ __device__ inline void init_colour_state(const RasterParams& p, PixelState<KCAP>
     else if (RGB == 1) { s.c0 = p.bg[0] * s.ssum; s.c1 = p.bg[1] * s.ssum; s.c2 = p.bg[2] * s.ssum; }
     s.depth_min = 10000000.f;
     s.face_min = -1;
+    s.inbits = 0u;
 }
 template <class KB>
 __device__ inline void init_kbuffer(const RasterParams& p, const TileGeom& t, int32_t* __restrict__ ids, KB& q) {
@@ -392,11 +400,17 @@ __device__ inline void store_ids(const RasterParams& p, const TileGeom& t, const
             else if (k >= q.size) io[(size_t)k * pp] = -1;           // the filled slots were stored when they were filled
         }
 }
+// hint for the backward's schedule (context-owned side plane, [B, IS, IS] u16): bit k = strictly inside the face of slot k
+__device__ inline void store_inside_hint(const RasterParams& p, const TileGeom& t, unsigned inbits, unsigned short* __restrict__ hint) {
+    if (tune::inside_hint && hint && t.valid) hint[((size_t)t.b * p.IS + t.row) * p.IS + t.col] = (unsigned short)inbits;
+}
 template <int RGB, int KCAP>
 __device__ inline void store_pixel(const RasterParams& p, const TileGeom& t, const PixelState<KCAP>& s,
-                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids,
+                                   unsigned short* __restrict__ hint) {
     store_colour<RGB>(p, t, s, aggrs, rgba);
     store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+    if (KCAP == 16) store_inside_hint(p, t, s.inbits, hint);
 }
 
 // ---- cull + stage: lane = list entry ------------------------------------------------------------------------
@@ -565,7 +579,8 @@ template <int DIST, int RGB, int KCAP, int BATCH, bool WAVE_IS_WG>
 __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int lane, float4* s_mem,
                                    const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
                                    const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
-                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids,
+                                   unsigned short* __restrict__ hint) {
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                        // [BATCH] record slots of this wavefront
     float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
     SectionClock clk;            // instrumented builds only: 0 set-up, 1 cull + stage, 2 ballots + pre-cull, 3 raster loop, 4 stores
@@ -616,7 +631,7 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
         clk.lap(3);
     }
     clk.lap(1);
-    store_pixel<RGB>(p, t, s, aggrs, rgba, ids);
+    store_pixel<RGB>(p, t, s, aggrs, rgba, ids, hint);
     clk.lap(4);
     if (JR_TUNE_PROFILE_SECTIONS == 1) clk.flush(counters, 4);
 }
@@ -646,7 +661,7 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
 // dependent steps in the same order; only the commutative alpha / softmax sums of inside pairs are unaffected here
 // (they stay in face order).
 // =====================================================================================================================
-constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHARD = 256u, CELL_INCLOSED = 512u;
+constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHARD = 256u, CELL_INCLOSED = 512u, CELL_INSIDE = 1024u;
 constexpr int CELL_TEXEL_SHIFT = 12;
 constexpr int HEAVY_BATCH = tune::fwd_batch_mixed;                                              // record slots of a heavy tile = of each of the four tiles of a lighter workgroup
 constexpr int HEAVY_LDS_BYTES = 4 * (int)sizeof(FaceRec) * HEAVY_BATCH;                         // = what four single-wavefront tiles use
@@ -680,7 +695,7 @@ __device__ inline float4 evaluate_pair(const RasterParams& p, const FaceRec& r, 
     }
     unsigned aux = slot;
     if (live) {
-        aux |= CELL_LIVE;
+        aux |= CELL_LIVE | (deferred ? CELL_INSIDE : 0u);
         if (p.alpha == 0 && !deferred) {           // 'hard' alpha: the decision of alpha_accumulate, taken here
             const float x = (DIST == 0) ? -1.f
                           : ((neg_num == 0.f || in_fast_range(neg_num)) ? div_known<FAST>(neg_num, p.sigma, p.r_sigma)
@@ -744,11 +759,11 @@ struct SortedKBuffer16 {
         L = 0x0123456789ABCDEFull;          // nibble k = 15 - k
         size = 0;
     }
-    __device__ inline void insert(int fn, float zp, int K) {
+    __device__ inline int insert(int fn, float zp, int K) {
         const float inf = __builtin_inff();
         const bool filling = S[15] == inf;
         const float z = (zp != zp) ? (filling ? -inf : inf) : zp;
-        if (!(z < S[15])) return;
+        if (!(z < S[15])) return -1;
         if (S[14] == S[15] && !filling) {
             // tie at the top: the reference evicts the smallest slot of the group
             unsigned bl = (unsigned)(L >> 60);
@@ -790,15 +805,17 @@ struct SortedKBuffer16 {
         for (int k = 15; k > 0; k--) S[k] = __builtin_amdgcn_fmed3f(S[k - 1], S[k], z);
         S[0] = fminf(S[0], z);
         if (filling) size++;
+        return (int)slot;
     }
 };
 
 // the K-buffer half of the state machine of one cell (lane = pixel, wavefront 0)
 template <class KB>
-__device__ inline void apply_kbuf(const RasterParams& p, const float4 cell, KB& q) {
+__device__ inline void apply_kbuf(const RasterParams& p, const float4 cell, KB& q, unsigned& inbits) {
     const unsigned aux = __builtin_bit_cast(unsigned, cell.w);
     if ((aux & (CELL_LIVE | CELL_DEPTH)) != (CELL_LIVE | CELL_DEPTH)) return;
-    q.insert(face_id(__builtin_bit_cast(int, cell.y)), cell.x, p.K);
+    const int slot = q.insert(face_id(__builtin_bit_cast(int, cell.y)), cell.x, p.K);
+    if (tune::inside_hint && slot >= 0 && slot < 16) inbits = (inbits & ~(1u << slot)) | (((aux & CELL_INSIDE) ? 1u : 0u) << slot);
 }
 
 // the colour half (lane = pixel, wavefront 1): alpha (SRK:350-358), hard rgb (SRK:390-397) or online softmax (SRK:399-419)
@@ -844,7 +861,8 @@ template <int DIST, int RGB, int KCAP>
 __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int wid, int lane, float4* s_mem,
                                   const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
                                   const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
-                                  float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+                                  float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids,
+                                  unsigned short* __restrict__ hint) {
     constexpr int BATCH = HEAVY_BATCH, CAP = HEAVY_CAP;
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                                        // [BATCH]
     float4* s_cell = reinterpret_cast<float4*>(s_rec + BATCH);                                 // [CAP]
@@ -866,6 +884,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     if (wid == 1) init_colour_state<RGB>(p, s);
     if (wid == 0) {
         if (SORTED) sk.init(p.K, s_kids + lane); else init_kbuffer(p, t, ids, s.q);
+        s.inbits = 0u;
         lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
         s_pix[lane] = make_float2(xp, yp);
     }
@@ -979,7 +998,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
                 for (int k = 0; ballot(k < span.y) != 0ull; k++) {
                     float4 nxt = s_cell[k + 1 < span.y ? span.x + k + 1 : 0];
                     if (!(k + 1 < span.y)) nxt.w = 0.f;
-                    if (wid == 0) { if (SORTED) apply_kbuf(p, cur, sk); else apply_kbuf(p, cur, s.q); }
+                    if (wid == 0) { if (SORTED) apply_kbuf(p, cur, sk, s.inbits); else apply_kbuf(p, cur, s.q, s.inbits); }
                     else apply_colour<RGB, KCAP>(p, cur, s_rec, tbase, s);
                     cur = nxt;
                 }
@@ -993,6 +1012,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
     if (wid == 0) {
         if (SORTED) store_ids<KCAP, false>(p, t, sk, ids); else store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+        if (KCAP == 16 && DIST == 2) store_inside_hint(p, t, s.inbits, hint);
         clk.lap(7);
         if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2]) clk.flush(counters, 4);   // the 16 tiles of the heaviest bin
     }
@@ -1006,7 +1026,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
     unsigned long long* __restrict__ counters, unsigned long long pool_cap,
-    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids, unsigned short* __restrict__ hint) {
     extern __shared__ float4 s_dyn[];
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
@@ -1020,7 +1040,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     if (tune::fwd_prio > 0 && n > tune::fwd_prio) __builtin_amdgcn_s_setprio(3);
     TileGeom t;
     if (!tile_geom(p, bin, k & 15, n, threadIdx.x, t)) return;
-    tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
+    tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids, hint);
 }
 
 // Four wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first (k_bin_schedule) and its
@@ -1033,7 +1053,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
     unsigned long long* __restrict__ counters, unsigned long long pool_cap,
-    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids, unsigned short* __restrict__ hint) {
     extern __shared__ float4 s_dyn[];
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1050,9 +1070,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
     TileGeom t;
     if (!tile_geom(p, bin, sub, n, lane, t)) return;     // (a heavy tile: uniform for the workgroup)
     const unsigned long long* seg = pool + bin_base[bin];
-    if (heavy) tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
+    if (heavy) tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids, hint);
     else tile_single<DIST, RGB, KCAP, HEAVY_BATCH, false>(p, t, lane, s_dyn + wid * (sizeof(FaceRec) * HEAVY_BATCH / sizeof(float4)),
-                                             textures, geo, seg, counters, aggrs, rgba, ids);
+                                             textures, geo, seg, counters, aggrs, rgba, ids, hint);
 }
 
 template <int DIST, int RGB, int KCAP>
@@ -1071,7 +1091,7 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
         const int heavy_cap = (int)(hcap < nbins ? hcap : nbins);
         const int per_xcd = 16 * ((heavy_cap + 7) / 8) + 4 * ((nbins + 7) / 8);
         k_softras_forward_mixed<DIST, RGB, KCAP><<<8 * per_xcd, 256, HEAVY_LDS_BYTES, st>>>(
-            p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+            p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids, ws.inside_hint);
         return;
     }
     const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
@@ -1079,7 +1099,7 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
     static const size_t pad = getenv("JR_FWD_LDS_PAD") ? (size_t)atol(getenv("JR_FWD_LDS_PAD")) : 0;
     const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0) + pad;
     k_softras_forward<DIST, RGB, KCAP><<<grid, 64, smem, st>>>(
-        p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+        p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids, ws.inside_hint);
 }
 
 template <int DIST, int RGB>
