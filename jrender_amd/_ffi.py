@@ -62,6 +62,7 @@ SIGNATURES = {
     "jr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "jr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "jr_softras_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "jr_softras_last_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "jr_debug_section_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "jr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "jr_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -293,6 +294,12 @@ class Context:
         s = (C.c_int64 * 4)()
         _check(load().jr_softras_last_stats(self.handle, s))
         return dict(bin_face_pairs=s[0], nonempty_bins=s[1], max_faces_in_bin=s[2], bins_per_image=s[3])
+
+    def last_launch(self):
+        """Which paths the last launches took (jr_softras_last_launch)."""
+        s = (C.c_int64 * 4)()
+        _check(load().jr_softras_last_launch(self.handle, s))
+        return dict(four_wavefront_kernel=bool(s[0]), heavy_bins=int(s[1]), backward_used_inside_hint=bool(s[2]))
 
     def close(self):
         if self.handle:

@@ -56,6 +56,7 @@ struct jr_ctx {
     int bins_B = 0, bins_NF = 0, bins_IS = 0;
     float bins_rad = 0.f;
     int64_t stats[4] = {0, 0, 0, 0};
+    int64_t launch_info[4] = {0, 0, 0, 0};  // last forward: four-wavefront kernel used, heavy bins; last backward: inside hint used
     unsigned long long* zkey = nullptr;     // n3mr z-buffer keys [B*IS*IS]
     size_t zkey_cap = 0;
     unsigned char* n3_scratch = nullptr;    // n3mr backward: packed per-pixel planes in both orientations
@@ -223,6 +224,8 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     ctx->stats[1] = (int64_t)ctx->h_counters[1];
     ctx->stats[2] = (int64_t)ctx->h_counters[2];
     ctx->stats[3] = (int64_t)p.bins_x * p.bins_y;
+    ctx->launch_info[0] = jr::forward_uses_heavy_path(p) ? 1 : 0;
+    ctx->launch_info[1] = ctx->launch_info[0] ? (int64_t)ctx->h_counters[3] : 0;
     if (pairs > 0x7fffffffULL)       // segment bases are 32-bit
         return fail("%zu (bin, face) pairs exceed the 2^31 - 1 the bin lists index: render fewer views per call", pairs);
     if (!speculative || pairs > ws.pool_cap) {
@@ -444,6 +447,7 @@ int jr_softras_backward_ex(jr_ctx* ctx, const float* face_vertices, const float*
         // the forward's inside hint belongs to THIS geometry generation and these shapes, or it is not used
         const unsigned short* hint = (reuse && ctx->hint_epoch == forward_token && ctx->hint_K == K && K <= 16 && func_id_dist == 2)
                                          ? ctx->ws.inside_hint : nullptr;
+        ctx->launch_info[2] = hint ? 1 : 0;
         jr::launch_softras_backward(ctx->stream, p, textures, soft_colors, aggrs_info, faces_id_buffer,
                                     grad_soft_colors, ctx->ws, hint, grad_faces, grad_textures);
     }
@@ -641,6 +645,12 @@ int jr_debug_section_clocks(jr_ctx* ctx, uint64_t clocks[20]) {
 int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]) {
     if (!ctx || !stats) return fail("NULL argument");
     memcpy(stats, ctx->stats, sizeof(ctx->stats));
+    return 0;
+}
+
+int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]) {
+    if (!ctx || !info) return fail("NULL argument");
+    memcpy(info, ctx->launch_info, sizeof(ctx->launch_info));
     return 0;
 }
 

@@ -39,6 +39,7 @@ void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& w
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
                             const BinWorkspace& ws, float* aggrs_info, float* soft_colors,
                             int32_t* faces_id_buffer);
+bool forward_uses_heavy_path(const RasterParams& p);   // launches of up to tune::fwd_heavy_pixels pixels: four wavefronts per tile of a heavy bin
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,
                              const float* soft_colors, const float* aggrs_info,
                              const int32_t* faces_id_buffer, const float* grad_soft_colors,

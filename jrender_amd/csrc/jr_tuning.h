@@ -45,9 +45,6 @@
 #ifndef JR_TUNE_FWD_HEAVY_PIXELS // forward: launches of up to this many pixels (B x IS x IS) use the four-wavefront kernel, larger ones one wavefront per tile
 #define JR_TUNE_FWD_HEAVY_PIXELS 4194304
 #endif
-#ifndef JR_TUNE_FWD_HEAVY_SORTED // forward, heavy tiles, K <= 16: K-buffer kept in depth order (v_med3 insertion, slot labels in 16 nibbles) instead of slot order
-#define JR_TUNE_FWD_HEAVY_SORTED 1
-#endif
 #ifndef JR_TUNE_FWD_PRIO         // forward: s_setprio(3) for the wavefronts of bins with more than this many listed faces (0 = off)
 #define JR_TUNE_FWD_PRIO 0
 #endif
@@ -93,7 +90,6 @@ constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_prio = JR_TUNE_FWD_PRIO;
 constexpr bool inside_hint = JR_TUNE_INSIDE_HINT != 0;
 constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY;
-constexpr bool fwd_heavy_sorted = JR_TUNE_FWD_HEAVY_SORTED != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 }  // namespace tune
 }  // namespace jr

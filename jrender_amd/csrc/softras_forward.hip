@@ -665,7 +665,7 @@ constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHA
 constexpr int CELL_TEXEL_SHIFT = 12;
 constexpr int HEAVY_BATCH = tune::fwd_batch_mixed;                                              // record slots of a heavy tile = of each of the four tiles of a lighter workgroup
 constexpr int HEAVY_LDS_BYTES = 4 * (int)sizeof(FaceRec) * HEAVY_BATCH;                         // = what four single-wavefront tiles use
-constexpr int HEAVY_FIXED_BYTES = (int)sizeof(FaceRec) * HEAVY_BATCH + 64 * 8 + 64 * 8 + 64 + 2 * 64 * 8 + 16 * 64 * 4;   // records, pixel centres, masks, scalars, per-pixel (first cell, cells) of two rounds, K-buffer ids
+constexpr int HEAVY_FIXED_BYTES = (int)sizeof(FaceRec) * HEAVY_BATCH + 64 * 8 + 64 * 8 + 64 + 2 * 64 * 8;   // records, pixel centres, masks, scalars, per-pixel (first cell, cells) of two rounds
 constexpr int HEAVY_CAP = ((HEAVY_LDS_BYTES - HEAVY_FIXED_BYTES) / 20) & ~63;                   // 16 B cell + 2 B pair + 2 B inside entry per pair
 static_assert(HEAVY_CAP >= 256 && HEAVY_CAP <= 4096, "cell buffer of the heavy-tile path");
 
@@ -725,89 +725,6 @@ __device__ inline float2 evaluate_inside(const RasterParams& p, const FaceRec& r
     }
     return make_float2(D, __builtin_bit_cast(float, aux));
 }
-
-// The K-buffer of a heavy tile's wavefront 0 (K <= 16).  In the tiles that need it, most apply trips have SOME lane that
-// replaces the largest depth, and KBuffer's replace path (per-lane slot write + rescan for the first maximum: ~130
-// instructions) then runs for the whole wavefront at one or two live lanes.  Here every insert is the same ~55
-// instructions, whatever mix of appends and replacements the lanes hold:
-//   S[0..15]  the buffered depths in ASCENDING order (free slots +inf at the top, registers beyond K -inf at the bottom):
-//             "is zp nearer than the largest" is zp < S[15]; dropping the largest and inserting zp is one v_med3 per
-//             register, S[k] = med3(S[k-1], S[k], zp);
-//   L         16 nibbles: the PHYSICAL slot (what SRK:369-385 indexes, what faces_id_buffer is laid out by) of the depth
-//             at each sorted position.  The evicted depth's slot is the top nibble; it passes to the new depth, inserted
-//             at its sorted position (binary search over the registers with selects).
-// Appends are evictions of a free slot: the nibbles start as 15 - k, so that free slots are handed out as 0, 1, 2, ...
-// The reference evicts the FIRST slot that holds the maximum (strict '>' rescan); equal depths sit next to each other in
-// S in no particular order, so a tie at the top is resolved when it matters: the smallest slot of the tied group is
-// swapped to the top before the eviction (oracle statistics of the headline scene: 0.5 % of the evictions).
-// A NaN depth (degenerate faces only) takes a slot while the buffer fills and never leaves it, as in the reference: it is
-// kept as -inf.
-// The face indices go to an LDS table [slot][lane] (one conflict-free ds_write per insert) and leave for
-// faces_id_buffer at the end of the tile: the per-insert global stores of the single-wavefront path scatter over up to 64
-// cache lines each, and a heavy tile's lone wavefront waited for them (apply: 600 clocks per trip).
-struct SortedKBuffer16 {
-    float S[16];
-    unsigned long long L;
-    int size;
-    int* lds_ids;                  // this lane's column of the [16][64] table
-
-    __device__ inline int id_of(int k) const { return k < size ? lds_ids[k * 64] : -1; }
-    __device__ inline void init(int K, int* ids_column) {
-        lds_ids = ids_column;
-#pragma unroll
-        for (int k = 0; k < 16; k++) S[k] = k >= 16 - K ? __builtin_inff() : -__builtin_inff();
-        L = 0x0123456789ABCDEFull;          // nibble k = 15 - k
-        size = 0;
-    }
-    __device__ inline int insert(int fn, float zp, int K) {
-        const float inf = __builtin_inff();
-        const bool filling = S[15] == inf;
-        const float z = (zp != zp) ? (filling ? -inf : inf) : zp;
-        if (!(z < S[15])) return -1;
-        if (S[14] == S[15] && !filling) {
-            // tie at the top: the reference evicts the smallest slot of the group
-            unsigned bl = (unsigned)(L >> 60);
-            int best = 15;
-            bool run = true;
-#pragma unroll
-            for (int k = 14; k >= 0; k--) {
-                run = run && (S[k] == S[15]);
-                const unsigned lab = (unsigned)(L >> (4 * k)) & 15u;
-                if (run && lab < bl) { bl = lab; best = k; }
-            }
-            if (best != 15) {
-                const unsigned top = (unsigned)(L >> 60);
-                const int sh = 4 * best;
-                L = (L & ~((15ull << 60) | (15ull << sh))) | ((unsigned long long)bl << 60) | ((unsigned long long)top << sh);
-            }
-        }
-        const unsigned slot = (unsigned)(L >> 60);
-        lds_ids[slot * 64] = fn;
-        // sorted position among S[0..14]: the number of depths below z (binary search with selects; z goes in front of its equals)
-        // (values first, selects second: a conditional expression over S[i] / S[j] would become ONE load through a selected
-        // address and push the whole array into scratch memory)
-        const float s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3], s4 = S[4], s5 = S[5], s6 = S[6], s7 = S[7], s8 = S[8],
-                    s9 = S[9], s10 = S[10], s11 = S[11], s12 = S[12], s13 = S[13], s14 = S[14];
-        const bool c3 = s7 < z;
-        const float a = c3 ? s11 : s3;
-        const bool c2 = a < z;
-        const float b1 = c2 ? s13 : s9, b0 = c2 ? s5 : s1;
-        const float b = c3 ? b1 : b0;
-        const bool c1 = b < z;
-        const float d3 = c1 ? s14 : s12, d2 = c1 ? s10 : s8, d1 = c1 ? s6 : s4, d0 = c1 ? s2 : s0;
-        const float dh = c2 ? d3 : d2, dl = c2 ? d1 : d0;
-        const float d = c3 ? dh : dl;
-        const bool c0 = d < z;
-        const int sh = 4 * ((c3 ? 8 : 0) + (c2 ? 4 : 0) + (c1 ? 2 : 0) + (c0 ? 1 : 0));
-        const unsigned long long low = (1ull << sh) - 1ull;
-        L = (L & low) | ((unsigned long long)slot << sh) | ((L & ~low) << 4);      // the old top nibble (= slot) falls off
-#pragma unroll
-        for (int k = 15; k > 0; k--) S[k] = __builtin_amdgcn_fmed3f(S[k - 1], S[k], z);
-        S[0] = fminf(S[0], z);
-        if (filling) size++;
-        return (int)slot;
-    }
-};
 
 // the K-buffer half of the state machine of one cell (lane = pixel, wavefront 0)
 template <class KB>
@@ -870,20 +787,17 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     unsigned long long* s_M = reinterpret_cast<unsigned long long*>(s_pix + 64);               // [64] face masks of the batch
     int* s_misc = reinterpret_cast<int*>(s_M + 64);                                            // [16] fill, total, j1, inside count
     int2* s_span = reinterpret_cast<int2*>(s_misc + 16);                                       // [2][64] a pixel's first cell, number of cells (by round parity)
-    int* s_kids = reinterpret_cast<int*>(s_span + 128);                                        // [16][64] face indices of the sorted K-buffer
-    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_kids + 16 * 64);                   // [CAP] slot | pixel << 6
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_span + 128);                   // [CAP] slot | pixel << 6
     unsigned short* s_in = s_pair + CAP;                                                       // [CAP] cells of inside pairs
     const float xp = t.xp, yp = t.yp;
     const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
     PixelState<KCAP> s;                                  // the K-buffer lives in wavefront 0, the colour state in wavefront 1
-    constexpr bool SORTED = KCAP == 16 && tune::fwd_heavy_sorted && ids_in_global<KCAP>();
-    SortedKBuffer16 sk;                                  // wavefront 0's K-buffer when K <= 16
     ListWalker lw;
     SectionClock clk;            // instrumented builds only (wavefront 0): 0 stage, 1 masks, 2 pair list, 3 evaluate, 5 inside, 6 apply, 7 stores
     clk.start();
     if (wid == 1) init_colour_state<RGB>(p, s);
     if (wid == 0) {
-        if (SORTED) sk.init(p.K, s_kids + lane); else init_kbuffer(p, t, ids, s.q);
+        init_kbuffer(p, t, ids, s.q);
         s.inbits = 0u;
         lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
         s_pix[lane] = make_float2(xp, yp);
@@ -998,7 +912,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
                 for (int k = 0; ballot(k < span.y) != 0ull; k++) {
                     float4 nxt = s_cell[k + 1 < span.y ? span.x + k + 1 : 0];
                     if (!(k + 1 < span.y)) nxt.w = 0.f;
-                    if (wid == 0) { if (SORTED) apply_kbuf(p, cur, sk, s.inbits); else apply_kbuf(p, cur, s.q, s.inbits); }
+                    if (wid == 0) apply_kbuf(p, cur, s.q, s.inbits);
                     else apply_colour<RGB, KCAP>(p, cur, s_rec, tbase, s);
                     cur = nxt;
                 }
@@ -1011,7 +925,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     }
     if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
     if (wid == 0) {
-        if (SORTED) store_ids<KCAP, false>(p, t, sk, ids); else store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+        store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
         if (KCAP == 16 && DIST == 2) store_inside_hint(p, t, s.inbits, hint);
         clk.lap(7);
         if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2]) clk.flush(counters, 4);   // the 16 tiles of the heaviest bin
@@ -1075,6 +989,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
                                              textures, geo, seg, counters, aggrs, rgba, ids, hint);
 }
 
+bool forward_uses_heavy_path(const RasterParams& p) {
+    return tune::fwd_heavy > 0 && p.tex == 0 && (long)p.B * p.IS * p.IS <= (long)tune::fwd_heavy_pixels;
+}
+
 template <int DIST, int RGB, int KCAP>
 static void launch_kk(hipStream_t st, const RasterParams& p, const float* textures,
                       const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
@@ -1084,8 +1002,7 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
     // waiting wavefronts hold slots that a full GPU has better uses for (eight views: 0.89 -> 0.98 ms even when only the
     // bins above 1024 faces are heavy): the four-wavefront kernel takes launches of up to fwd_heavy_pixels pixels.
     // Heavy tiles need single-texel or per-texel surface colours (the cell has no room for three vertex colours).
-    const bool small = (long)p.B * p.IS * p.IS <= (long)tune::fwd_heavy_pixels;
-    if (tune::fwd_heavy > 0 && p.tex == 0 && small) {
+    if (forward_uses_heavy_path(p)) {
         // upper bound of the heavy bins the device will find: their lists hold more than fwd_heavy_floor() entries each
         const long hcap = (long)(ws.pool_cap / (unsigned long long)fwd_heavy_floor()) + 8;
         const int heavy_cap = (int)(hcap < nbins ? hcap : nbins);

@@ -192,3 +192,55 @@ def test_whole_view_dense_backward_vs_oracle(scene):
     others = [v for v in range(B) if v != view]
     assert np.abs(gf[others]).max() == 0 and np.abs(gt[others]).max() == 0
     assert (np.abs(gfo) > 0).mean() > 0.2            # the view's gradient is dense, not a corner case
+
+
+def test_heavy_tile_path_whole_view_forward_and_dense_backward():
+    """Round 3: launches of up to 4 Mpixels run the four-wavefront kernel - the tiles of bins with more than 512 listed
+    faces (the sphere's limb) are evaluated by four wavefronts on a dense pair list and applied by two.  ONE 39k-face
+    view at 1024^2 rendered on its own takes that path (asserted through jr_softras_last_launch): every pixel of the
+    index buffer bit-exact against the oracle, RGBA / aggregates 1e-4, and the dense backward (which also uses the
+    forward's inside hint) within 1e-4 of the largest gradient."""
+    ctx = _ffi.Context.default()
+    port = Oracle("port", nthreads=0)
+    fv, tex = syn.sphere_views(NF, 1, azimuth0=77.0)
+    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+    out = fn(fv, tex)
+    info = ctx.last_launch()
+    assert info["four_wavefront_kernel"] and info["heavy_bins"] >= 4, info
+    saved = [x.numpy() for x in fn.save_vars]
+    ref = port.forward(fv, tex, image_size=IS, max_faces_per_pixel_for_grad=K)
+    assert port.ub_events() == 0
+    bad = (saved[5] != ref["faces_id_buffer"]).any(1)
+    assert not bad.any(), "id buffer differs in %d pixels, first at %s" % (bad.sum(), np.argwhere(bad)[:3].tolist())
+    assert bits_equal(saved[3], ref["faces_info"])
+    assert rel_err(out.numpy(), ref["soft_colors"], RGBA_ATOL) <= 1.0
+    assert rel_err(saved[4], ref["aggrs_info"], RGBA_ATOL) <= 1.0
+    g = np.random.default_rng(23).uniform(-1, 1, (1, 4, IS, IS)).astype(np.float32)
+    gf, gt = fn.grad(g)
+    assert ctx.last_launch()["backward_used_inside_hint"]
+    gfo, gto = port.backward(ref, g, nthreads=port.num_procs())
+    assert grad_err(gf.numpy().reshape(gfo.shape), gfo) <= 1e-4 and grad_err(gt.numpy(), gto) <= 1e-4
+    # the same forward through the one-wavefront-per-tile kernel (a batch of 8 is beyond the pixel budget): same bits
+    fv8, tex8 = np.repeat(fv, 8, 0), np.repeat(tex, 8, 0)
+    fn8 = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+    out8 = fn8(fv8, tex8)
+    assert not ctx.last_launch()["four_wavefront_kernel"]
+    assert bits_equal(fn8.save_vars[5].numpy()[3:4], saved[5])
+    assert rel_err(out8.numpy()[3:4], out.numpy(), RGBA_ATOL) <= 1.0
+
+
+def test_backward_is_the_same_with_and_without_the_inside_hint(scene):
+    """The hint only orders the backward's work items.  A backward whose forward token is stale (another forward ran
+    on the context in between) rebuilds the records and runs WITHOUT the hint: same gradients to the 1e-4 bar
+    (float atomics reorder the sums)."""
+    ctx, fv, tex, fn, saved = scene
+    g = ctx.array(np.random.default_rng(29).uniform(-1, 1, (B, 4, IS, IS)).astype(np.float32))
+    fn2 = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+    fn2(fv, tex)
+    a = fn2.grad(g)
+    assert ctx.last_launch()["backward_used_inside_hint"]
+    other = SoftRasterizeFunction(image_size=64, ctx=ctx)          # any other forward: fn2's token is stale now
+    other(*syn.sphere_views(280, 1))
+    b_ = fn2.grad(g)
+    assert not ctx.last_launch()["backward_used_inside_hint"]
+    assert grad_err(a[0].numpy(), b_[0].numpy()) <= 1e-4 and grad_err(a[1].numpy(), b_[1].numpy()) <= 1e-4
