@@ -218,7 +218,7 @@ int jr_selftest_reciprocal(jr_ctx* ctx, uint64_t* mismatches);
  * [2]=max faces in a bin, [3]=bins per image */
 int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]);
 /* which paths the last launches took: [0]=1 when the last forward ran the four-wavefront kernel (launches of up to 4 Mpixels),
- * [1]=bins whose tiles got four wavefronts each in it, [2]=1 when the last backward used the forward's inside hint, [3]=0 */
+ * [1]=bins whose tiles got four wavefronts each in it, [2]=[3]=0 */
 int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]);
 /* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
  * previous call, [0..7] forward raster, [8..15] backward raster; all zero in the product build */

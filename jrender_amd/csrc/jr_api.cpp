@@ -50,13 +50,11 @@ struct jr_ctx {
     // deliberately not part of the test: allocators recycle addresses.
     uint64_t geo_epoch = 0;
     uint64_t last_forward_token = 0;
-    uint64_t hint_epoch = 0;                // generation whose forward wrote ws.inside_hint (K <= 16, euclidean), 0 = none
-    int hint_K = 0;
     int bins_T = 0;
     int bins_B = 0, bins_NF = 0, bins_IS = 0;
     float bins_rad = 0.f;
     int64_t stats[4] = {0, 0, 0, 0};
-    int64_t launch_info[4] = {0, 0, 0, 0};  // last forward: four-wavefront kernel used, heavy bins; last backward: inside hint used
+    int64_t launch_info[4] = {0, 0, 0, 0};  // last forward: four-wavefront kernel used, heavy bins
     unsigned long long* zkey = nullptr;     // n3mr z-buffer keys [B*IS*IS]
     size_t zkey_cap = 0;
     unsigned char* n3_scratch = nullptr;    // n3mr backward: packed per-pixel planes in both orientations
@@ -195,16 +193,6 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
                      float* faces_info, float* aggrs_info, float* soft_colors, int32_t* faces_id_buffer) {
     jr::BinWorkspace& ws = ctx->ws;
     if (setup_faces(ctx, p, faces, textures, faces_info)) return 1;
-    {   // side plane of the forward -> backward scheduling hint (2 bytes per pixel)
-        const size_t npix = (size_t)p.B * p.IS * p.IS;
-        if (npix > ws.hint_cap || !ws.inside_hint) {
-            size_t c = ws.hint_cap;
-            if (grow(ws.inside_hint, c, npix, 1.0)) return 1;
-            ws.hint_cap = c;
-        }
-        ctx->hint_epoch = (p.K <= 16 && p.dist == 2) ? ctx->geo_epoch : 0;
-        ctx->hint_K = p.K;
-    }
     JR_HIP(hipMemcpyAsync(ctx->h_counters, ws.counters, sizeof(unsigned long long) * 4,
                           hipMemcpyDeviceToHost, ctx->stream));
     JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));
@@ -281,7 +269,6 @@ int jr_ctx_destroy(jr_ctx* ctx) {
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     jr::BinWorkspace& ws = ctx->ws;
     (void)hipFree(ctx->zkey); (void)hipFree(ctx->n3_scratch);
-    (void)hipFree(ws.inside_hint);
     (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor); (void)hipFree(ws.bin_order);
     (void)hipFree(ws.counters); (void)hipFree(ws.pool); (void)hipFree(ws.pool_scratch);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
@@ -444,12 +431,8 @@ int jr_softras_backward_ex(jr_ctx* ctx, const float* face_vertices, const float*
     if (!reuse && setup_faces(ctx, p, face_vertices, textures, nullptr)) return 1;
     {
         ProfScope ps(ctx, JR_PHASE_BWD_RASTER);
-        // the forward's inside hint belongs to THIS geometry generation and these shapes, or it is not used
-        const unsigned short* hint = (reuse && ctx->hint_epoch == forward_token && ctx->hint_K == K && K <= 16 && func_id_dist == 2)
-                                         ? ctx->ws.inside_hint : nullptr;
-        ctx->launch_info[2] = hint ? 1 : 0;
         jr::launch_softras_backward(ctx->stream, p, textures, soft_colors, aggrs_info, faces_id_buffer,
-                                    grad_soft_colors, ctx->ws, hint, grad_faces, grad_textures);
+                                    grad_soft_colors, ctx->ws, grad_faces, grad_textures);
     }
     JR_HIP(hipGetLastError());
     return 0;

@@ -19,8 +19,7 @@ struct BinWorkspace {
     unsigned long long* counters = nullptr;    // [4] device: total pairs, non-empty bins, max count, heavy bins (a prefix of bin_order)
     unsigned long long* pool = nullptr;        // [pool_cap] (face id << 32 | tile mask), per bin ascending
     unsigned long long* pool_scratch = nullptr;// [pool_cap] the same segments as filled (unordered)
-    unsigned short* inside_hint = nullptr;     // [B*IS*IS] forward -> backward scheduling hint (K <= 16, euclidean): bit k = pixel strictly inside the face of slot k
-    size_t faces_cap = 0, bins_cap = 0, pool_cap = 0, hint_cap = 0;
+    size_t faces_cap = 0, bins_cap = 0, pool_cap = 0;
 };
 
 // Launch order of the bins (k_bin_schedule): ~12 buckets per octave of the list length, heaviest first.  Bins in
@@ -43,7 +42,7 @@ bool forward_uses_heavy_path(const RasterParams& p);   // launches of up to tune
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,
                              const float* soft_colors, const float* aggrs_info,
                              const int32_t* faces_id_buffer, const float* grad_soft_colors,
-                             const BinWorkspace& ws, const unsigned short* inside_hint, float* grad_faces, float* grad_textures);
+                             const BinWorkspace& ws, float* grad_faces, float* grad_textures);
 
 void launch_face_vertices_forward(hipStream_t st, const float* vertices, const int32_t* faces,
                                   float* fv, int B, int NV, int NF);

@@ -51,10 +51,6 @@
 #ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert
 #define JR_TUNE_DIAG 0
 #endif
-#ifndef JR_TUNE_INSIDE_HINT      // forward (K <= 16, euclidean) keeps one bit per K-buffer slot 'the pixel is strictly inside this face' in a side plane;
-                                 // the backward schedules the pairs that need three edge projections together (scheduling only: never changes a result)
-#define JR_TUNE_INSIDE_HINT 1
-#endif
 #ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
@@ -88,7 +84,6 @@ constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
 constexpr bool fwd_defer_inside = JR_TUNE_FWD_DEFER_INSIDE != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_prio = JR_TUNE_FWD_PRIO;
-constexpr bool inside_hint = JR_TUNE_INSIDE_HINT != 0;
 constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 }  // namespace tune

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
-    const int32_t* __restrict__ ids, const unsigned short* __restrict__ inside_hint, const float* __restrict__ grad_rgba,
+    const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
     float* __restrict__ grad_faces, float* __restrict__ grad_textures, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 s_dyn[];
     // faces per batch: a tile of the headline workload needs ~40; 64 slots of 176 B cap a CU at 13 wavefronts
@@ -227,9 +227,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
     float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
     __shared__ unsigned long long s_has[BATCH];     // slot -> pixels (lanes) that hold the face
-    __shared__ unsigned long long s_hin[BATCH];     // ... and those of them that lie strictly inside it (the forward's hint)
-    __shared__ int s_ioff[CHUNK + 1];                // slot -> first of its work items of class B (exclusive prefix), [64] = total
-    __shared__ unsigned char s_alist[CHUNK];        // class A items (one per slot with inside pixels) -> slot
+    __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
 
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
     const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
@@ -266,18 +264,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         if (!ballot(raw[0] >= 0)) return;           // nothing buffered anywhere in this tile
 #pragma unroll
         for (int k = 1; k < KCAP; k++) raw[k] = (valid && k < p.K) ? ip[(size_t)k * pp] : -1;
-        // The forward's hint (K <= 16, euclidean): bit k = this pixel lies strictly inside the face of slot k.  Inside pairs
-        // need three edge projections instead of one (105 more instructions) and with 64 lanes on arbitrary pairs nearly
-        // every trip had one.  The bit rides in the sort key (id << 1 | bit), the extraction below yields every face's
-        // holder mask AND its inside-holder mask, and the work items are ordered so that the inside holders of all faces
-        // share a few trips.  A hint only: every lane still evaluates the exact predicate, a wrong bit costs time, not bits.
-        const unsigned hint = (KCAP <= 16 && DIST == 2 && tune::inside_hint && inside_hint != nullptr && valid)
-                                  ? inside_hint[(size_t)b * pp + pn] : 0u;
         bool live = true;
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             live = live && raw[k] >= 0 && raw[k] < p.NF;   // -1 ends the list (ids outside [0, NF) too)
-            mine[k] = live ? ((raw[k] << 1) | (int)((hint >> k) & 1u)) : BIG;
+            mine[k] = live ? raw[k] : BIG;
         }
     }
     sort_ascending(mine);
@@ -312,14 +303,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     clk.lap(0);
     for (;;) {
         int fill = 0, myid = 0;
-        unsigned long long has = 0ull, hin = 0ull;
+        unsigned long long has = 0ull;
         while (fill < BATCH) {
-            const int m = wave_min(cur >> 1);                       // face id (the key's low bit is the inside hint)
-            if (m == (BIG >> 1)) break;
-            const bool hit = (cur >> 1) == m;
+            const int m = wave_min(cur);
+            if (m == BIG) break;
+            const bool hit = cur == m;
             const unsigned long long h = ballot(hit);
-            const unsigned long long hi = ballot(hit && (cur & 1));
-            if (lane == fill) { myid = m; has = h; hin = hi; }
+            if (lane == fill) { myid = m; has = h; }
             if (hit) {
 #pragma unroll
                 for (int k = 0; k + 1 < KCAP; k++) mine[k] = mine[k + 1];
@@ -345,25 +335,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         }
 
         // ---- work items: (face slot, group of <= 16 of the pixels that hold it) ----
-        // A slot's holders are numbered inside pixels first.  Class A = the FIRST item of every slot that has inside
-        // holders (all of them, unless a face has more than 16 in this tile); class B = all other items.  A items run
-        // first, four per trip: the trips after them skip the three-projection path altogether.
         const int items = (__builtin_popcountll(has) + 15) >> 4;
-        const bool flagged = hin != 0ull;
-        const unsigned long long fa = ballot(flagged);
-        const int nA = __builtin_popcountll(fa);
-        const int bitems = items - (flagged ? 1 : 0);
-        int incl = bitems;
+        int incl = items;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(incl, d);
             if (lane >= d) incl += o;
         }
-        const int nitems = nA + __builtin_amdgcn_readlane(incl, 63);
-        if (lane < BATCH) { s_has[lane] = has; s_hin[lane] = hin; }
-        s_ioff[lane] = incl - bitems;
-        if (lane == 0) s_ioff[64] = nitems - nA;
-        if (flagged) s_alist[__builtin_amdgcn_mbcnt_hi((unsigned)(fa >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fa, 0u))] = (unsigned char)lane;
+        const int nitems = __builtin_amdgcn_readlane(incl, 63);
+        if (lane < BATCH) s_has[lane] = has;
+        s_ioff[lane] = incl - items;
+        if (lane == 0) s_ioff[64] = nitems;
         __syncthreads();
 
         // ---- each 16-lane DPP row takes one item per trip (four faces in flight per wavefront): gather
@@ -372,36 +354,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         clk.lap(2);
         // The item of the NEXT trip is looked up (slot, rank base, holder mask: dependent LDS reads) before the
         // reduction of the current one, so that the latency hides behind the reduction instead of heading the trip.
-        int j = 0, jb = 0, nth = 64;
-        unsigned long long hs = 0ull;      // the holders this row's lanes number with nth: inside ones first
-        int cin = 0;
-        unsigned long long hsin = 0ull;
-        bool ract = false;
-        auto lookup = [&](int item) {                           // -> j, nth, hs, hsin, cin of this row's item
-            ract = item < nitems;
-            nth = 64; hs = 0ull; hsin = 0ull; cin = 0;
-            if (ract) {
-                int first;
-                if (item < nA) { j = s_alist[item]; first = 0; }
-                else {
-                    const int ib = item - nA;
-                    while (s_ioff[jb + 1] <= ib) jb++;
-                    j = jb;
-                    first = ib - s_ioff[jb];
-                }
-                hs = s_has[j]; hsin = s_hin[j];
-                cin = __builtin_popcountll(hsin);
-                if (item >= nA && cin > 0) first++;             // the slot's item 0 ran in class A
-                nth = first * 16 + li;
-            }
-        };
-        lookup(blk);
+        int j = 0, nth = 64;
+        unsigned long long hs = 0ull;
+        bool ract = blk < nitems;                                // uniform within a row
+        if (ract) {
+            while (s_ioff[j + 1] <= blk) j++;
+            nth = (blk - s_ioff[j]) * 16 + li;
+            hs = s_has[j];
+        }
         for (int i0 = 0; i0 < nitems; i0 += 4) {
             const int jc = j;                                    // slot of this trip's item
             const bool ractc = ract;
             const bool act = nth < __builtin_popcountll(hs);
-            const bool in_part = nth < cin;                      // holder number nth: the inside holders come first
-            const int src = act ? select_bit(in_part ? hsin : (hs & ~hsin), in_part ? nth : nth - cin) : lane;   // the pixel (lane) this pair belongs to
+            const int src = act ? select_bit(hs, nth) : lane;    // the pixel (lane) this pair belongs to
             PixelGrad q;
             q.g0 = gather(px.g0, src); q.g1 = gather(px.g1, src); q.g2 = gather(px.g2, src); q.g3 = gather(px.g3, src);
             q.o0 = gather(px.o0, src); q.o1 = gather(px.o1, src); q.o2 = gather(px.o2, src); q.o3 = gather(px.o3, src);
@@ -449,7 +414,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             }
             clk.lap(4);
             const int fn = face_id(fr.meta);
-            lookup(i0 + 4 + blk);                                // next trip's item
+            {                                                    // next trip's item
+                const int item = i0 + 4 + blk;
+                ract = item < nitems;
+                nth = 64; hs = 0ull;
+                if (ract) {
+                    while (s_ioff[j + 1] <= item) j++;
+                    nth = (item - s_ioff[j]) * 16 + li;
+                    hs = s_has[j];
+                }
+            }
             const float s = row_transpose_reduce(v, li);         // lane li: component li summed over the row
             if (ractc && s != 0.f) {                              // SRK:1349-1358 does one atomic per pixel
                 if (li < 9) atomicAdd(gfbase + (size_t)fn * 9 + li, s);
@@ -477,32 +451,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
 template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, const float* rgba, const float* aggrs, const int32_t* ids,
-                     const unsigned short* hint, const float* grad_rgba, float* grad_faces, float* grad_textures) {
+                     const float* grad_rgba, float* grad_faces, float* grad_textures) {
     const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
     const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0);
     if (p.K <= 16)
         k_softras_backward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, hint, grad_rgba,
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures, ws.counters);
     else if (p.K <= 32)
         k_softras_backward<DIST, RGB, 32><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, hint, grad_rgba,
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures, ws.counters);
     else
         k_softras_backward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, hint, grad_rgba,
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
             grad_faces, grad_textures, ws.counters);
 }
 
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,
                              const float* rgba, const float* aggrs, const int32_t* ids,
-                             const float* grad_rgba, const BinWorkspace& ws, const unsigned short* hint,
-                             float* grad_faces, float* grad_textures) {
+                             const float* grad_rgba, const BinWorkspace& ws, float* grad_faces,
+                             float* grad_textures) {
     const int ntiles = p.B * p.bins_x * p.bins_y * SUBS * SUBS;
     (void)hipMemsetAsync(grad_faces, 0, sizeof(float) * (size_t)p.B * p.NF * 9, st);          // SRK:1374
     (void)hipMemsetAsync(grad_textures, 0, sizeof(float) * (size_t)p.B * p.NF * p.T * 3, st); // SRK:1375
 #define JR_BWD(D, R) \
-    launch_k<D, R>(st, p, ntiles, textures, ws, rgba, aggrs, ids, hint, grad_rgba, grad_faces, grad_textures)
+    launch_k<D, R>(st, p, ntiles, textures, ws, rgba, aggrs, ids, grad_rgba, grad_faces, grad_textures)
     const int rgb = p.rgb == 0 ? 0 : (p.rgb == 1 ? 1 : 2);
     switch (p.dist * 3 + rgb) {
         case 0: JR_BWD(0, 0); break;

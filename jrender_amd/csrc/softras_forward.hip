@@ -144,7 +144,6 @@ template <int KCAP>
 struct PixelState {                 // SRK:291-309
     float c0, c1, c2, alpha, ssum, smax, depth_min;
     int face_min;
-    unsigned inbits;                // bit k: the pixel lies strictly inside the face of K-buffer slot k (a hint for the backward's schedule)
     KBuffer<KCAP> q;
 };
 
@@ -233,7 +232,7 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
     const Bary w = barycentric(r, xp, yp);
     const int meta = r.meta;
     float D = 1.f, neg_num = -1.f;
-    bool deferred = false, inside = false;
+    bool deferred = false;
     if (DIST == 0) {                                                           // SRK:331-333
         if (!pixel_inside(w)) return false;
     } else if (DIST == 1) {                                                    // SRK:335-338
@@ -243,7 +242,6 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
         D = coverage_fast(neg_num, p);
     } else if (tune::fwd_defer_inside) {                                       // SRK:340-344
         deferred = strictly_inside_t<FAST>(w);
-        inside = deferred;
         if (!deferred) {
             const float dis = euclidean_outside_dis<FAST>(r, meta, w, xp, yp);
             if (dis >= p.thr) return false;
@@ -259,7 +257,6 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
             dis = dd.dx * dd.dx + dd.dy * dd.dy;
         }
         if (sign < 0 && dis >= p.thr) return false;
-        inside = sign > 0.f;
         neg_num = -sign * dis;
         D = coverage_fast(neg_num, p);
     }
@@ -270,9 +267,7 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
     const float zp = depth_of<FAST>(r, wc);
     if (zp < p.near_ || zp > p.far_) return deferred;                         // SRK:365
     const int fn = face_id(meta);
-    const int slot = s.q.insert(fn, zp, p.K);
-    if (DIST == 2 && KCAP == 16 && tune::inside_hint && slot >= 0)
-        s.inbits = (s.inbits & ~(1u << slot)) | ((inside ? 1u : 0u) << slot);
+    s.q.insert(fn, zp, p.K);
 
     if (RGB == 0) {                                                            // SRK:390-397
         if (zp < s.depth_min && pixel_inside(w) && (p.double_side || face_front(meta))) {
@@ -352,7 +347,6 @@ __device__ inline void init_colour_state(const RasterParams& p, PixelState<KCAP>
     else if (RGB == 1) { s.c0 = p.bg[0] * s.ssum; s.c1 = p.bg[1] * s.ssum; s.c2 = p.bg[2] * s.ssum; }
     s.depth_min = 10000000.f;
     s.face_min = -1;
-    s.inbits = 0u;
 }
 template <class KB>
 __device__ inline void init_kbuffer(const RasterParams& p, const TileGeom& t, int32_t* __restrict__ ids, KB& q) {
@@ -400,17 +394,11 @@ __device__ inline void store_ids(const RasterParams& p, const TileGeom& t, const
             else if (k >= q.size) io[(size_t)k * pp] = -1;           // the filled slots were stored when they were filled
         }
 }
-// hint for the backward's schedule (context-owned side plane, [B, IS, IS] u16): bit k = strictly inside the face of slot k
-__device__ inline void store_inside_hint(const RasterParams& p, const TileGeom& t, unsigned inbits, unsigned short* __restrict__ hint) {
-    if (tune::inside_hint && hint && t.valid) hint[((size_t)t.b * p.IS + t.row) * p.IS + t.col] = (unsigned short)inbits;
-}
 template <int RGB, int KCAP>
 __device__ inline void store_pixel(const RasterParams& p, const TileGeom& t, const PixelState<KCAP>& s,
-                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids,
-                                   unsigned short* __restrict__ hint) {
+                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     store_colour<RGB>(p, t, s, aggrs, rgba);
     store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
-    if (KCAP == 16) store_inside_hint(p, t, s.inbits, hint);
 }
 
 // ---- cull + stage: lane = list entry ------------------------------------------------------------------------
@@ -579,8 +567,7 @@ template <int DIST, int RGB, int KCAP, int BATCH, bool WAVE_IS_WG>
 __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int lane, float4* s_mem,
                                    const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
                                    const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
-                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids,
-                                   unsigned short* __restrict__ hint) {
+                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                        // [BATCH] record slots of this wavefront
     float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
     SectionClock clk;            // instrumented builds only: 0 set-up, 1 cull + stage, 2 ballots + pre-cull, 3 raster loop, 4 stores
@@ -631,7 +618,7 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
         clk.lap(3);
     }
     clk.lap(1);
-    store_pixel<RGB>(p, t, s, aggrs, rgba, ids, hint);
+    store_pixel<RGB>(p, t, s, aggrs, rgba, ids);
     clk.lap(4);
     if (JR_TUNE_PROFILE_SECTIONS == 1) clk.flush(counters, 4);
 }
@@ -661,7 +648,7 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
 // dependent steps in the same order; only the commutative alpha / softmax sums of inside pairs are unaffected here
 // (they stay in face order).
 // =====================================================================================================================
-constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHARD = 256u, CELL_INCLOSED = 512u, CELL_INSIDE = 1024u;
+constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHARD = 256u, CELL_INCLOSED = 512u;
 constexpr int CELL_TEXEL_SHIFT = 12;
 constexpr int HEAVY_BATCH = tune::fwd_batch_mixed;                                              // record slots of a heavy tile = of each of the four tiles of a lighter workgroup
 constexpr int HEAVY_LDS_BYTES = 4 * (int)sizeof(FaceRec) * HEAVY_BATCH;                         // = what four single-wavefront tiles use
@@ -695,7 +682,7 @@ __device__ inline float4 evaluate_pair(const RasterParams& p, const FaceRec& r, 
     }
     unsigned aux = slot;
     if (live) {
-        aux |= CELL_LIVE | (deferred ? CELL_INSIDE : 0u);
+        aux |= CELL_LIVE;
         if (p.alpha == 0 && !deferred) {           // 'hard' alpha: the decision of alpha_accumulate, taken here
             const float x = (DIST == 0) ? -1.f
                           : ((neg_num == 0.f || in_fast_range(neg_num)) ? div_known<FAST>(neg_num, p.sigma, p.r_sigma)
@@ -728,11 +715,10 @@ __device__ inline float2 evaluate_inside(const RasterParams& p, const FaceRec& r
 
 // the K-buffer half of the state machine of one cell (lane = pixel, wavefront 0)
 template <class KB>
-__device__ inline void apply_kbuf(const RasterParams& p, const float4 cell, KB& q, unsigned& inbits) {
+__device__ inline void apply_kbuf(const RasterParams& p, const float4 cell, KB& q) {
     const unsigned aux = __builtin_bit_cast(unsigned, cell.w);
     if ((aux & (CELL_LIVE | CELL_DEPTH)) != (CELL_LIVE | CELL_DEPTH)) return;
-    const int slot = q.insert(face_id(__builtin_bit_cast(int, cell.y)), cell.x, p.K);
-    if (tune::inside_hint && slot >= 0 && slot < 16) inbits = (inbits & ~(1u << slot)) | (((aux & CELL_INSIDE) ? 1u : 0u) << slot);
+    q.insert(face_id(__builtin_bit_cast(int, cell.y)), cell.x, p.K);
 }
 
 // the colour half (lane = pixel, wavefront 1): alpha (SRK:350-358), hard rgb (SRK:390-397) or online softmax (SRK:399-419)
@@ -778,8 +764,7 @@ template <int DIST, int RGB, int KCAP>
 __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int wid, int lane, float4* s_mem,
                                   const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
                                   const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
-                                  float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids,
-                                  unsigned short* __restrict__ hint) {
+                                  float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     constexpr int BATCH = HEAVY_BATCH, CAP = HEAVY_CAP;
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                                        // [BATCH]
     float4* s_cell = reinterpret_cast<float4*>(s_rec + BATCH);                                 // [CAP]
@@ -798,7 +783,6 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     if (wid == 1) init_colour_state<RGB>(p, s);
     if (wid == 0) {
         init_kbuffer(p, t, ids, s.q);
-        s.inbits = 0u;
         lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
         s_pix[lane] = make_float2(xp, yp);
     }
@@ -912,7 +896,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
                 for (int k = 0; ballot(k < span.y) != 0ull; k++) {
                     float4 nxt = s_cell[k + 1 < span.y ? span.x + k + 1 : 0];
                     if (!(k + 1 < span.y)) nxt.w = 0.f;
-                    if (wid == 0) apply_kbuf(p, cur, s.q, s.inbits);
+                    if (wid == 0) apply_kbuf(p, cur, s.q);
                     else apply_colour<RGB, KCAP>(p, cur, s_rec, tbase, s);
                     cur = nxt;
                 }
@@ -926,7 +910,6 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
     if (wid == 0) {
         store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
-        if (KCAP == 16 && DIST == 2) store_inside_hint(p, t, s.inbits, hint);
         clk.lap(7);
         if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2]) clk.flush(counters, 4);   // the 16 tiles of the heaviest bin
     }
@@ -940,7 +923,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
     unsigned long long* __restrict__ counters, unsigned long long pool_cap,
-    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids, unsigned short* __restrict__ hint) {
+    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     extern __shared__ float4 s_dyn[];
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
@@ -954,7 +937,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     if (tune::fwd_prio > 0 && n > tune::fwd_prio) __builtin_amdgcn_s_setprio(3);
     TileGeom t;
     if (!tile_geom(p, bin, k & 15, n, threadIdx.x, t)) return;
-    tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids, hint);
+    tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
 }
 
 // Four wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first (k_bin_schedule) and its
@@ -967,7 +950,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
     unsigned long long* __restrict__ counters, unsigned long long pool_cap,
-    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids, unsigned short* __restrict__ hint) {
+    float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     extern __shared__ float4 s_dyn[];
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -984,9 +967,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
     TileGeom t;
     if (!tile_geom(p, bin, sub, n, lane, t)) return;     // (a heavy tile: uniform for the workgroup)
     const unsigned long long* seg = pool + bin_base[bin];
-    if (heavy) tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids, hint);
+    if (heavy) tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
     else tile_single<DIST, RGB, KCAP, HEAVY_BATCH, false>(p, t, lane, s_dyn + wid * (sizeof(FaceRec) * HEAVY_BATCH / sizeof(float4)),
-                                             textures, geo, seg, counters, aggrs, rgba, ids, hint);
+                                             textures, geo, seg, counters, aggrs, rgba, ids);
 }
 
 bool forward_uses_heavy_path(const RasterParams& p) {
@@ -1008,7 +991,7 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
         const int heavy_cap = (int)(hcap < nbins ? hcap : nbins);
         const int per_xcd = 16 * ((heavy_cap + 7) / 8) + 4 * ((nbins + 7) / 8);
         k_softras_forward_mixed<DIST, RGB, KCAP><<<8 * per_xcd, 256, HEAVY_LDS_BYTES, st>>>(
-            p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids, ws.inside_hint);
+            p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
         return;
     }
     const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
@@ -1016,7 +999,7 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
     static const size_t pad = getenv("JR_FWD_LDS_PAD") ? (size_t)atol(getenv("JR_FWD_LDS_PAD")) : 0;
     const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0) + pad;
     k_softras_forward<DIST, RGB, KCAP><<<grid, 64, smem, st>>>(
-        p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids, ws.inside_hint);
+        p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
 }
 
 template <int DIST, int RGB>

@@ -198,8 +198,8 @@ def test_heavy_tile_path_whole_view_forward_and_dense_backward():
     """Round 3: launches of up to 4 Mpixels run the four-wavefront kernel - the tiles of bins with more than 512 listed
     faces (the sphere's limb) are evaluated by four wavefronts on a dense pair list and applied by two.  ONE 39k-face
     view at 1024^2 rendered on its own takes that path (asserted through jr_softras_last_launch): every pixel of the
-    index buffer bit-exact against the oracle, RGBA / aggregates 1e-4, and the dense backward (which also uses the
-    forward's inside hint) within 1e-4 of the largest gradient."""
+    index buffer bit-exact against the oracle, RGBA / aggregates 1e-4, and the dense backward within 1e-4 of the
+    largest gradient."""
     ctx = _ffi.Context.default()
     port = Oracle("port", nthreads=0)
     fv, tex = syn.sphere_views(NF, 1, azimuth0=77.0)
@@ -217,7 +217,6 @@ def test_heavy_tile_path_whole_view_forward_and_dense_backward():
     assert rel_err(saved[4], ref["aggrs_info"], RGBA_ATOL) <= 1.0
     g = np.random.default_rng(23).uniform(-1, 1, (1, 4, IS, IS)).astype(np.float32)
     gf, gt = fn.grad(g)
-    assert ctx.last_launch()["backward_used_inside_hint"]
     gfo, gto = port.backward(ref, g, nthreads=port.num_procs())
     assert grad_err(gf.numpy().reshape(gfo.shape), gfo) <= 1e-4 and grad_err(gt.numpy(), gto) <= 1e-4
     # the same forward through the one-wavefront-per-tile kernel (a batch of 8 is beyond the pixel budget): same bits
@@ -227,20 +226,3 @@ def test_heavy_tile_path_whole_view_forward_and_dense_backward():
     assert not ctx.last_launch()["four_wavefront_kernel"]
     assert bits_equal(fn8.save_vars[5].numpy()[3:4], saved[5])
     assert rel_err(out8.numpy()[3:4], out.numpy(), RGBA_ATOL) <= 1.0
-
-
-def test_backward_is_the_same_with_and_without_the_inside_hint(scene):
-    """The hint only orders the backward's work items.  A backward whose forward token is stale (another forward ran
-    on the context in between) rebuilds the records and runs WITHOUT the hint: same gradients to the 1e-4 bar
-    (float atomics reorder the sums)."""
-    ctx, fv, tex, fn, saved = scene
-    g = ctx.array(np.random.default_rng(29).uniform(-1, 1, (B, 4, IS, IS)).astype(np.float32))
-    fn2 = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
-    fn2(fv, tex)
-    a = fn2.grad(g)
-    assert ctx.last_launch()["backward_used_inside_hint"]
-    other = SoftRasterizeFunction(image_size=64, ctx=ctx)          # any other forward: fn2's token is stale now
-    other(*syn.sphere_views(280, 1))
-    b_ = fn2.grad(g)
-    assert not ctx.last_launch()["backward_used_inside_hint"]
-    assert grad_err(a[0].numpy(), b_[0].numpy()) <= 1e-4 and grad_err(a[1].numpy(), b_[1].numpy()) <= 1e-4

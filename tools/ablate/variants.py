@@ -47,7 +47,6 @@ VARIANTS = {
     "w4b56": ["JR_TUNE_FWD_WAVES16=4", "JR_TUNE_FWD_BATCH=56", "JR_TUNE_FWD_HEAVY=0"],   # single-wavefront forward at 4 wavefronts per SIMD (round 2) / 5 with other batch sizes / 6
     "w5b44": ["JR_TUNE_FWD_WAVES16=5", "JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_HEAVY=0"],
     "w6b36": ["JR_TUNE_FWD_WAVES16=6", "JR_TUNE_FWD_BATCH=36", "JR_TUNE_FWD_HEAVY=0"],
-    "no_hint": ["JR_TUNE_INSIDE_HINT=0"],                    # round 3: backward without the forward's inside hint (work items in slot order)
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
