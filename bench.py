@@ -530,6 +530,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("JRENDER_BENCH_FAIL_RANK") == str(rank):       # tests/test_parallel.py: the launcher must notice a dead rank
+        sys.exit("bench.py: injected failure of rank %d (launcher test)" % rank)
     from jrender_amd import _ffi, comm as jcomm
     ndev = _ffi.device_count()
     if ndev < 1:

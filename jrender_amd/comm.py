@@ -293,10 +293,10 @@ def init_from_env(ctx=None, backend=None):
     context is given), else the host communicator (ranks share GPUs: plumbing only)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1:
-        return SingleCommunicator()
     if backend is None:
         backend = os.environ.get("JRENDER_COMM")
+    if world == 1 and backend != "rccl":        # (JRENDER_COMM=rccl: a one-rank RCCL communicator, to exercise that path on one GPU)
+        return SingleCommunicator()
     if backend is None:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         backend = "rccl" if (ctx is not None and _ffi.device_count() >= local_world) else "host"

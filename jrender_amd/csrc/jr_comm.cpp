@@ -7,7 +7,18 @@
 // librccl.so is dlopen'ed on first use so that single-GPU users never pay for loading it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+
+// The few RCCL / NCCL declarations this file needs, restated from the public API (nccl.h): the library is only
+// dlopen'ed, so building libjrender_hip.so must not require the RCCL development headers either.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;                     /* every other value is an error */
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+}
 
 #include <cstdarg>
 #include <cstdio>
@@ -123,8 +134,16 @@ int jr_comm_create(jr_ctx* ctx, const void* id_host, int nranks, int rank, jr_co
         return cfail("ncclCommInitRank(rank %d of %d, GPU %d) failed: %s", rank, nranks, jr_ctx_device(ctx),
                      g_rccl.GetErrorString(r));
     }
-    JR_HIPC(hipMalloc((void**)&c->scratch, sizeof(double) * 2));
-    JR_HIPC(hipHostMalloc((void**)&c->h_scratch, sizeof(double) * 2, hipHostMallocDefault));
+    // a communicator that cannot get its scratch words is torn down again: the peers must not be left holding a
+    // half-created one, and neither the struct nor the live ncclComm may leak
+    hipError_t he = hipMalloc((void**)&c->scratch, sizeof(double) * 2);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&c->h_scratch, sizeof(double) * 2, hipHostMallocDefault);
+    if (he != hipSuccess) {
+        (void)g_rccl.CommDestroy(c->comm);
+        if (c->scratch) (void)hipFree(c->scratch);
+        delete c;
+        return cfail("jr_comm_create: scratch allocation failed: %s", hipGetErrorString(he));
+    }
     *out = c;
     return 0;
 }
@@ -144,9 +163,10 @@ int jr_comm_rank(const jr_comm* c) { return c ? c->rank : -1; }
 int jr_comm_size(const jr_comm* c) { return c ? c->nranks : 0; }
 
 int jr_comm_all_gather(jr_comm* c, const void* send, void* recv, size_t bytes_per_rank) {
-    if (!c || !send || !recv) return cfail("jr_comm_all_gather: NULL argument");
+    if (!c) return cfail("jr_comm_all_gather: NULL communicator");
+    if (bytes_per_rank == 0) return 0;                    // an empty shard has no buffers to speak of
+    if (!send || !recv) return cfail("jr_comm_all_gather: NULL buffer");
     JR_HIPC(hipSetDevice(jr_ctx_device(c->ctx)));
-    if (bytes_per_rank == 0) return 0;
     hipStream_t st = (hipStream_t)jr_ctx_stream(c->ctx);
     // whole floats where possible (RCCL's copy kernels move wider elements faster than bytes)
     if (bytes_per_rank % 4 == 0)

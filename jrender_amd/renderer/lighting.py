@@ -161,6 +161,9 @@ class Lighting:
 
     def __call__(self, mesh, eyes=None):
         """lighting.py:177-223."""
+        # d(lit)/d(textures) belongs to THIS call or to none: Renderer.grad_textures must not multiply by the mask of
+        # an earlier render (vertex mode and unlit modes leave it at None and grad_textures raises "render first")
+        self._last = None
         if self.light_mode == 'surface':
             diffuse = self.ambient(np.zeros(mesh.faces.shape, F32))
             specular = np.zeros(mesh.faces.shape, F32)
@@ -169,7 +172,6 @@ class Lighting:
                 diffuse, specular = d(diffuse, specular, mesh.surface_normals, centres, eyes,
                                       mesh.with_specular, mesh.metallic_textures, mesh.roughness_textures)
             diffuse, specular = diffuse[:, :, None], specular[:, :, None]
-            self._last = None
             if mesh.textures.ndim == 6:
                 diffuse, specular = diffuse[:, :, None, None], specular[:, :, None, None]
             if mesh.textures.ndim in (4, 6):

@@ -57,6 +57,8 @@ class Renderer:
         self.set_texture_mode(mesh.texture_type)
         if mode != 'silhouettes':           # lighting only rewrites the textures (REN:57): no effect on alpha
             mesh = self.lighting(mesh, self.transform.eyes)
+        else:
+            self.lighting._last = None      # no lighting in this render: grad_textures must not reuse an earlier render's mask
         self._world_vertices, self._faces = np.array(mesh.vertices, np.float32), mesh.faces
         mesh = self.transform(mesh)
         return self.rasterizer(mesh, mode)

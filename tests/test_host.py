@@ -274,3 +274,26 @@ def test_lighting_surface_applies_diffuse_and_specular_and_vertex_rule():
     mv = jr.Mesh(v, f, textures=tv, texture_type='vertex')
     jr.Lighting(light_mode='vertex')(mv, eyes=[0, 0, -2.7])
     assert np.array_equal(mv.textures[0], tv)
+
+
+def test_lighting_derivative_mask_belongs_to_the_last_call():
+    """Lighting keeps d(lit)/d(textures) of the 'surface' branch for Renderer.grad_textures; a later call that
+    does not produce one (vertex mode here) must clear it instead of leaving the mask of an earlier render."""
+    import types
+    from jrender_amd.renderer.lighting import Lighting
+    v, f = jr.synthetic.uv_sphere(14, 11)
+    fv = v[f][None]
+    n = np.cross(fv[:, :, 1] - fv[:, :, 0], fv[:, :, 2] - fv[:, :, 0])
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+
+    def mesh(textures):
+        return types.SimpleNamespace(textures=textures, faces=f[None], face_vertices=fv, surface_normals=n.astype(np.float32),
+                                     vertices=v[None], vertex_normals=(v / np.linalg.norm(v, axis=-1, keepdims=True))[None].astype(np.float32),
+                                     with_specular=False, metallic_textures=None, roughness_textures=None, normal_textures=None, with_SSS=False)
+    tex = np.full((1, f.shape[0], 4, 3), 0.5, np.float32)
+    L = Lighting('surface')
+    L(mesh(tex.copy()), eyes=np.array([[0, 0, -2.7]], np.float32))
+    assert L._last is not None and L._last["dlit"].shape == tex.shape
+    L.light_mode = 'vertex'
+    L(mesh(np.full((1, v.shape[0], 4, 3), 0.5, np.float32)), eyes=np.array([[0, 0, -2.7]], np.float32))
+    assert L._last is None

