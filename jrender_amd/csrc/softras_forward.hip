@@ -179,21 +179,29 @@ __device__ inline void softmax_accumulate(const RasterParams& p, const FaceRec& 
         // ONE v_exp of -|zn - smax| and two selects give the same two values, bit for bit
         const float x = zn - s.smax;
         const bool up = x > 0.f;                       // zn > smax (NaN: false, like the reference's compare)
-        const float e = exp_over_gamma(up ? -x : x, p);
+        const float e = exp_over_gamma(-fabsf(x), p);  // (neg / abs are operand modifiers)
         ed = up ? e : 1.f;
         ez = up ? 1.f : e;
-        s.smax = up ? zn : s.smax;
+        s.smax = fmaxf(s.smax, zn);                    // (a NaN zn leaves smax alone, like the compare)
     } else {
         ed = 1.f;
         if (zn > s.smax) { ed = exp_over_gamma(s.smax - zn, p); s.smax = zn; }
         ez = exp_over_gamma(zn - s.smax, p);
     }
-    s.ssum = ed * s.ssum + ez * D;
     float k0, k1, k2;
     sample_colour<FAST>(p, r, vc, tbase, wc, zp, k0, k1, k2);
-    s.c0 = ed * s.c0 + ez * D * k0;
-    s.c1 = ed * s.c1 + ez * D * k1;
-    s.c2 = ed * s.c2 + ez * D * k2;
+    if (tune::fwd_exp1) {                              // colour path (1e-4): fused multiply-adds
+        const float t = ez * D;
+        s.ssum = __builtin_fmaf(ed, s.ssum, t);
+        s.c0 = __builtin_fmaf(ed, s.c0, t * k0);
+        s.c1 = __builtin_fmaf(ed, s.c1, t * k1);
+        s.c2 = __builtin_fmaf(ed, s.c2, t * k2);
+    } else {
+        s.ssum = ed * s.ssum + ez * D;
+        s.c0 = ed * s.c0 + ez * D * k0;
+        s.c1 = ed * s.c1 + ez * D * k1;
+        s.c2 = ed * s.c2 + ez * D * k2;
+    }
 }
 
 // alpha aggregation (SRK:350-358); neg_num = the sigmoid's numerator -sign*dis (any negative value for 'hard' distance)
@@ -750,13 +758,14 @@ __device__ inline void apply_colour(const RasterParams& p, const float4 cell, co
                                                             : div_known<false>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
         const float x = zn - s.smax;
         const bool up = x > 0.f;
-        const float e = exp_over_gamma(up ? -x : x, p);
+        const float e = exp_over_gamma(-fabsf(x), p);
         const float ed = up ? e : 1.f, ez = up ? 1.f : e;
-        s.smax = up ? zn : s.smax;
-        s.ssum = ed * s.ssum + ez * D;
-        s.c0 = ed * s.c0 + ez * D * k0;
-        s.c1 = ed * s.c1 + ez * D * k1;
-        s.c2 = ed * s.c2 + ez * D * k2;
+        s.smax = fmaxf(s.smax, zn);
+        const float t = ez * D;
+        s.ssum = __builtin_fmaf(ed, s.ssum, t);
+        s.c0 = __builtin_fmaf(ed, s.c0, t * k0);
+        s.c1 = __builtin_fmaf(ed, s.c1, t * k1);
+        s.c2 = __builtin_fmaf(ed, s.c2, t * k2);
     }
 }
 

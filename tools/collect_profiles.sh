@@ -3,7 +3,7 @@
 # trace : rocprofv3 --kernel-trace --stats of the default bench command (no PMC in that pass)
 # bench : the plain default bench line (what the driver runs)
 # fetch / write / sq : separate --pmc passes (FETCH_SIZE | WRITE_SIZE | the SQ instruction / lane counters)
-# JRENDER_LIB=<other build of libjrender_hip.so> profiles that build instead of the product.
+# JRENDER_LIB=<other build of libjrender_hip.so> profiles that build instead of the product; BENCH_ARGS="--batch 1" another workload.
 tag=$1; shift
 passes=${*:-trace bench fetch write sq}
 out=gpurun_out/profiles_$tag
@@ -11,7 +11,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for p in $passes; do
   case $p in
-    trace) rocprofv3 --kernel-trace --stats -d $out/trace -o $tag --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $out/bench_traced.log 2>&1
+    trace) rocprofv3 --kernel-trace --stats -d $out/trace -o $tag --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary $BENCH_ARGS > $out/bench_traced.log 2>&1
            cp $out/trace/*kernel_stats.csv $out/${tag}_kernel_stats.csv ;;
     bench) python bench.py > $out/${tag}_bench.json 2> $out/bench.err ;;
     fetch) tools/pmc_run.sh $out/fetch FETCH_SIZE ;;
