@@ -48,8 +48,12 @@
 #ifndef JR_TUNE_FWD_PRIO         // forward: s_setprio(3) for the wavefronts of bins with more than this many listed faces (0 = off)
 #define JR_TUNE_FWD_PRIO 0
 #endif
-#ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert
+#ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert;
+                                 // backward: bit 2 no three-projection path, bit 3 no n-th-holder search, bit 4 no row reduction, bit 5 no atomics
 #define JR_TUNE_DIAG 0
+#endif
+#ifndef JR_TUNE_BWD_ROW_RANGES   // backward: a row takes a contiguous quarter of the work items and adds up consecutive items of one face before its atomic
+#define JR_TUNE_BWD_ROW_RANGES 1
 #endif
 #ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
 #define JR_TUNE_BWD_TV_RCP 0
@@ -86,5 +90,6 @@ constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_prio = JR_TUNE_FWD_PRIO;
 constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
+constexpr bool bwd_row_ranges = JR_TUNE_BWD_ROW_RANGES != 0;
 }  // namespace tune
 }  // namespace jr

@@ -314,7 +314,7 @@ __device__ inline bool strictly_inside_t(const Bary& b) {
 // tools/ablate/patches/, profiles/r02_ab_inside_select.log.)
 template <bool FAST, int TV = TV_IEEE>
 __device__ inline Dist euclidean_p2f(const FaceGeo& r, int meta, const Bary& b, float xp, float yp) {
-    const bool inside = strictly_inside_t<FAST>(b);
+    const bool inside = (JR_TUNE_DIAG & 4) ? false : strictly_inside_t<FAST>(b);    // (diagnostic bit 2: what do the inside pairs' extra projections cost?)
     const int v0 = outside_edge(r, face_obtuse(meta), b, xp, yp);
     Dist d;
     const EdgeCand c = edge_candidate<FAST, TV>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);

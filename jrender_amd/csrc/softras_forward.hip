@@ -110,7 +110,7 @@ struct KBuffer {
         const bool filling = size < K;
         if (!filling && !(zp < max_z)) return -1;
         const int slot = filling ? size : max_slot;
-        if (IDS_GLOBAL) gplane[(unsigned)slot * gstride + goff] = fn;
+        if (IDS_GLOBAL && !(JR_TUNE_DIAG & 64)) gplane[(unsigned)slot * gstride + goff] = fn;     // (diagnostic bit 6: what do the per-insert id stores cost?)
         if (SHIFT) {
             if (filling) {
 #pragma unroll

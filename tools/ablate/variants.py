@@ -47,6 +47,9 @@ VARIANTS = {
     "w4b56": ["JR_TUNE_FWD_WAVES16=4", "JR_TUNE_FWD_BATCH=56", "JR_TUNE_FWD_HEAVY=0"],   # single-wavefront forward at 4 wavefronts per SIMD (round 2) / 5 with other batch sizes / 6
     "w5b44": ["JR_TUNE_FWD_WAVES16=5", "JR_TUNE_FWD_BATCH=44", "JR_TUNE_FWD_HEAVY=0"],
     "w6b36": ["JR_TUNE_FWD_WAVES16=6", "JR_TUNE_FWD_BATCH=36", "JR_TUNE_FWD_HEAVY=0"],
+    "bdiag_noinside": ["JR_TUNE_DIAG=4"], "bdiag_nosearch": ["JR_TUNE_DIAG=8"], "bdiag_noreduce": ["JR_TUNE_DIAG=16"], "bdiag_noatomics": ["JR_TUNE_DIAG=32"],   # WRONG results: cost probes of the backward
+    "no_ranges": ["JR_TUNE_BWD_ROW_RANGES=0"],              # round 3: backward rows take every fourth item, one atomic per item
+    "diag_nostore": ["JR_TUNE_DIAG=64", "JR_TUNE_FWD_HEAVY=0"],   # WRONG results: forward without the per-insert id stores
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
