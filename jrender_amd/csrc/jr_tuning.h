@@ -42,6 +42,9 @@
 #ifndef JR_TUNE_FWD_HEAVY        // forward: bins whose list is longer than this get FOUR wavefronts per tile (evaluate / apply split); 0 = one wavefront per tile everywhere
 #define JR_TUNE_FWD_HEAVY 512
 #endif
+#ifndef JR_TUNE_FWD_HEAVY_DEFER_COPY // forward, heavy tiles: the record copies of a batch in one round after the list walk
+#define JR_TUNE_FWD_HEAVY_DEFER_COPY 1
+#endif
 #ifndef JR_TUNE_FWD_HEAVY_PIXELS // forward: launches of up to this many pixels (B x IS x IS) use the four-wavefront kernel, larger ones one wavefront per tile
 #define JR_TUNE_FWD_HEAVY_PIXELS 4194304
 #endif
@@ -89,6 +92,7 @@ constexpr bool fwd_defer_inside = JR_TUNE_FWD_DEFER_INSIDE != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_prio = JR_TUNE_FWD_PRIO;
 constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY;
+constexpr bool fwd_heavy_defer_copy = JR_TUNE_FWD_HEAVY_DEFER_COPY != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 constexpr bool bwd_row_ranges = JR_TUNE_BWD_ROW_RANGES != 0;
 }  // namespace tune

@@ -215,7 +215,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
 }
 
 template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? JR_TUNE_BWD_WAVES : 1))) void k_softras_backward(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? JR_TUNE_BWD_WAVES : (KCAP <= 32 ? 4 : 3)))) void k_softras_backward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,

@@ -474,6 +474,46 @@ struct ListWalker {
         }
         return fill;
     }
+    // The same with the record copies DEFERRED to one round per batch (heavy tiles): the walk only notes which face
+    // goes to which slot (LDS), then lane = slot copies its record - one exposed global-load latency per batch
+    // instead of one per list chunk with survivors.  (Measured +-0 on the single-wavefront kernel at full load, where
+    // other wavefronts hide the latency; a heavy tile's wavefront 0 walks 23 chunks for 9 batches on its own: -5 %.)
+    template <int BATCH>
+    __device__ inline int stage_deferred(const RasterParams& p, FaceRec* s_rec, int* s_slot, int lane) {
+        int fill = 0;
+        while (pending || s0 < n) {
+            if (!pending) {
+                const unsigned long long e = e_next;
+                s0 += CHUNK;
+                e_next = s0 + lane < n ? seg[s0 + lane] : 0ull;
+                keep = (e >> sub) & 1ull;
+                const unsigned long long surv = ballot(keep);
+                if (!surv) continue;
+                gp = gbase + (int)(e >> 32);
+                cnt = __builtin_popcountll(surv);
+                rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(surv >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((unsigned)surv, 0u));
+            }
+            const int take = min(cnt, BATCH - fill);
+            if (keep && rank < take) s_slot[fill + rank] = (int)(gp - gbase);
+            fill += take;
+            pending = take < cnt;
+            if (pending) {
+                keep = keep && rank >= take;
+                rank -= take;
+                cnt -= take;
+                break;
+            }
+        }
+        wave_sync<false>();
+        if (lane < fill) {
+            const float4* src = reinterpret_cast<const float4*>(gbase + s_slot[lane]);
+            float4* dst = reinterpret_cast<float4*>(&s_rec[lane]);
+#pragma unroll
+            for (int k = 0; k < 11; k++) dst[k] = src[k];
+        }
+        return fill;
+    }
 };
 
 // ---- ballots + pre-cull: lane = slot -> per-pixel masks of the batch's faces ---------------------------------
@@ -797,7 +837,8 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     }
     for (;;) {
         if (wid == 0) {
-            const int f = lw.stage<BATCH>(p, s_rec, nullptr, lane);
+            const int f = tune::fwd_heavy_defer_copy ? lw.stage_deferred<BATCH>(p, s_rec, reinterpret_cast<int*>(s_M), lane)   // (s_M is free until the masks)
+                                                     : lw.stage<BATCH>(p, s_rec, nullptr, lane);
             if (lane == 0) s_misc[0] = f;
         }
         __syncthreads();                                                       // A: records staged

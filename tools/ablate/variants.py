@@ -50,6 +50,7 @@ VARIANTS = {
     "bdiag_noinside": ["JR_TUNE_DIAG=4"], "bdiag_nosearch": ["JR_TUNE_DIAG=8"], "bdiag_noreduce": ["JR_TUNE_DIAG=16"], "bdiag_noatomics": ["JR_TUNE_DIAG=32"],   # WRONG results: cost probes of the backward
     "no_ranges": ["JR_TUNE_BWD_ROW_RANGES=0"],              # round 3: backward rows take every fourth item, one atomic per item
     "diag_nostore": ["JR_TUNE_DIAG=64", "JR_TUNE_FWD_HEAVY=0"],   # WRONG results: forward without the per-insert id stores
+    "no_defer_copy": ["JR_TUNE_FWD_HEAVY_DEFER_COPY=0"],     # round 3: heavy tiles copy their records chunk by chunk while walking the list
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }

@@ -16,10 +16,11 @@ for p in $passes; do
     bench) python bench.py > $out/${tag}_bench.json 2> $out/bench.err ;;
     fetch) tools/pmc_run.sh $out/fetch FETCH_SIZE ;;
     write) tools/pmc_run.sh $out/write WRITE_SIZE ;;
-    sq)    tools/pmc_run.sh $out/sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU ;;
+    sq)    tools/pmc_run.sh $out/sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
+           tools/pmc_run.sh $out/sq2 SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_FLAT ;;
   esac
 done
-for d in fetch write sq; do
+for d in fetch write sq sq2; do
   f=$(find $out/$d -name '*counter_collection.csv' 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py "$f" > $out/${tag}_pmc_$d.txt
 done
