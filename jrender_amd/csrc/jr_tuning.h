@@ -29,6 +29,15 @@
 #ifndef JR_TUNE_FWD_WAVES16      // forward, one wavefront per tile, K <= 16: wavefronts per SIMD asked of the register allocator (5 -> 96 VGPRs, no scratch)
 #define JR_TUNE_FWD_WAVES16 5
 #endif
+#ifndef JR_TUNE_FWD_WAVES32      // the same for 16 < K <= 32 (3 -> up to 168 VGPRs; the allocator uses 131)
+#define JR_TUNE_FWD_WAVES32 3
+#endif
+#ifndef JR_TUNE_FWD_WAVES64      // and for 32 < K <= 64 (2 -> up to 256 VGPRs; 187 used)
+#define JR_TUNE_FWD_WAVES64 2
+#endif
+#ifndef JR_TUNE_FWD_EMPTY_BINS   // forward: one wavefront writes the outputs of all 16 tiles of an empty bin with 16-byte stores
+#define JR_TUNE_FWD_EMPTY_BINS 1
+#endif
 #ifndef JR_TUNE_FWD_FILL_SHIFT   // forward: K-buffer appends shift the depth registers (KCAP v_mov) instead of writing a per-lane slot (KCAP v_cmp + v_cndmask)
 #define JR_TUNE_FWD_FILL_SHIFT 1
 #endif
@@ -85,9 +94,12 @@ constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
 constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
 constexpr int fwd_batch_mixed = JR_TUNE_FWD_BATCH_MIXED;
 constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
+constexpr int fwd_waves32 = JR_TUNE_FWD_WAVES32;
+constexpr int fwd_waves64 = JR_TUNE_FWD_WAVES64;
 constexpr long fwd_heavy_pixels = JR_TUNE_FWD_HEAVY_PIXELS;
 constexpr bool fwd_ids_global = JR_TUNE_FWD_IDS_GLOBAL != 0;
 constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
+constexpr bool fwd_empty_bins = JR_TUNE_FWD_EMPTY_BINS != 0;
 constexpr bool fwd_defer_inside = JR_TUNE_FWD_DEFER_INSIDE != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_prio = JR_TUNE_FWD_PRIO;

@@ -308,7 +308,7 @@ __device__ inline void forward_pair_inside(const RasterParams& p, const FaceRec&
 // wavefronts per SIMD asked of the register allocator: K <= 16: the single-wavefront kernel fits 96 VGPRs (5), the
 // four-wavefront one 128 (4); K <= 32: 168 (3); K <= 64: 256 (2) - all without scratch
 constexpr int fwd_waves(int kcap, bool mixed) {
-    return kcap <= 16 ? (mixed ? 4 : tune::fwd_waves16) : (kcap <= 32 ? 3 : 2);
+    return kcap <= 16 ? (mixed ? 4 : tune::fwd_waves16) : (kcap <= 32 ? tune::fwd_waves32 : tune::fwd_waves64);
 }
 
 // LDS hand-over inside ONE wavefront (writes by some lanes, reads by others): LDS instructions of a wavefront
@@ -368,27 +368,62 @@ __device__ inline void init_pixel_state(const RasterParams& p, const TileGeom& t
 
 // ---- finalise (SRK:426-455): colour planes / K-buffer planes (two wavefronts hold the two halves of a heavy tile's state) ----
 template <int RGB, int KCAP>
+__device__ inline void final_colour(const RasterParams& p, const PixelState<KCAP>& s, float (&o)[6]) {    // r g b a, aggrs_info[2]
+    if (p.alpha == 0) o[3] = s.alpha;
+    else if (p.alpha == 1) o[3] = s.alpha / p.NF;
+    else o[3] = (float)(1. - (double)s.alpha);
+    o[0] = p.bg[0]; o[1] = p.bg[1]; o[2] = p.bg[2]; o[4] = 0.f; o[5] = 0.f;
+    if (RGB == 0) {
+        if (s.face_min != -1) { o[0] = s.c0; o[1] = s.c1; o[2] = s.c2; }
+        o[4] = s.depth_min; o[5] = (float)s.face_min;
+    } else if (RGB == 1) {
+        o[0] = s.c0 / s.ssum; o[1] = s.c1 / s.ssum; o[2] = s.c2 / s.ssum;
+        o[4] = s.ssum; o[5] = s.smax;
+    }
+}
+template <int RGB, int KCAP>
 __device__ inline void store_colour(const RasterParams& p, const TileGeom& t, const PixelState<KCAP>& s,
                                     float* __restrict__ aggrs, float* __restrict__ rgba) {
     if (!t.valid) return;
     const size_t pp = (size_t)p.IS * p.IS;
     const size_t pn = (size_t)t.row * p.IS + t.col;
-    float a_out;
-    if (p.alpha == 0) a_out = s.alpha;
-    else if (p.alpha == 1) a_out = s.alpha / p.NF;
-    else a_out = (float)(1. - (double)s.alpha);
-    float o0 = p.bg[0], o1 = p.bg[1], o2 = p.bg[2], g0 = 0.f, g1 = 0.f;
-    if (RGB == 0) {
-        if (s.face_min != -1) { o0 = s.c0; o1 = s.c1; o2 = s.c2; }
-        g0 = s.depth_min; g1 = (float)s.face_min;
-    } else if (RGB == 1) {
-        o0 = s.c0 / s.ssum; o1 = s.c1 / s.ssum; o2 = s.c2 / s.ssum;
-        g0 = s.ssum; g1 = s.smax;
-    }
+    float o[6];
+    final_colour<RGB>(p, s, o);
     float* out = rgba + (size_t)t.b * 4 * pp + pn;
-    out[0] = o0; out[pp] = o1; out[2 * pp] = o2; out[3 * pp] = a_out;
+    out[0] = o[0]; out[pp] = o[1]; out[2 * pp] = o[2]; out[3 * pp] = o[3];
     float* ag = aggrs + (size_t)t.b * 2 * pp + pn;
-    ag[0] = g0; ag[pp] = g1;
+    ag[0] = o[4]; ag[pp] = o[5];
+}
+// An EMPTY bin (no face reaches its 32x32 pixels; more than half of the bins of the headline batch): ONE wavefront writes
+// the initial state's outputs for all 16 tiles with 16-byte stores of full 128-byte rows - the same values the tiles'
+// own wavefronts would have stored (final_colour of the untouched state), 88 wide stores instead of 16 x 22 narrow ones.
+// Only when image rows are 16-byte aligned and bins are whole (IS % 32 == 0); other sizes take the per-tile path.
+template <int RGB, int KCAP>
+__device__ inline void store_empty_bin(const RasterParams& p, int bin, int lane,
+                                       float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    const int bins_per_img = p.bins_x * p.bins_y;
+    const int b = bin / bins_per_img, bb = bin - b * bins_per_img;
+    const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
+    PixelState<KCAP> s;
+    init_colour_state<RGB>(p, s);
+    float o[6];
+    final_colour<RGB>(p, s, o);
+    const size_t pp = (size_t)p.IS * p.IS;
+    const size_t base = ((size_t)(by * BIN + (lane >> 3))) * p.IS + bx * BIN + (lane & 7) * 4;    // 8 lanes x 16 B = one 128-byte row
+    const size_t rstep = (size_t)8 * p.IS;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        float* pl = (c < 4 ? rgba + ((size_t)b * 4 + c) * pp : aggrs + ((size_t)b * 2 + (c - 4)) * pp) + base;
+        const float4 v = make_float4(o[c], o[c], o[c], o[c]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<float4*>(pl + i * rstep) = v;
+    }
+    const int4 m1 = make_int4(-1, -1, -1, -1);
+    for (int k = 0; k < p.K; k++) {
+        int32_t* pl = ids + ((size_t)b * p.K + k) * pp + base;
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<int4*>(pl + i * rstep) = m1;
+    }
 }
 template <int KCAP, bool WRITTEN_THROUGH, class KB>
 __device__ inline void store_ids(const RasterParams& p, const TileGeom& t, const KB& q, int32_t* __restrict__ ids) {
@@ -985,6 +1020,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     const int n = bin_count[bin];
     // tune::fwd_prio: issue priority for the wavefronts of the heaviest bins (measured: no effect)
     if (tune::fwd_prio > 0 && n > tune::fwd_prio) __builtin_amdgcn_s_setprio(3);
+    if (tune::fwd_empty_bins && n == 0 && (p.IS & (BIN - 1)) == 0) {    // empty bin: tile 0's wavefront writes all 16 tiles
+        if ((k & 15) == 0) store_empty_bin<RGB, KCAP>(p, bin, threadIdx.x, aggrs, rgba, ids);
+        return;
+    }
     TileGeom t;
     if (!tile_geom(p, bin, k & 15, n, threadIdx.x, t)) return;
     tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
@@ -1014,6 +1053,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
     if (brank >= nbins) return;
     const int bin = bin_order[brank];
     const int n = bin_count[bin];
+    if (tune::fwd_empty_bins && n == 0 && (p.IS & (BIN - 1)) == 0) {    // empty bin (never heavy): the first of its four workgroups' wavefront 0
+        if (sub == 0) store_empty_bin<RGB, KCAP>(p, bin, lane, aggrs, rgba, ids);
+        return;
+    }
     TileGeom t;
     if (!tile_geom(p, bin, sub, n, lane, t)) return;     // (a heavy tile: uniform for the workgroup)
     const unsigned long long* seg = pool + bin_base[bin];

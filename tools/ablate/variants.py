@@ -51,6 +51,7 @@ VARIANTS = {
     "no_ranges": ["JR_TUNE_BWD_ROW_RANGES=0"],              # round 3: backward rows take every fourth item, one atomic per item
     "diag_nostore": ["JR_TUNE_DIAG=64", "JR_TUNE_FWD_HEAVY=0"],   # WRONG results: forward without the per-insert id stores
     "no_defer_copy": ["JR_TUNE_FWD_HEAVY_DEFER_COPY=0"],     # round 3: heavy tiles copy their records chunk by chunk while walking the list
+    "no_empty_bins": ["JR_TUNE_FWD_EMPTY_BINS=0"],           # round 3: the 16 tiles of an empty bin store their own outputs
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/kernel_resources.sh jrender_amd/csrc/file.hip  -> per-kernel VGPR / SGPR / scratch / occupancy / LDS
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -x hip -c "$1" -o /dev/null --cuda-device-only -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -x hip $KR_FLAGS -c "$1" -o /dev/null --cuda-device-only -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re
 cur={}
 for l in sys.stdin:
