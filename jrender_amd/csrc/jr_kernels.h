@@ -39,6 +39,7 @@ void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* 
                             const BinWorkspace& ws, float* aggrs_info, float* soft_colors,
                             int32_t* faces_id_buffer);
 bool forward_uses_heavy_path(const RasterParams& p);   // launches of up to tune::fwd_heavy_pixels pixels: four wavefronts per tile of a heavy bin
+bool backward_splits_heavy_tiles(const RasterParams& p);   // launches of up to tune::bwd_split_pixels pixels: tune::bwd_split wavefronts per tile of a heavy bin, each with the face ids of one residue class
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,
                              const float* soft_colors, const float* aggrs_info,
                              const int32_t* faces_id_buffer, const float* grad_soft_colors,

@@ -30,10 +30,10 @@
 #define JR_TUNE_FWD_WAVES16 5
 #endif
 #ifndef JR_TUNE_FWD_WAVES32      // the same for 16 < K <= 32 (3 -> up to 168 VGPRs; the allocator uses 131)
-#define JR_TUNE_FWD_WAVES32 3
+#define JR_TUNE_FWD_WAVES32 4
 #endif
 #ifndef JR_TUNE_FWD_WAVES64      // and for 32 < K <= 64 (2 -> up to 256 VGPRs; 187 used)
-#define JR_TUNE_FWD_WAVES64 2
+#define JR_TUNE_FWD_WAVES64 3
 #endif
 #ifndef JR_TUNE_FWD_EMPTY_BINS   // forward: one wavefront writes the outputs of all 16 tiles of an empty bin with 16-byte stores
 #define JR_TUNE_FWD_EMPTY_BINS 1
@@ -53,6 +53,9 @@
 #endif
 #ifndef JR_TUNE_FWD_HEAVY_DEFER_COPY // forward, heavy tiles: the record copies of a batch in one round after the list walk
 #define JR_TUNE_FWD_HEAVY_DEFER_COPY 1
+#endif
+#ifndef JR_TUNE_FWD_HEAVY_OVERLAP // heavy tiles: wavefront 3 stages the next batch and wavefront 2 writes the next round's pair list WHILE wavefronts 0 / 1 apply (0: wavefront 0 does both between the passes)
+#define JR_TUNE_FWD_HEAVY_OVERLAP 1
 #endif
 #ifndef JR_TUNE_FWD_HEAVY_PIXELS // forward: launches of up to this many pixels (B x IS x IS) use the four-wavefront kernel, larger ones one wavefront per tile
 #define JR_TUNE_FWD_HEAVY_PIXELS 4194304
@@ -74,6 +77,15 @@
 #ifndef JR_TUNE_BWD_BATCH         // backward: faces per batch (LDS record slots per wavefront), <= 64; 40 slots + tables = 7.6 KB -> 20 wavefronts per CU
 #define JR_TUNE_BWD_BATCH 40
 #endif
+#ifndef JR_TUNE_BWD_WAVES64       // backward at 32 < K <= 64: wavefronts per SIMD (3 -> 158 VGPRs; 4 -> 128 with 52 B of scratch)
+#define JR_TUNE_BWD_WAVES64 3
+#endif
+#ifndef JR_TUNE_BWD_SPLIT         // backward: wavefronts per tile of a HEAVY bin in launches of up to BWD_SPLIT_PIXELS pixels (each keeps the ids with id % SPLIT == its part); 0 / 1 = off
+#define JR_TUNE_BWD_SPLIT 4
+#endif
+#ifndef JR_TUNE_BWD_SPLIT_PIXELS
+#define JR_TUNE_BWD_SPLIT_PIXELS 1572864
+#endif
 #ifndef JR_TUNE_BWD_WAVES         // backward: wavefronts per SIMD asked of the register allocator at K <= 16 (5 -> 96 VGPRs, still 32 B of scratch;
                                   // 6 and 7 spill 64-112 B and are 1.5-2.2x slower: profiles/r02_ablation_sweep.log)
 #define JR_TUNE_BWD_WAVES 5
@@ -94,6 +106,9 @@ constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
 constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
 constexpr int fwd_batch_mixed = JR_TUNE_FWD_BATCH_MIXED;
 constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
+constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;
+constexpr int bwd_split = JR_TUNE_BWD_SPLIT;
+constexpr long bwd_split_pixels = JR_TUNE_BWD_SPLIT_PIXELS;
 constexpr int fwd_waves32 = JR_TUNE_FWD_WAVES32;
 constexpr int fwd_waves64 = JR_TUNE_FWD_WAVES64;
 constexpr long fwd_heavy_pixels = JR_TUNE_FWD_HEAVY_PIXELS;

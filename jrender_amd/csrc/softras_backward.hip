@@ -215,8 +215,8 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
 }
 
 template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? JR_TUNE_BWD_WAVES : (KCAP <= 32 ? 4 : 3)))) void k_softras_backward(
-    RasterParams p, int ntiles_total, const float* __restrict__ textures,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? JR_TUNE_BWD_WAVES : (KCAP <= 32 ? 4 : JR_TUNE_BWD_WAVES64)))) void k_softras_backward(
+    RasterParams p, int nbins, int heavy_cap, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
     const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
@@ -229,10 +229,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     __shared__ unsigned long long s_has[BATCH];     // slot -> pixels (lanes) that hold the face
     __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
 
-    const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
-    const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
-    if (brank * 16 >= ntiles_total) return;
-    const int bin = bin_order[brank], sub = k & 15;      // ... heaviest first (k_bin_schedule)
+    // XCD-aware order as in the forward.  tune::bwd_split (small launches only, heavy_cap > 0): the tiles of the HEAVY
+    // bins (the first counters[3] ranks of the order, the forward's definition) are taken by SPLIT wavefronts each -
+    // wavefront `part` keeps the buffered ids with id % SPLIT == part and is otherwise a complete tile job.  The
+    // gradient is a sum over (pixel, face) pairs, so the parts do not talk to each other; what they share is the
+    // critical path of a launch that cannot fill the GPU (one view: the limb tiles' extraction + pair loop).
+    constexpr int SPLIT = tune::bwd_split > 0 ? tune::bwd_split : 1;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;      // k-th workgroup of its XCD
+    const int nheavy = heavy_cap > 0 ? min((int)counters[3], heavy_cap) : 0;
+    const int hx = (nheavy - xcd + 7) >> 3;                   // heavy bins dealt to this XCD (launch ranks xcd, xcd + 8, ...)
+    int brank, sub, part = -1;
+    if (k < hx * 16 * SPLIT) { brank = (k / (16 * SPLIT)) * 8 + xcd; sub = (k / SPLIT) & 15; part = k % SPLIT; }
+    else { const int k2 = k - hx * 16 * SPLIT; brank = (hx + (k2 >> 4)) * 8 + xcd; sub = k2 & 15; }   // bins are dealt round-robin to the XCDs ...
+    if (brank >= nbins) return;
+    const int bin = bin_order[brank];                         // ... heaviest first (k_bin_schedule)
     const int n = bin_count[bin];
     if (n == 0) return;
     const int bins_per_img = p.bins_x * p.bins_y;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             live = live && raw[k] >= 0 && raw[k] < p.NF;   // -1 ends the list (ids outside [0, NF) too)
-            mine[k] = live ? raw[k] : BIG;
+            mine[k] = (live && (part < 0 || (int)((unsigned)raw[k] % (unsigned)SPLIT) == part)) ? raw[k] : BIG;
         }
     }
     sort_ascending(mine);
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         // kernel's time (cost probe: no atomics -27 %), and the L2 sees ~2x fewer of them.
         constexpr bool RANGES = tune::bwd_row_ranges;
         const int per_row = RANGES ? (nitems + 3) >> 2 : 0;
-        const int item0 = RANGES ? blk * per_row : blk, item_step = RANGES ? 1 : 4;
+        const int item0 = RANGES ? blk * per_row : blk;
         const int item_end = RANGES ? min(item0 + per_row, nitems) : nitems;
         int j = 0, nth = 64;
         unsigned long long hs = 0ull;
@@ -485,20 +495,27 @@ template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, const float* rgba, const float* aggrs, const int32_t* ids,
                      const float* grad_rgba, float* grad_faces, float* grad_textures) {
-    const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
+    const int nbins = ntiles / (SUBS * SUBS);
+    // heavy bins' tiles by tune::bwd_split wavefronts each when the launch is too small to fill the GPU anyway
+    int heavy_cap = 0;
+    if (backward_splits_heavy_tiles(p)) {
+        const long hcap = (long)(ws.pool_cap / (unsigned long long)fwd_heavy_floor()) + 8;   // (bound of counters[3], as in the forward)
+        heavy_cap = (int)(hcap < nbins ? hcap : nbins);
+    }
+    const int grid = 8 * 16 * (tune::bwd_split * ((heavy_cap + 7) / 8) + (nbins + 7) / 8);   // whole bins (16 tiles) per XCD slot
     const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0);
-    if (p.K <= 16)
-        k_softras_backward<DIST, RGB, 16><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
-            grad_faces, grad_textures, ws.counters);
-    else if (p.K <= 32)
-        k_softras_backward<DIST, RGB, 32><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
-            grad_faces, grad_textures, ws.counters);
-    else
-        k_softras_backward<DIST, RGB, 64><<<grid, 64, smem, st>>>(
-            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba,
-            grad_faces, grad_textures, ws.counters);
+#define JR_BWD_K(KC) \
+    k_softras_backward<DIST, RGB, KC><<<grid, 64, smem, st>>>( \
+        p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba, \
+        grad_faces, grad_textures, ws.counters)
+    if (p.K <= 16) JR_BWD_K(16);
+    else if (p.K <= 32) JR_BWD_K(32);
+    else JR_BWD_K(64);
+#undef JR_BWD_K
+}
+
+bool backward_splits_heavy_tiles(const RasterParams& p) {
+    return tune::bwd_split > 1 && tune::fwd_heavy > 0 && (long)p.B * p.IS * p.IS <= (long)tune::bwd_split_pixels;
 }
 
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,

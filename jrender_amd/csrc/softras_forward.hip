@@ -308,7 +308,8 @@ __device__ inline void forward_pair_inside(const RasterParams& p, const FaceRec&
 // wavefronts per SIMD asked of the register allocator: K <= 16: the single-wavefront kernel fits 96 VGPRs (5), the
 // four-wavefront one 128 (4); K <= 32: 168 (3); K <= 64: 256 (2) - all without scratch
 constexpr int fwd_waves(int kcap, bool mixed) {
-    return kcap <= 16 ? (mixed ? 4 : tune::fwd_waves16) : (kcap <= 32 ? tune::fwd_waves32 : tune::fwd_waves64);
+    return kcap <= 16 ? (mixed ? 4 : tune::fwd_waves16)
+                      : (kcap <= 32 ? (mixed ? 3 : tune::fwd_waves32) : (mixed ? 2 : tune::fwd_waves64));   // (the four-wavefront kernel spills at one more)
 }
 
 // LDS hand-over inside ONE wavefront (writes by some lanes, reads by others): LDS instructions of a wavefront
@@ -735,7 +736,7 @@ constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHA
 constexpr int CELL_TEXEL_SHIFT = 12;
 constexpr int HEAVY_BATCH = tune::fwd_batch_mixed;                                              // record slots of a heavy tile = of each of the four tiles of a lighter workgroup
 constexpr int HEAVY_LDS_BYTES = 4 * (int)sizeof(FaceRec) * HEAVY_BATCH;                         // = what four single-wavefront tiles use
-constexpr int HEAVY_FIXED_BYTES = (int)sizeof(FaceRec) * HEAVY_BATCH + 64 * 8 + 64 * 8 + 64 + 2 * 64 * 8;   // records, pixel centres, masks, scalars, per-pixel (first cell, cells) of two rounds
+constexpr int HEAVY_FIXED_BYTES = (int)sizeof(FaceRec) * HEAVY_BATCH + 64 * 8 + 64 * 8 + 64 + 2 * 64 * 8 + 2 * HEAVY_BATCH * 12;   // records, pixel centres, masks, scalars, per-pixel (first cell, cells) of two rounds, colours of two batches
 constexpr int HEAVY_CAP = ((HEAVY_LDS_BYTES - HEAVY_FIXED_BYTES) / 20) & ~63;                   // 16 B cell + 2 B pair + 2 B inside entry per pair
 static_assert(HEAVY_CAP >= 256 && HEAVY_CAP <= 4096, "cell buffer of the heavy-tile path");
 
@@ -806,7 +807,7 @@ __device__ inline void apply_kbuf(const RasterParams& p, const float4 cell, KB& 
 
 // the colour half (lane = pixel, wavefront 1): alpha (SRK:350-358), hard rgb (SRK:390-397) or online softmax (SRK:399-419)
 template <int RGB, int KCAP>
-__device__ inline void apply_colour(const RasterParams& p, const float4 cell, const FaceRec* s_rec,
+__device__ inline void apply_colour(const RasterParams& p, const float4 cell, const float* s_col,
                                     const float* __restrict__ tbase, PixelState<KCAP>& s) {
     const unsigned aux = __builtin_bit_cast(unsigned, cell.w);
     if (!(aux & CELL_LIVE)) return;
@@ -821,7 +822,7 @@ __device__ inline void apply_colour(const RasterParams& p, const float4 cell, co
     else if (!facing) return;
     const int fn = face_id(meta);
     float k0, k1, k2;
-    if (p.T == 1) { const float* col = s_rec[aux & CELL_SLOT].col; k0 = col[0]; k1 = col[1]; k2 = col[2]; }
+    if (p.T == 1) { const float* col = s_col + (aux & CELL_SLOT) * 3; k0 = col[0]; k1 = col[1]; k2 = col[2]; }
     else {
         const float* tx_ = tbase + ((size_t)fn * p.T + (aux >> CELL_TEXEL_SHIFT)) * 3;
         k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
@@ -850,33 +851,80 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
                                   const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
                                   float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     constexpr int BATCH = HEAVY_BATCH, CAP = HEAVY_CAP;
+    // tune::fwd_heavy_overlap: the apply pass keeps two wavefronts busy for half of the tile's time while the other two
+    // wait.  Wavefront 3 therefore owns the list walk and stages the NEXT batch's records during the apply of a batch's
+    // LAST round (the records are not read after the inside pass: the colours apply needs were copied to s_col), and
+    // wavefront 2 owns the pixels' face masks and writes the NEXT round's pair list during the apply of the current one.
+    constexpr bool OVERLAP = tune::fwd_heavy_overlap;
+    constexpr int STAGER = OVERLAP ? 3 : 0, LISTER = OVERLAP ? 2 : 0;
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                                        // [BATCH]
     float4* s_cell = reinterpret_cast<float4*>(s_rec + BATCH);                                 // [CAP]
     float2* s_pix = reinterpret_cast<float2*>(s_cell + CAP);                                   // [64] pixel centres
     unsigned long long* s_M = reinterpret_cast<unsigned long long*>(s_pix + 64);               // [64] face masks of the batch
     int* s_misc = reinterpret_cast<int*>(s_M + 64);                                            // [16] fill, total, j1, inside count
     int2* s_span = reinterpret_cast<int2*>(s_misc + 16);                                       // [2][64] a pixel's first cell, number of cells (by round parity)
-    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_span + 128);                   // [CAP] slot | pixel << 6
+    float* s_col = reinterpret_cast<float*>(s_span + 128);                                     // [2][BATCH][3] single-texel colours of the batch (by batch parity)
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_col + 2 * BATCH * 3);          // [CAP] slot | pixel << 6
     unsigned short* s_in = s_pair + CAP;                                                       // [CAP] cells of inside pairs
     const float xp = t.xp, yp = t.yp;
     const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
     PixelState<KCAP> s;                                  // the K-buffer lives in wavefront 0, the colour state in wavefront 1
     ListWalker lw;
-    SectionClock clk;            // instrumented builds only (wavefront 0): 0 stage, 1 masks, 2 pair list, 3 evaluate, 5 inside, 6 apply, 7 stores
+    SectionClock clk;            // instrumented builds only (wavefront 0): 0 stage (wait), 1 masks, 2 pair list (wait), 3 evaluate, 5 inside, 6 apply, 7 stores
     clk.start();
     if (wid == 1) init_colour_state<RGB>(p, s);
     if (wid == 0) {
         init_kbuffer(p, t, ids, s.q);
-        lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
         s_pix[lane] = make_float2(xp, yp);
     }
-    for (;;) {
-        if (wid == 0) {
-            const int f = tune::fwd_heavy_defer_copy ? lw.stage_deferred<BATCH>(p, s_rec, reinterpret_cast<int*>(s_M), lane)   // (s_M is free until the masks)
-                                                     : lw.stage<BATCH>(p, s_rec, nullptr, lane);
-            if (lane == 0) s_misc[0] = f;
+    // stage batch `nb` (wavefront STAGER): records, their colours, the fill count
+    auto stage_batch = [&](int nb) {
+        const int f = tune::fwd_heavy_defer_copy ? lw.stage_deferred<BATCH>(p, s_rec, reinterpret_cast<int*>(s_M), lane)   // (s_M is free: its owner holds the masks in registers)
+                                                 : lw.stage<BATCH>(p, s_rec, nullptr, lane);
+        wave_sync<false>();
+        if (lane < f) {
+            float* c = s_col + ((nb & 1) * BATCH + lane) * 3;
+            c[0] = s_rec[lane].col[0]; c[1] = s_rec[lane].col[1]; c[2] = s_rec[lane].col[2];
         }
-        __syncthreads();                                                       // A: records staged
+        if (lane == 0) s_misc[0] = f;
+    };
+    // pair list of the round that starts at slot j0 (wavefront LISTER, lane = pixel): the widest slot range [j0, j1)
+    // whose pairs fit the cell buffer (a face has <= 64 pairs); pixel-major, ascending face inside a pixel
+    unsigned long long M = 0ull;
+    auto build_list = [&](int j0, int fill, int round) {
+        int j1 = fill, total, cnt, base;
+        unsigned long long Mr;
+        for (;;) {
+            const unsigned long long range = (j1 >= 64 ? ~0ull : ((1ull << j1) - 1ull)) & ~((1ull << j0) - 1ull);
+            Mr = M & range;
+            cnt = __builtin_popcountll(Mr);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            total = __builtin_amdgcn_readlane(incl, 63);
+            base = incl - cnt;
+            if (total <= CAP || j1 - j0 <= 1) break;
+            j1 = j0 + ((j1 - j0 + 1) >> 1);
+        }
+        if (lane == 0) { s_misc[1] = total; s_misc[2] = j1; s_misc[3] = 0; }
+        s_span[(round & 1) * 64 + lane] = make_int2(base, cnt);   // (the apply pass may still be reading the previous round's)
+        int a = base;
+        while (Mr) {
+            const int j = __builtin_ctzll(Mr);
+            Mr &= Mr - 1;
+            s_pair[a++] = (unsigned short)(j | (lane << 6));
+        }
+    };
+    if (wid == STAGER) {
+        lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
+        if (OVERLAP) stage_batch(0);
+    }
+    for (int nb = 0;; nb++) {
+        if (!OVERLAP && wid == STAGER) stage_batch(nb);
+        __syncthreads();                                                       // A: records staged (and the previous batch applied)
         const int fill = s_misc[0];
         if (wid == 0) clk.lap(0);
         if (fill == 0) break;
@@ -892,42 +940,13 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
         }
         __syncthreads();                                                       // B: masks of all 64 pixels
         if (wid == 0) clk.lap(1);
-        unsigned long long M = 0ull;
-        if (wid == 0) M = s_M[lane];
-        int j0 = 0;
+        if (wid == LISTER) { M = s_M[lane]; build_list(0, fill, 0); }
+        if (wid == 0) clk.lap(2);
         for (int round = 0;; round++) {                                        // rounds of the batch
-            int cnt = 0, base = 0;
-            if (wid == 0) {
-                // the widest slot range [j0, j1) whose pairs fit the cell buffer (a face has <= 64 pairs)
-                int j1 = fill, total;
-                unsigned long long Mr;
-                for (;;) {
-                    const unsigned long long range = (j1 >= 64 ? ~0ull : ((1ull << j1) - 1ull)) & ~((1ull << j0) - 1ull);
-                    Mr = M & range;
-                    cnt = __builtin_popcountll(Mr);
-                    int incl = cnt;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const int o = __shfl_up(incl, d);
-                        if (lane >= d) incl += o;
-                    }
-                    total = __builtin_amdgcn_readlane(incl, 63);
-                    base = incl - cnt;
-                    if (total <= CAP || j1 - j0 <= 1) break;
-                    j1 = j0 + ((j1 - j0 + 1) >> 1);
-                }
-                if (lane == 0) { s_misc[1] = total; s_misc[2] = j1; s_misc[3] = 0; }
-                s_span[(round & 1) * 64 + lane] = make_int2(base, cnt);   // (wavefront 1 may still be reading the previous round's)
-                int a = base;                                                  // this pixel's pairs, ascending face
-                while (Mr) {
-                    const int j = __builtin_ctzll(Mr);
-                    Mr &= Mr - 1;
-                    s_pair[a++] = (unsigned short)(j | (lane << 6));
-                }
-            }
-            if (wid == 0) clk.lap(2);
-            __syncthreads();                                                   // C: pair list
+            __syncthreads();                                                   // C: pair list (and the previous round applied)
             const int total = s_misc[1], j1 = s_misc[2];
+            const bool last = j1 >= fill;
+            if (wid == 0) clk.lap(2);
             for (int q0 = wid * 64; q0 < total; q0 += 256) {                   // ---- evaluate: lane = pair ----
                 const int q = q0 + lane;
                 const bool act = q < total;
@@ -970,11 +989,12 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
                         *reinterpret_cast<float2*>(&s_cell[q].z) = da;
                     }
                 }
-                __syncthreads();                                               // E: coverage of the inside pairs
+                __syncthreads();                                               // E: coverage of the inside pairs; records, pair list and scalars are free
                 if (wid == 0) clk.lap(5);
             }
             if (wid <= 1) {                                                    // ---- apply: lane = pixel, K-buffer | colour ----
                 const int2 span = s_span[(round & 1) * 64 + lane];
+                const float* colb = s_col + (nb & 1) * BATCH * 3;
                 // (cells are read one ahead of their use; beyond the pixel's last cell: cell 0 with aux = 0, "not live")
                 float4 cur = s_cell[span.y > 0 ? span.x : 0];
                 if (!(span.y > 0)) cur.w = 0.f;
@@ -982,15 +1002,18 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
                     float4 nxt = s_cell[k + 1 < span.y ? span.x + k + 1 : 0];
                     if (!(k + 1 < span.y)) nxt.w = 0.f;
                     if (wid == 0) apply_kbuf(p, cur, s.q);
-                    else apply_colour<RGB, KCAP>(p, cur, s_rec, tbase, s);
+                    else apply_colour<RGB, KCAP>(p, cur, colb, tbase, s);
                     cur = nxt;
                 }
                 if (wid == 0) clk.lap(6);
             }
-            j0 = j1;
-            if (j0 >= fill) break;
+            if (OVERLAP) {
+                if (wid == LISTER && !last) build_list(j1, fill, round + 1);   // ... meanwhile: the next round's pair list,
+                if (wid == STAGER && last) stage_batch(nb + 1);                // the next batch's records
+            }
+            if (last) break;
+            if (!OVERLAP && wid == LISTER) build_list(j1, fill, round + 1);
         }
-        __syncthreads();                // F: wavefront 1 reads colours from the records until its apply ends; then they may be restaged
     }
     if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
     if (wid == 0) {

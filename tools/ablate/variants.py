@@ -52,6 +52,11 @@ VARIANTS = {
     "diag_nostore": ["JR_TUNE_DIAG=64", "JR_TUNE_FWD_HEAVY=0"],   # WRONG results: forward without the per-insert id stores
     "no_defer_copy": ["JR_TUNE_FWD_HEAVY_DEFER_COPY=0"],     # round 3: heavy tiles copy their records chunk by chunk while walking the list
     "no_empty_bins": ["JR_TUNE_FWD_EMPTY_BINS=0"],           # round 3: the 16 tiles of an empty bin store their own outputs
+    "fwd_k32w3_k64w2": ["JR_TUNE_FWD_WAVES32=3", "JR_TUNE_FWD_WAVES64=2"],   # round 3: K > 16 forward at the wavefront counts it had before (131 / 187 VGPRs)
+    "no_bwd_split": ["JR_TUNE_BWD_SPLIT=0"],                 # round 3: one wavefront per backward tile whatever the launch
+    "bwd_split2": ["JR_TUNE_BWD_SPLIT=2"], "bwd_split8": ["JR_TUNE_BWD_SPLIT=8"],
+    "no_heavy_overlap": ["JR_TUNE_FWD_HEAVY_OVERLAP=0"],     # round 3: heavy tiles stage / list between the passes (wavefront 0) instead of during the apply (wavefronts 3 / 2)
+    "bwd_k64w4": ["JR_TUNE_BWD_WAVES64=4"],                  # round 3: backward at K = 64 with 4 wavefronts per SIMD (52 B of scratch)
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
