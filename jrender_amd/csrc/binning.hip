@@ -11,7 +11,7 @@
 // Pipeline (all on the context stream; one 32-byte read-back of the totals sizes the pool):
 //   k_face_setup : per face -> faces_info (SRK:176-236), packed FaceGeo record, conservative pixel
 //                  rectangle, per-bin counts
-//   k_bin_alloc  : per bin  -> segment base in the pool (atomic bump; placement is irrelevant)
+//   k_bin_alloc_schedule : one workgroup -> segment bases in the pool (placement is irrelevant), totals, launch order
 //   k_bin_fill   : per face -> append (id, tile mask) to each touched bin's segment (unordered)
 //   k_bin_order  : per bin  -> write the segment in ascending id order.  Ids inside one view are unique
 //                  and < NF, so the order is a COUNTING problem, not a comparison sort: set one bit per
@@ -147,24 +147,6 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     }
 }
 
-// counters: [0] = total pairs (bump pointer), [1] = non-empty bins, [2] = max bin count, [3] = heavy bins (k_bin_schedule)
-__global__ __launch_bounds__(256) void k_bin_alloc(int nbins_total, const int* __restrict__ bin_count,
-                                                   int* __restrict__ bin_base,
-                                                   int* __restrict__ bin_cursor,
-                                                   unsigned long long* __restrict__ counters) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nbins_total) return;
-    const int n = bin_count[t];
-    int base = 0;
-    if (n > 0) {
-        base = (int)atomicAdd(&counters[0], (unsigned long long)n);
-        atomicAdd(&counters[1], 1ull);
-        atomicMax(&counters[2], (unsigned long long)n);
-    }
-    bin_base[t] = base;
-    bin_cursor[t] = 0;
-}
-
 __global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4* __restrict__ face_rect,
                                                   const int* __restrict__ bin_base,
                                                   int* __restrict__ bin_cursor,
@@ -261,26 +243,71 @@ __global__ __launch_bounds__(256) void k_bin_order(int NF, const int* __restrict
     }
 }
 
-// Launch order of the bins for the raster kernels: heaviest lists first (longest-processing-time-first
-// keeps the tail of the launch short: the list length of a bin varies from 1 to >1000 faces), empty bins
-// last.  One workgroup: histogram over ~12 buckets per octave of the count, descending prefix, scatter.
-__global__ __launch_bounds__(1024) void k_bin_schedule(int nbins_total, const int* __restrict__ bin_count,
-                                                       int* __restrict__ bin_order,
-                                                       unsigned long long* __restrict__ counters, int heavy_bucket) {
+// Segment bases AND launch order of the bins, one workgroup (round 3: it was two kernels and a memset; the 8 192
+// same-address global atomics of the per-bin allocation alone took as long as a launch).
+//   bases: wave-level prefix of the counts + ONE LDS atomic per wavefront and pass (placement in the pool is irrelevant);
+//   order for the raster kernels: heaviest lists first (longest-processing-time-first keeps the tail of the launch
+//   short: the list length of a bin varies from 1 to > 1000 faces), empty bins last - histogram over ~12 buckets per
+//   octave of the count, descending prefix, scatter.
+// counters: [0] = total pairs, [1] = non-empty bins, [2] = max bin count, [3] = heavy bins - WRITTEN here (nothing to
+// clear beforehand), and copied to `host_counters` (pinned, device-visible) so that the host's read-back of the pair
+// total is a wait on an event, not a copy engine's turn in the stream.
+__global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, const int* __restrict__ bin_count,
+                                                             int* __restrict__ bin_base, int* __restrict__ bin_cursor,
+                                                             int* __restrict__ bin_order,
+                                                             unsigned long long* __restrict__ counters,
+                                                             volatile unsigned long long* __restrict__ host_counters,
+                                                             int heavy_bucket) {
     __shared__ int s_hist[256], s_start[256];
+    __shared__ unsigned long long s_total;
+    __shared__ int s_nonempty, s_max, s_heavy;
     auto bucket = [](int n) { return n <= 0 ? 0 : min(255, 1 + (int)(__log2f((float)n) * 12.f)); };
     if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_total = 0ull; s_nonempty = 0; s_max = 0; s_heavy = 0; }
     __syncthreads();
-    for (int t = threadIdx.x; t < nbins_total; t += 1024) atomicAdd(&s_hist[bucket(bin_count[t])], 1);
+    const int lane = threadIdx.x & 63;
+    for (int t0 = 0; t0 < nbins_total; t0 += 1024) {         // (uniform trip count: the wavefront scans need every lane)
+        const int t = t0 + (int)threadIdx.x;
+        const int n = t < nbins_total ? bin_count[t] : 0;
+        if (t < nbins_total) atomicAdd(&s_hist[bucket(n)], 1);
+        int incl = n, mx = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+            mx = max(mx, __shfl_xor(mx, d));
+        }
+        const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+        const int wnz = __builtin_popcountll(ballot(n > 0));
+        unsigned long long wbase = 0ull;
+        if (wtotal > 0) {                                    // wave-uniform
+            if (lane == 63) {
+                wbase = atomicAdd(&s_total, (unsigned long long)wtotal);
+                atomicAdd(&s_nonempty, wnz);
+                atomicMax(&s_max, mx);
+            }
+            wbase = __shfl(wbase, 63);
+        }
+        if (t < nbins_total) {
+            bin_base[t] = n > 0 ? (int)(wbase + (unsigned long long)(incl - n)) : 0;
+            bin_cursor[t] = 0;
+        }
+    }
     __syncthreads();
     if (threadIdx.x < 256) {                // first rank of bucket b = number of bins in heavier buckets
         int run = 0;
         for (int b = 255; b > (int)threadIdx.x; b--) run += s_hist[b];
         s_start[threadIdx.x] = run;
-        // the bins of buckets >= heavy_bucket are the first `run + own` ranks of the order: counters[3]
-        if ((int)threadIdx.x == min(heavy_bucket, 255)) counters[3] = heavy_bucket > 255 ? 0ull : (unsigned long long)(run + s_hist[threadIdx.x]);
+        // the bins of buckets >= heavy_bucket are the first `run + own` ranks of the order
+        if ((int)threadIdx.x == min(heavy_bucket, 255)) s_heavy = heavy_bucket > 255 ? 0 : run + s_hist[threadIdx.x];
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long c[4] = {s_total, (unsigned long long)s_nonempty, (unsigned long long)s_max, (unsigned long long)s_heavy};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { counters[k] = c[k]; host_counters[k] = c[k]; }
+        __threadfence_system();
+    }
     for (int t = threadIdx.x; t < nbins_total; t += 1024)
         bin_order[atomicAdd(&s_start[bucket(bin_count[t])], 1)] = t;
 }
@@ -346,10 +373,8 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, c
     const int nfaces = p.B * p.NF;
     const int nbins = p.B * p.bins_x * p.bins_y;
     (void)hipMemsetAsync(ws.bin_count, 0, sizeof(int) * (size_t)nbins, st);
-    (void)hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * 4, st);
     k_face_setup<<<(nfaces + SETUP_WG - 1) / SETUP_WG, SETUP_WG, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_count);
-    k_bin_alloc<<<(nbins + 255) / 256, 256, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.counters);
-    k_bin_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_order, ws.counters, heavy_bucket());
+    k_bin_alloc_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.bin_order, ws.counters, ws.host_counters, heavy_bucket());
 }
 
 // Every kernel here is guarded by "total pairs <= pool capacity" read from device memory, so that the
@@ -358,7 +383,7 @@ void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& w
     const int nfaces = p.B * p.NF;
     const int nbins = p.B * p.bins_x * p.bins_y;
     const unsigned long long cap = ws.pool_cap;
-    // k_bin_alloc left the cursors at zero; only a second attempt (after the pool grew) has to clear them
+    // k_bin_alloc_schedule left the cursors at zero; only a second attempt (after the pool grew) has to clear them
     if (reset_cursors) (void)hipMemsetAsync(ws.bin_cursor, 0, sizeof(int) * (size_t)nbins, st);
     k_bin_fill<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.bin_base, ws.bin_cursor, ws.pool_scratch,
                                                      ws.counters, cap);

@@ -184,7 +184,7 @@ int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, cons
 }
 
 // Forward = setup + per-bin ascending lists + raster.  The pool that holds the lists must fit the total
-// number of (bin, face) pairs, which only the device knows after k_bin_alloc.  Waiting for that number
+// number of (bin, face) pairs, which only the device knows after k_bin_alloc_schedule.  Waiting for that number
 // before enqueueing the rest costs a host round trip with an idle GPU on every call, so the rest is
 // enqueued SPECULATIVELY against the pool we already have (every kernel re-checks "pairs <= capacity" in
 // device memory and does nothing otherwise); the host then waits for the 32-byte read-back only, and in
@@ -193,9 +193,7 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
                      float* faces_info, float* aggrs_info, float* soft_colors, int32_t* faces_id_buffer) {
     jr::BinWorkspace& ws = ctx->ws;
     if (setup_faces(ctx, p, faces, textures, faces_info)) return 1;
-    JR_HIP(hipMemcpyAsync(ctx->h_counters, ws.counters, sizeof(unsigned long long) * 4,
-                          hipMemcpyDeviceToHost, ctx->stream));
-    JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));
+    JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));     // k_bin_alloc_schedule has written the totals to h_counters
     auto enqueue = [&](bool again) {
         {
             ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
@@ -252,7 +250,8 @@ int jr_ctx_create(int device, jr_ctx** out) {
     if (!c) return fail("out of host memory");
     c->device = device;
     JR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    JR_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * 4, hipHostMallocDefault));
+    JR_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    JR_HIP(hipHostGetDevicePointer((void**)&c->ws.host_counters, c->h_counters, 0));
     JR_HIP(hipMalloc((void**)&c->ws.counters, sizeof(unsigned long long) * 24));   // [0..3] bin totals, [4..23] section clocks (instrumented builds)
     JR_HIP(hipMemset(c->ws.counters, 0, sizeof(unsigned long long) * 24));
     JR_HIP(hipEventCreateWithFlags(&c->ev_counters, hipEventDisableTiming));

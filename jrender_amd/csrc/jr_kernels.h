@@ -17,12 +17,13 @@ struct BinWorkspace {
     int* bin_cursor = nullptr;                 // [B*bins]
     int* bin_order = nullptr;                  // [B*bins] launch rank -> bin, heaviest list first
     unsigned long long* counters = nullptr;    // [4] device: total pairs, non-empty bins, max count, heavy bins (a prefix of bin_order)
+    unsigned long long* host_counters = nullptr;   // the same four in pinned host memory (device address), written by k_bin_alloc_schedule
     unsigned long long* pool = nullptr;        // [pool_cap] (face id << 32 | tile mask), per bin ascending
     unsigned long long* pool_scratch = nullptr;// [pool_cap] the same segments as filled (unordered)
     size_t faces_cap = 0, bins_cap = 0, pool_cap = 0;
 };
 
-// Launch order of the bins (k_bin_schedule): ~12 buckets per octave of the list length, heaviest first.  Bins in
+// Launch order of the bins (k_bin_alloc_schedule): ~12 buckets per octave of the list length, heaviest first.  Bins in
 // buckets >= heavy_bucket() are the "heavy" prefix of the order (counters[3]) that the forward gives four
 // wavefronts per tile; every one of them lists at least fwd_heavy_floor() faces.
 inline int heavy_bucket() { return tune::fwd_heavy > 0 ? 1 + (int)(log2f((float)tune::fwd_heavy) * 12.f) : 1 << 30; }

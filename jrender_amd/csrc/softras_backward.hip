@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     if (k < hx * 16 * SPLIT) { brank = (k / (16 * SPLIT)) * 8 + xcd; sub = (k / SPLIT) & 15; part = k % SPLIT; }
     else { const int k2 = k - hx * 16 * SPLIT; brank = (hx + (k2 >> 4)) * 8 + xcd; sub = k2 & 15; }   // bins are dealt round-robin to the XCDs ...
     if (brank >= nbins) return;
-    const int bin = bin_order[brank];                         // ... heaviest first (k_bin_schedule)
+    const int bin = bin_order[brank];                         // ... heaviest first (k_bin_alloc_schedule)
     const int n = bin_count[bin];
     if (n == 0) return;
     const int bins_per_img = p.bins_x * p.bins_y;
@@ -518,13 +518,34 @@ bool backward_splits_heavy_tiles(const RasterParams& p) {
     return tune::bwd_split > 1 && tune::fwd_heavy > 0 && (long)p.B * p.IS * p.IS <= (long)tune::bwd_split_pixels;
 }
 
+// Both gradient outputs cleared by ONE launch (they are separate caller-owned buffers: two memsets were two launches,
+// which is what a single view's backward notices).  16-byte stores over the aligned body, scalar head / tail.
+__global__ __launch_bounds__(256) void k_zero2(float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        float* q = which ? b : a;
+        const size_t n = which ? nb : na;
+        const size_t head = min(n, (size_t)((16 - ((uintptr_t)q & 15)) & 15) >> 2);   // floats up to the first 16-byte boundary
+        const size_t body = (n - head) >> 2;
+        float4* q4 = reinterpret_cast<float4*>(q + head);
+        for (size_t i = tid; i < body; i += nthreads) q4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < head) q[tid] = 0.f;
+        const size_t tail0 = head + (body << 2);
+        if (tid < n - tail0) q[tail0 + tid] = 0.f;
+    }
+}
+
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,
                              const float* rgba, const float* aggrs, const int32_t* ids,
                              const float* grad_rgba, const BinWorkspace& ws, float* grad_faces,
                              float* grad_textures) {
     const int ntiles = p.B * p.bins_x * p.bins_y * SUBS * SUBS;
-    (void)hipMemsetAsync(grad_faces, 0, sizeof(float) * (size_t)p.B * p.NF * 9, st);          // SRK:1374
-    (void)hipMemsetAsync(grad_textures, 0, sizeof(float) * (size_t)p.B * p.NF * p.T * 3, st); // SRK:1375
+    {                                                                                           // SRK:1374-1375
+        const size_t na = (size_t)p.B * p.NF * 9, nb = (size_t)p.B * p.NF * p.T * 3;
+        const size_t wgs = ((na + nb) / 4 + 255) / 256;
+        k_zero2<<<(unsigned)(wgs < 1 ? 1 : (wgs > 4096 ? 4096 : wgs)), 256, 0, st>>>(grad_faces, na, grad_textures, nb);
+    }
 #define JR_BWD(D, R) \
     launch_k<D, R>(st, p, ntiles, textures, ws, rgba, aggrs, ids, grad_rgba, grad_faces, grad_textures)
     const int rgb = p.rgb == 0 ? 0 : (p.rgb == 1 ? 1 : 2);

@@ -17,7 +17,7 @@
 //                         and runs the per-(pixel,face) arithmetic on the LDS record of ITS face — lanes
 //                         stay busy although neighbouring pixels see different face subsets.
 //
-// Tiles are visited heaviest bin first (k_bin_schedule), bins dealt round-robin to the XCDs: the list
+// Tiles are visited heaviest bin first (k_bin_alloc_schedule), bins dealt round-robin to the XCDs: the list
 // length varies from 1 to >1000 faces and the launch would otherwise end with a long tail.
 //
 // The per-pixel state machine (alpha, online softmax over depth, K-nearest buffer) lives in VGPRs;
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
     const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
     if (brank * 16 >= ntiles_total) return;
-    const int bin = bin_order[brank];                    // ... heaviest first (k_bin_schedule)
+    const int bin = bin_order[brank];                    // ... heaviest first (k_bin_alloc_schedule)
     const int n = bin_count[bin];
     // tune::fwd_prio: issue priority for the wavefronts of the heaviest bins (measured: no effect)
     if (tune::fwd_prio > 0 && n > tune::fwd_prio) __builtin_amdgcn_s_setprio(3);
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
 }
 
-// Four wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first (k_bin_schedule) and its
+// Four wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first (k_bin_alloc_schedule) and its
 // first counters[3] bins are HEAVY (list longer than tune::fwd_heavy): a workgroup takes ONE tile of a heavy bin with
 // its four wavefronts together (tile_heavy), or FOUR tiles (one row of tiles) of a lighter bin, one per wavefront
 // (tile_single, each with a quarter of the workgroup's LDS).  Per XCD (workgroup id % 8) the heavy tiles come first.
