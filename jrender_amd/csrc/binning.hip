@@ -48,38 +48,34 @@ __device__ inline void pixel_range(float vlo, float vhi, int is, int& lo, int& h
 }
 
 // Wave-aggregated counter bump: lanes that target the same bin form a group (ballot match against the
-// first pending lane), the group's first lane adds the group size, every member gets base + its rank.
-// After a few rounds the stragglers (unrelated faces, e.g. a triangle soup) fall back to one atomic each.
+// first pending lane; after four rounds the stragglers - unrelated faces, e.g. a triangle soup - are groups of
+// one), the group's first lane adds the group size, every member gets base + its rank.  The matching is ALU only
+// and ALL leaders add in ONE atomic instruction: one memory round trip per call (round 3; it was one per group,
+// and a single view's k_bin_fill - 610 wavefronts, nothing to hide latency behind - was a chain of ~16 of them).
 template <bool RET>
 __device__ inline int wave_bin_add(int* __restrict__ arr, int tb) {
-    int pos = 0;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int rank = 0, leader = lane, cnt = 1, key = tb;
     unsigned long long todo = ballot(tb >= 0);
     for (int round = 0; todo != 0 && round < 4; round++) {
-        const int leader = __builtin_ctzll(todo);
-        const int lb = __builtin_amdgcn_readlane(tb, leader);
-        const unsigned long long same = ballot(tb == lb);
-        int base = 0;
-        if (tb == lb) {
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
-            if (rank == 0) {
-                if (RET) base = atomicAdd(&arr[lb], __builtin_popcountll(same));
-                else (void)atomicAdd(&arr[lb], __builtin_popcountll(same));
-            }
-            pos = rank;
-            tb = -2 - tb;                 // done (kept recoverable: only the sign matters below)
-        }
-        if (RET) {
-            const int gb = __builtin_amdgcn_readlane(base, leader);
-            if (tb < -1 && -2 - tb == lb) pos += gb;
+        const int l = __builtin_ctzll(todo);
+        const int lb = __builtin_amdgcn_readlane(key, l);
+        const unsigned long long same = ballot(key == lb);
+        if (key == lb) {
+            rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+            leader = l;
+            cnt = __builtin_popcountll(same);
+            key = -1;                     // done
         }
         todo &= ~same;
     }
-    if (tb >= 0) {
-        if (RET) pos = atomicAdd(&arr[tb], 1);
-        else (void)atomicAdd(&arr[tb], 1);
+    int base = 0;
+    if (tb >= 0 && rank == 0) {
+        if (RET) base = atomicAdd(&arr[tb], cnt);
+        else (void)atomicAdd(&arr[tb], cnt);
     }
-    return pos;
+    if (!RET) return 0;
+    return __shfl(base, leader) + rank;
 }
 
 constexpr int SETUP_WG = 128;      // faces per workgroup of k_face_setup (22 KB of LDS: 7 workgroups per CU in flight)

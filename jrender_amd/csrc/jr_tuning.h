@@ -57,6 +57,12 @@
 #ifndef JR_TUNE_FWD_HEAVY_OVERLAP // heavy tiles: wavefront 3 stages the next batch and wavefront 2 writes the next round's pair list WHILE wavefronts 0 / 1 apply (0: wavefront 0 does both between the passes)
 #define JR_TUNE_FWD_HEAVY_OVERLAP 1
 #endif
+#ifndef JR_TUNE_FWD_HEAVY_PIPE    // heavy tiles as a pipeline: wavefronts 0 / 1 apply round n-1 while round n is evaluated around them (0: tile_heavy, passes in sequence)
+#define JR_TUNE_FWD_HEAVY_PIPE 1
+#endif
+#ifndef JR_TUNE_FWD_PIPE_CONSUMER_TASKS   // pipelined heavy tile: which applying wavefronts also take evaluate / mask tasks once their apply is done (bit 0: the K-buffer wavefront, bit 1: the colour wavefront)
+#define JR_TUNE_FWD_PIPE_CONSUMER_TASKS 3
+#endif
 #ifndef JR_TUNE_FWD_HEAVY_PIXELS // forward: launches of up to this many pixels (B x IS x IS) use the four-wavefront kernel, larger ones one wavefront per tile
 #define JR_TUNE_FWD_HEAVY_PIXELS 4194304
 #endif
@@ -107,6 +113,8 @@ constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
 constexpr int fwd_batch_mixed = JR_TUNE_FWD_BATCH_MIXED;
 constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
 constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;
+constexpr bool fwd_heavy_pipe = JR_TUNE_FWD_HEAVY_PIPE != 0;
+constexpr int fwd_pipe_consumer_tasks = JR_TUNE_FWD_PIPE_CONSUMER_TASKS;
 constexpr int bwd_split = JR_TUNE_BWD_SPLIT;
 constexpr long bwd_split_pixels = JR_TUNE_BWD_SPLIT_PIXELS;
 constexpr int fwd_waves32 = JR_TUNE_FWD_WAVES32;

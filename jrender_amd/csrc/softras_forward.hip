@@ -1023,6 +1023,249 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     }
 }
 
+// =====================================================================================================================
+// The same heavy tile as a PIPELINE (tune::fwd_heavy_pipe, round 3).  In tile_heavy the apply pass is 55 % of the tile's
+// clocks and two of the four wavefronts wait through it; the evaluate pass of the NEXT round needs nothing from it.  So
+// the rounds are cut smaller (PIPE_CAP cells, PIPE_BATCH records), cells / pair lists / records are double-buffered, and a
+// STEP is: wavefronts 0 / 1 apply round n-1 while everything else of round n (and of the batch after) happens around them:
+//
+//   pinned     wavefront 3 owns the list walk: it stages the batch AFTER the one being evaluated (records of two batches
+//              are resident), and writes the pair list of the round to be evaluated in the next step
+//   claimable  64-pair evaluate chunks of round n, and the four 2-row mask tasks of a freshly staged batch: every wavefront
+//              (0 / 1 once their apply is done) takes the next one from an LDS counter
+//   inside     a wavefront collects the inside pairs of ITS chunks and runs them in dense trips of its own
+//
+// One barrier per step; all decisions that shape the control flow are taken by wavefront 3 and published in the step's
+// state block (two blocks, by step parity), so every wavefront takes the same branches.  Results: the same device
+// functions on the same operands in the same per-pixel order as tile_heavy / tile_single.
+// =====================================================================================================================
+constexpr int PIPE_BATCH = 40, PIPE_CAP = 512, PIPE_IN = 128;
+constexpr int PIPE_LDS_BYTES = 2 * PIPE_BATCH * (int)sizeof(FaceRec) + 2 * PIPE_CAP * 16 + 64 * 8 + 2 * 64 * 8 + 3 * 64 * 8
+                             + 4 * PIPE_BATCH * 12 + 64 * 4 + PIPE_BATCH * 4 + 2 * PIPE_CAP * 2 + 4 * PIPE_IN * 2;
+static_assert(PIPE_LDS_BYTES <= HEAVY_LDS_BYTES, "the pipelined heavy tile must fit the workgroup's LDS");
+enum { PS_VALID = 0, PS_BATCH, PS_J0, PS_J1, PS_TOTAL, PS_LAST, PS_MASKS, PS_MBATCH, PS_MFILL, PS_CLAIM, PS_DONE, PS_WORDS = 16 };
+
+template <int DIST, int RGB, int KCAP>
+__device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t, int wid, int lane, float4* s_mem,
+                                       const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
+                                       const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
+                                       float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    constexpr int BATCH = PIPE_BATCH, CAP = PIPE_CAP;
+    FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                                        // [2][BATCH] by batch parity
+    float4* s_cell = reinterpret_cast<float4*>(s_rec + 2 * BATCH);                             // [2][CAP]   by step parity
+    float2* s_pix = reinterpret_cast<float2*>(s_cell + 2 * CAP);                               // [64] pixel centres
+    unsigned long long* s_M = reinterpret_cast<unsigned long long*>(s_pix + 64);               // [2][64] face masks, by batch parity
+    int2* s_span = reinterpret_cast<int2*>(s_M + 2 * 64);                                      // [3][64] first cell, cells of a pixel, by step % 3
+    float* s_col = reinterpret_cast<float*>(s_span + 3 * 64);                                  // [4][BATCH][3] colours, by batch & 3
+    int* s_state = reinterpret_cast<int*>(s_col + 4 * BATCH * 3);                              // [2][PS_WORDS] by step parity
+    int* s_slot = s_state + 64;                                                                // [BATCH] staging scratch
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_slot + BATCH);                 // [2][CAP] slot | pixel << 6, by step parity
+    unsigned short* s_in = s_pair + 2 * CAP + wid * PIPE_IN;                                   // [PIPE_IN] this wavefront's inside pairs
+    const float xp = t.xp, yp = t.yp;
+    const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
+    PixelState<KCAP> s;                                  // the K-buffer lives in wavefront 0, the colour state in wavefront 1
+    ListWalker lw;
+    SectionClock clk;            // instrumented builds only (wavefront 0): 0 barrier wait, 3 claimed tasks, 6 apply, 7 stores
+    clk.start();
+    if (wid == 1) init_colour_state<RGB>(p, s);
+    if (wid == 0) {
+        init_kbuffer(p, t, ids, s.q);
+        s_pix[lane] = make_float2(xp, yp);
+    }
+    // ---- wavefront 3: staging and pair lists ----
+    auto stage_batch = [&](int nb) -> int {
+        FaceRec* rec = s_rec + (nb & 1) * BATCH;
+        const int f = lw.stage_deferred<BATCH>(p, rec, s_slot, lane);
+        wave_sync<false>();
+        if (lane < f) {
+            float* c = s_col + ((nb & 3) * BATCH + lane) * 3;
+            c[0] = rec[lane].col[0]; c[1] = rec[lane].col[1]; c[2] = rec[lane].col[2];
+        }
+        return f;
+    };
+    // pair list of the round of batch `nb` that starts at slot j0, for the step `ns`: the widest slot range [j0, j1) whose
+    // pairs fit the cell buffer (a face has <= 64 pairs); pixel-major, ascending face inside a pixel
+    auto build_list = [&](int nb, int j0, int fill, int ns, int* st) {
+        const unsigned long long M = s_M[(nb & 1) * 64 + lane];
+        int j1 = fill, total, cnt, base;
+        unsigned long long Mr;
+        for (;;) {
+            const unsigned long long range = (j1 >= 64 ? ~0ull : ((1ull << j1) - 1ull)) & ~((1ull << j0) - 1ull);
+            Mr = M & range;
+            cnt = __builtin_popcountll(Mr);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            total = __builtin_amdgcn_readlane(incl, 63);
+            base = incl - cnt;
+            if (total <= CAP || j1 - j0 <= 1) break;
+            j1 = j0 + ((j1 - j0 + 1) >> 1);
+        }
+        if (lane == 0) { st[PS_VALID] = 1; st[PS_BATCH] = nb; st[PS_J0] = j0; st[PS_J1] = j1; st[PS_TOTAL] = total; st[PS_LAST] = j1 >= fill; }
+        s_span[(ns % 3) * 64 + lane] = make_int2(base, cnt);
+        unsigned short* pl = s_pair + (ns & 1) * CAP;
+        int a = base;
+        while (Mr) {
+            const int j = __builtin_ctzll(Mr);
+            Mr &= Mr - 1;
+            pl[a++] = (unsigned short)(j | (lane << 6));
+        }
+    };
+    // the four 2-row mask tasks of batch nb
+    auto mask_task = [&](int k, int nb, int fill) {
+        const FaceRec* rec = s_rec + (nb & 1) * BATCH;
+        unsigned long long Mw;
+        switch (k) {
+            case 0: Mw = pixel_masks<DIST, 0, 2>(p, rec, fill, lane, xp, yp); break;
+            case 1: Mw = pixel_masks<DIST, 2, 4>(p, rec, fill, lane, xp, yp); break;
+            case 2: Mw = pixel_masks<DIST, 4, 6>(p, rec, fill, lane, xp, yp); break;
+            default: Mw = pixel_masks<DIST, 6, 8>(p, rec, fill, lane, xp, yp); break;
+        }
+        if ((lane >> 4) == k) s_M[(nb & 1) * 64 + lane] = t.valid ? Mw : 0ull;
+    };
+
+    // ---- prologue: batch 0 staged, masked, its first round listed (serial, as in tile_heavy) ----
+    int w3_fill = 0;                                     // wavefront 3: records of the batch it lists from
+    if (wid == 3) {
+        lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
+        w3_fill = stage_batch(0);
+        if (lane == 0) s_state[PS_MFILL] = w3_fill;
+    }
+    __syncthreads();
+    const int fill0 = s_state[PS_MFILL];
+    if (fill0 > 0) {
+        mask_task(wid, 0, fill0);
+        __syncthreads();
+        if (wid == 3) {
+            build_list(0, 0, fill0, 0, s_state);
+            if (lane == 0) { s_state[PS_MASKS] = 0; s_state[PS_CLAIM] = 0; s_state[PS_DONE] = 0; }
+        }
+        __syncthreads();
+        // wavefront 3's private view of the pipeline
+        int cur_batch = 0;               // batch of the latest listed round
+        bool staged = false, masked = false, walker_done = false;
+        bool offer_next = false, offer_now = false;      // the staged batch's mask tasks run in the next / in this step
+        int staged_fill = 0;
+        // every wavefront: the round applied in this step = the round evaluated in the previous one
+        bool a_valid = false;
+        int a_batch = 0;
+        for (int step = 0;; step++) {
+            const int* st = s_state + (step & 1) * PS_WORDS;
+            int* nx = s_state + ((step + 1) & 1) * PS_WORDS;
+            const bool e_valid = st[PS_VALID] != 0;
+            const int e_batch = st[PS_BATCH], e_total = st[PS_TOTAL];
+            const bool offer = st[PS_MASKS] != 0;
+            if (st[PS_DONE] && !a_valid) break;
+            if (wid == 0) clk.lap(0);
+            // ---- apply round step-1: lane = pixel, K-buffer | colour ----
+            if (wid <= 1 && a_valid) {
+                const int2 span = s_span[((step + 2) % 3) * 64 + lane];                        // (step - 1) % 3
+                const float4* cells = s_cell + ((step + 1) & 1) * CAP;
+                const float* colb = s_col + (a_batch & 3) * BATCH * 3;
+                float4 cur = cells[span.y > 0 ? span.x : 0];
+                if (!(span.y > 0)) cur.w = 0.f;
+                for (int k = 0; ballot(k < span.y) != 0ull; k++) {
+                    float4 nxt = cells[k + 1 < span.y ? span.x + k + 1 : 0];
+                    if (!(k + 1 < span.y)) nxt.w = 0.f;
+                    if (wid == 0) apply_kbuf(p, cur, s.q);
+                    else apply_colour<RGB, KCAP>(p, cur, colb, tbase, s);
+                    cur = nxt;
+                }
+                if (wid == 0) clk.lap(6);
+            }
+            // ---- wavefront 3: the batch after, the next round's list, the next step's state ----
+            if (wid == 3) {
+                if (offer_now) masked = true;                // the mask tasks that ran in the previous step are complete
+                offer_now = offer_next; offer_next = false;
+                int nmasks = 0;
+                if (!staged && !walker_done && !st[PS_DONE]) {
+                    const int f = stage_batch(cur_batch + 1);
+                    if (f == 0) walker_done = true;
+                    else { staged = true; staged_fill = f; nmasks = 1; offer_next = true; }
+                }
+                bool listed = false;
+                if (e_valid && !st[PS_LAST]) { build_list(e_batch, st[PS_J1], w3_fill, step + 1, nx); listed = true; }
+                else if (masked) {
+                    cur_batch++; w3_fill = staged_fill;
+                    staged = false; masked = false;
+                    build_list(cur_batch, 0, w3_fill, step + 1, nx);
+                    listed = true;
+                }
+                if (lane == 0) {
+                    if (!listed) nx[PS_VALID] = 0;
+                    nx[PS_MASKS] = nmasks; nx[PS_MBATCH] = cur_batch + 1; nx[PS_MFILL] = staged_fill;
+                    nx[PS_CLAIM] = 0;
+                    nx[PS_DONE] = (!listed && walker_done && !staged) ? 1 : 0;
+                }
+            }
+            // ---- claimable tasks: evaluate chunks of this step's round, mask tasks of a freshly staged batch ----
+            // (tune::fwd_pipe_consumer_tasks: bit 0 / 1 = wavefront 0 / 1 joins after its apply)
+            if (wid >= 2 || ((tune::fwd_pipe_consumer_tasks >> wid) & 1)) {
+                const int nchunks = e_valid ? (e_total + 63) >> 6 : 0;
+                const int ntasks = nchunks + (offer ? 4 : 0);
+                const FaceRec* recE = s_rec + (e_batch & 1) * BATCH;
+                const unsigned short* pl = s_pair + (step & 1) * CAP;
+                float4* cells = s_cell + (step & 1) * CAP;
+                int n_in = 0;
+                auto run_inside = [&](int base, int count) {
+                    wave_sync<false>();
+                    if (lane < count) {
+                        const int q = s_in[base + lane];
+                        const unsigned pr = pl[q];
+                        const FaceRec& r = recE[pr & 63u];
+                        const float2 c = s_pix[pr >> 6];
+                        const unsigned aux = __builtin_bit_cast(unsigned, cells[q].w);
+                        float2 da;
+                        if (face_safe(r.meta) && p.consts_safe) da = evaluate_inside<true>(p, r, c.x, c.y, aux);
+                        else da = evaluate_inside<false>(p, r, c.x, c.y, aux);
+                        *reinterpret_cast<float2*>(&cells[q].z) = da;
+                    }
+                };
+                for (;;) {
+                    int k = 0;
+                    if (lane == 0) k = atomicAdd(const_cast<int*>(&st[PS_CLAIM]), 1);
+                    k = __builtin_amdgcn_readfirstlane(k);
+                    if (k >= ntasks) break;
+                    if (k >= nchunks) { mask_task(k - nchunks, st[PS_MBATCH], st[PS_MFILL]); continue; }
+                    const int q = k * 64 + lane;
+                    bool deferred = false;
+                    if (q < e_total) {
+                        const unsigned pr = pl[q];
+                        const FaceRec& r = recE[pr & 63u];
+                        const float2 c = s_pix[pr >> 6];
+                        float4 cell;
+                        if (face_safe(r.meta) && p.consts_safe) cell = evaluate_pair<DIST, RGB, true>(p, r, c.x, c.y, pr & 63u, deferred);
+                        else cell = evaluate_pair<DIST, RGB, false>(p, r, c.x, c.y, pr & 63u, deferred);
+                        cells[q] = cell;
+                    }
+                    if (DIST == 2) {
+                        const unsigned long long im = ballot(deferred);
+                        if (im) {
+                            const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(im >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)im, 0u));
+                            if (deferred) s_in[n_in + rk] = (unsigned short)q;
+                            n_in += __builtin_popcountll(im);
+                            if (n_in >= 64) { n_in -= 64; run_inside(n_in, 64); }      // a dense trip of the newest 64
+                        }
+                    }
+                }
+                if (DIST == 2 && n_in > 0) run_inside(0, n_in);
+                if (wid == 0) clk.lap(3);
+            }
+            a_valid = e_valid; a_batch = e_batch;
+            __syncthreads();
+        }
+    }
+    if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
+    if (wid == 0) {
+        store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+        clk.lap(7);
+        if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2]) clk.flush(counters, 4);   // the 16 tiles of the heaviest bin
+    }
+}
+
 // ---- kernels -----------------------------------------------------------------------------------------------------------
 // One wavefront per workgroup, one tile per wavefront (rounds 1-2; tune::fwd_heavy = 0, and vertex colours).
 template <int DIST, int RGB, int KCAP>
@@ -1083,7 +1326,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
     TileGeom t;
     if (!tile_geom(p, bin, sub, n, lane, t)) return;     // (a heavy tile: uniform for the workgroup)
     const unsigned long long* seg = pool + bin_base[bin];
-    if (heavy) tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
+    if (heavy) {
+        if (tune::fwd_heavy_pipe) tile_heavy_pipe<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
+        else tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
+    }
     else tile_single<DIST, RGB, KCAP, HEAVY_BATCH, false>(p, t, lane, s_dyn + wid * (sizeof(FaceRec) * HEAVY_BATCH / sizeof(float4)),
                                              textures, geo, seg, counters, aggrs, rgba, ids);
 }

@@ -83,3 +83,13 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stderr)
     assert "gfx950" in out.stdout
+
+
+def test_library_is_not_older_than_its_sources():
+    """The GPU box runs the prebuilt in-tree library: a library older than csrc/ means the measured / tested code is
+    not the code in the tree (`python -m jrender_amd._build`, or `__graft_entry__.build()`, rebuilds it)."""
+    from jrender_amd import _build
+    deps = [os.path.join(_build.CSRC, f) for f in _build.SOURCES + _build.HEADERS]
+    t = os.path.getmtime(_ffi.LIB_PATH)
+    newer = [os.path.relpath(d, ROOT) for d in deps if os.path.getmtime(d) > t]
+    assert not newer, "libjrender_hip.so is older than %s" % newer
