@@ -217,8 +217,8 @@ int jr_selftest_reciprocal(jr_ctx* ctx, uint64_t* mismatches);
 /* statistics of the last forward on this context: [0]=bin-face pairs, [1]=non-empty 32x32 bins,
  * [2]=max faces in a bin, [3]=bins per image */
 int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]);
-/* which paths the last launches took: [0]=1 when the last forward ran the four-wavefront kernel (launches of up to 4 Mpixels),
- * [1]=bins whose tiles got four wavefronts each in it, [2]=[3]=0 */
+/* which paths the last launches took: [0]=1 when the last forward ran the multi-wavefront kernel (launches of up to 4 Mpixels),
+ * [1]=bins whose tiles got a whole workgroup each in it, [2]=wavefronts per workgroup (4 or 8; 1 = one wavefront per tile), [3]=0 */
 int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]);
 /* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
  * previous call, [0..7] forward raster, [8..15] backward raster; all zero in the product build */

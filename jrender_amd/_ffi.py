@@ -299,7 +299,7 @@ class Context:
         """Which paths the last launches took (jr_softras_last_launch)."""
         s = (C.c_int64 * 4)()
         _check(load().jr_softras_last_launch(self.handle, s))
-        return dict(four_wavefront_kernel=bool(s[0]), heavy_bins=int(s[1]))
+        return dict(four_wavefront_kernel=bool(s[0]), heavy_bins=int(s[1]), wavefronts_per_workgroup=int(s[2]))
 
     def close(self):
         if self.handle:

@@ -54,7 +54,8 @@ struct jr_ctx {
     int bins_B = 0, bins_NF = 0, bins_IS = 0;
     float bins_rad = 0.f;
     int64_t stats[4] = {0, 0, 0, 0};
-    int64_t launch_info[4] = {0, 0, 0, 0};  // last forward: four-wavefront kernel used, heavy bins
+    int64_t launch_info[4] = {0, 0, 0, 0};  // last forward: multi-wavefront kernel used, heavy bins, wavefronts per workgroup
+    int last_B = 0, last_NF = 0, last_IS = 0; int64_t last_heavy = -1;   // heavy bins the previous forward found (for the next one's workgroup size)
     unsigned long long* zkey = nullptr;     // n3mr z-buffer keys [B*IS*IS]
     size_t zkey_cap = 0;
     unsigned char* n3_scratch = nullptr;    // n3mr backward: packed per-pixel planes in both orientations
@@ -192,6 +193,15 @@ int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, cons
 int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
                      float* faces_info, float* aggrs_info, float* soft_colors, int32_t* faces_id_buffer) {
     jr::BinWorkspace& ws = ctx->ws;
+    // Workgroup size of the multi-wavefront kernel.  Eight wavefronts per heavy tile cut a lone view's critical path
+    // further (one 39k-face view: 0.33 -> 0.28 ms), but they and the eight light tiles per workgroup cost throughput as
+    // soon as the launch can fill the GPU (two views: 0.33 -> 0.37 ms).  How many heavy tiles a launch has is known on
+    // the device only, so the host uses what the PREVIOUS forward of the same shape found (an optimisation loop renders
+    // the same scene again and again): eight when those tiles' wavefronts fit a fraction of the GPU, else four.
+    ws.heavy_waves = 4;
+    if (jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8 && ctx->last_heavy >= 0 && ctx->last_B == p.B &&
+        ctx->last_NF == p.NF && ctx->last_IS == p.IS && ctx->last_heavy * 16 * 8 <= jr::tune::fwd_heavy_waves8_budget)
+        ws.heavy_waves = 8;
     if (setup_faces(ctx, p, faces, textures, faces_info)) return 1;
     JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));     // k_bin_alloc_schedule has written the totals to h_counters
     auto enqueue = [&](bool again) {
@@ -212,6 +222,8 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     ctx->stats[3] = (int64_t)p.bins_x * p.bins_y;
     ctx->launch_info[0] = jr::forward_uses_heavy_path(p) ? 1 : 0;
     ctx->launch_info[1] = ctx->launch_info[0] ? (int64_t)ctx->h_counters[3] : 0;
+    ctx->launch_info[2] = ctx->launch_info[0] ? ws.heavy_waves : 1;
+    ctx->last_B = p.B; ctx->last_NF = p.NF; ctx->last_IS = p.IS; ctx->last_heavy = (int64_t)ctx->h_counters[3];
     if (pairs > 0x7fffffffULL)       // segment bases are 32-bit
         return fail("%zu (bin, face) pairs exceed the 2^31 - 1 the bin lists index: render fewer views per call", pairs);
     if (!speculative || pairs > ws.pool_cap) {

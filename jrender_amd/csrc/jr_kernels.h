@@ -21,6 +21,7 @@ struct BinWorkspace {
     unsigned long long* pool = nullptr;        // [pool_cap] (face id << 32 | tile mask), per bin ascending
     unsigned long long* pool_scratch = nullptr;// [pool_cap] the same segments as filled (unordered)
     size_t faces_cap = 0, bins_cap = 0, pool_cap = 0;
+    int heavy_waves = 4;                        // wavefronts per workgroup of the next forward's four-/eight-wavefront kernel (host policy, jr_api.cpp)
 };
 
 // Launch order of the bins (k_bin_alloc_schedule): ~12 buckets per octave of the list length, heaviest first.  Bins in

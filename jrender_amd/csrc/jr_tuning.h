@@ -60,6 +60,12 @@
 #ifndef JR_TUNE_FWD_HEAVY_PIPE    // heavy tiles as a pipeline: wavefronts 0 / 1 apply round n-1 while round n is evaluated around them (0: tile_heavy, passes in sequence)
 #define JR_TUNE_FWD_HEAVY_PIPE 1
 #endif
+#ifndef JR_TUNE_FWD_HEAVY_WAVES   // wavefronts per workgroup of the multi-wavefront kernel when the heavy tiles are pipelined: 4, or 8 = eight where the host's policy says so (jr_api.cpp)
+#define JR_TUNE_FWD_HEAVY_WAVES 8
+#endif
+#ifndef JR_TUNE_FWD_HEAVY_WAVES8_BUDGET   // eight wavefronts per heavy tile while (heavy tiles of the previous forward) x 8 wavefronts stay below this (the GPU holds 4096 at 16 per CU)
+#define JR_TUNE_FWD_HEAVY_WAVES8_BUDGET 2048
+#endif
 #ifndef JR_TUNE_FWD_PIPE_CONSUMER_TASKS   // pipelined heavy tile: which applying wavefronts also take evaluate / mask tasks once their apply is done (bit 0: the K-buffer wavefront, bit 1: the colour wavefront)
 #define JR_TUNE_FWD_PIPE_CONSUMER_TASKS 3
 #endif
@@ -115,6 +121,9 @@ constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
 constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;
 constexpr bool fwd_heavy_pipe = JR_TUNE_FWD_HEAVY_PIPE != 0;
 constexpr int fwd_pipe_consumer_tasks = JR_TUNE_FWD_PIPE_CONSUMER_TASKS;
+constexpr int fwd_heavy_waves = JR_TUNE_FWD_HEAVY_WAVES;
+constexpr long fwd_heavy_waves8_budget = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET;
+static_assert(fwd_heavy_waves == 4 || fwd_heavy_waves == 8, "JR_TUNE_FWD_HEAVY_WAVES");
 constexpr int bwd_split = JR_TUNE_BWD_SPLIT;
 constexpr long bwd_split_pixels = JR_TUNE_BWD_SPLIT_PIXELS;
 constexpr int fwd_waves32 = JR_TUNE_FWD_WAVES32;

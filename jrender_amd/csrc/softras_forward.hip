@@ -29,6 +29,7 @@
 // reciprocal multiplies where the reference divides by sigma / gamma (error <= 1-2 ulp).
 #include <stdlib.h>
 
+#include <type_traits>
 #include "jr_kernels.h"
 
 namespace jr {
@@ -1039,18 +1040,25 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
 // state block (two blocks, by step parity), so every wavefront takes the same branches.  Results: the same device
 // functions on the same operands in the same per-pixel order as tile_heavy / tile_single.
 // =====================================================================================================================
-constexpr int PIPE_BATCH = 40, PIPE_CAP = 512, PIPE_IN = 128;
-constexpr int PIPE_LDS_BYTES = 2 * PIPE_BATCH * (int)sizeof(FaceRec) + 2 * PIPE_CAP * 16 + 64 * 8 + 2 * 64 * 8 + 3 * 64 * 8
-                             + 4 * PIPE_BATCH * 12 + 64 * 4 + PIPE_BATCH * 4 + 2 * PIPE_CAP * 2 + 4 * PIPE_IN * 2;
-static_assert(PIPE_LDS_BYTES <= HEAVY_LDS_BYTES, "the pipelined heavy tile must fit the workgroup's LDS");
+// NW wavefronts per workgroup (tune::fwd_heavy_waves): 4, or 8 - two apply, one stages / lists, five only take tasks; the
+// workgroup's LDS is what NW single-wavefront tiles use, so eight wavefronts also get longer rounds and batches.
+constexpr int PIPE_IN = 128;
+constexpr int pipe_batch(int nw) { return nw >= 8 ? 56 : 40; }
+constexpr int pipe_cap(int nw) { return nw >= 8 ? 1024 : 512; }
+constexpr int pipe_lds_bytes(int nw) {
+    return 2 * pipe_batch(nw) * (int)sizeof(FaceRec) + 2 * pipe_cap(nw) * 16 + 64 * 8 + 2 * 64 * 8 + 3 * 64 * 8
+           + 4 * pipe_batch(nw) * 12 + 64 * 4 + pipe_batch(nw) * 4 + 2 * pipe_cap(nw) * 2 + nw * PIPE_IN * 2;
+}
+constexpr int mixed_lds_bytes(int nw) { return nw * (int)sizeof(FaceRec) * HEAVY_BATCH; }     // = what nw single-wavefront tiles use
+static_assert(pipe_lds_bytes(4) <= mixed_lds_bytes(4) && pipe_lds_bytes(8) <= mixed_lds_bytes(8), "the pipelined heavy tile must fit the workgroup's LDS");
 enum { PS_VALID = 0, PS_BATCH, PS_J0, PS_J1, PS_TOTAL, PS_LAST, PS_MASKS, PS_MBATCH, PS_MFILL, PS_CLAIM, PS_DONE, PS_WORDS = 16 };
 
-template <int DIST, int RGB, int KCAP>
+template <int DIST, int RGB, int KCAP, int NW>
 __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t, int wid, int lane, float4* s_mem,
                                        const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
                                        const unsigned long long* __restrict__ seg, unsigned long long* __restrict__ counters,
                                        float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
-    constexpr int BATCH = PIPE_BATCH, CAP = PIPE_CAP;
+    constexpr int BATCH = pipe_batch(NW), CAP = pipe_cap(NW);
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_mem);                                        // [2][BATCH] by batch parity
     float4* s_cell = reinterpret_cast<float4*>(s_rec + 2 * BATCH);                             // [2][CAP]   by step parity
     float2* s_pix = reinterpret_cast<float2*>(s_cell + 2 * CAP);                               // [64] pixel centres
@@ -1137,7 +1145,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
     __syncthreads();
     const int fill0 = s_state[PS_MFILL];
     if (fill0 > 0) {
-        mask_task(wid, 0, fill0);
+        if (wid < 4) mask_task(wid, 0, fill0);
         __syncthreads();
         if (wid == 3) {
             build_list(0, 0, fill0, 0, s_state);
@@ -1295,12 +1303,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
 }
 
-// Four wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first (k_bin_alloc_schedule) and its
-// first counters[3] bins are HEAVY (list longer than tune::fwd_heavy): a workgroup takes ONE tile of a heavy bin with
-// its four wavefronts together (tile_heavy), or FOUR tiles (one row of tiles) of a lighter bin, one per wavefront
-// (tile_single, each with a quarter of the workgroup's LDS).  Per XCD (workgroup id % 8) the heavy tiles come first.
-template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP, true)))) void k_softras_forward_mixed(
+// NW = four or eight wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first
+// (k_bin_alloc_schedule) and its first counters[3] bins are HEAVY (list longer than tune::fwd_heavy): a workgroup takes
+// ONE tile of a heavy bin with all its wavefronts together (tile_heavy_pipe; tile_heavy with four), or NW tiles of a
+// lighter bin, one per wavefront (tile_single, each with its share of the workgroup's LDS).  Per XCD (workgroup id % 8)
+// the heavy tiles come first.
+template <int DIST, int RGB, int KCAP, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP, true)))) void k_softras_forward_mixed(
     RasterParams p, int nbins, int heavy_cap, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
@@ -1315,7 +1324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
     const bool heavy = k < hx * 16;
     int brank, sub;
     if (heavy) { brank = (k >> 4) * 8 + xcd; sub = k & 15; }
-    else { const int k2 = k - hx * 16; brank = (hx + (k2 >> 2)) * 8 + xcd; sub = (k2 & 3) * 4 + wid; }
+    else { constexpr int WGB = 16 / NW; const int k2 = k - hx * 16; brank = (hx + k2 / WGB) * 8 + xcd; sub = (k2 % WGB) * NW + wid; }   // NW tiles of a lighter bin per workgroup
     if (brank >= nbins) return;
     const int bin = bin_order[brank];
     const int n = bin_count[bin];
@@ -1327,8 +1336,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fwd_waves(K
     if (!tile_geom(p, bin, sub, n, lane, t)) return;     // (a heavy tile: uniform for the workgroup)
     const unsigned long long* seg = pool + bin_base[bin];
     if (heavy) {
-        if (tune::fwd_heavy_pipe) tile_heavy_pipe<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
-        else tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
+        if (tune::fwd_heavy_pipe) tile_heavy_pipe<DIST, RGB, KCAP, NW>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
+        else if (NW == 4) tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
     }
     else tile_single<DIST, RGB, KCAP, HEAVY_BATCH, false>(p, t, lane, s_dyn + wid * (sizeof(FaceRec) * HEAVY_BATCH / sizeof(float4)),
                                              textures, geo, seg, counters, aggrs, rgba, ids);
@@ -1351,9 +1360,19 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
         // upper bound of the heavy bins the device will find: their lists hold more than fwd_heavy_floor() entries each
         const long hcap = (long)(ws.pool_cap / (unsigned long long)fwd_heavy_floor()) + 8;
         const int heavy_cap = (int)(hcap < nbins ? hcap : nbins);
-        const int per_xcd = 16 * ((heavy_cap + 7) / 8) + 4 * ((nbins + 7) / 8);
-        k_softras_forward_mixed<DIST, RGB, KCAP><<<8 * per_xcd, 256, HEAVY_LDS_BYTES, st>>>(
-            p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+        auto launch = [&](auto nw_tag) {
+            constexpr int NW = decltype(nw_tag)::value;
+            const int per_xcd = 16 * ((heavy_cap + 7) / 8) + (16 / NW) * ((nbins + 7) / 8);
+            static const hipError_t lds_opt_in = mixed_lds_bytes(NW) > 65536      // (more than 64 KB of dynamic LDS per workgroup)
+                ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softras_forward_mixed<DIST, RGB, KCAP, NW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, mixed_lds_bytes(NW)) : hipSuccess;
+            (void)lds_opt_in;
+            k_softras_forward_mixed<DIST, RGB, KCAP, NW><<<8 * per_xcd, 64 * NW, mixed_lds_bytes(NW), st>>>(
+                p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+        };
+        // (the sequential heavy tile is written for four wavefronts; eight only where the host's policy asks for them)
+        if (tune::fwd_heavy_pipe && tune::fwd_heavy_waves == 8 && ws.heavy_waves == 8) launch(std::integral_constant<int, 8>());
+        else launch(std::integral_constant<int, 4>());
         return;
     }
     const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot

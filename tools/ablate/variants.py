@@ -59,6 +59,7 @@ VARIANTS = {
     "bwd_k64w4": ["JR_TUNE_BWD_WAVES64=4"],                  # round 3: backward at K = 64 with 4 wavefronts per SIMD (52 B of scratch)
     "no_heavy_pipe": ["JR_TUNE_FWD_HEAVY_PIPE=0"],           # round 3: heavy tiles with the passes in sequence (tile_heavy) instead of the pipeline
     "pipe_ct2": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=2"], "pipe_ct0": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=0"],   # round 3: the K-buffer wavefront / both applying wavefronts take no evaluate tasks
+    "pipe_nw4": ["JR_TUNE_FWD_HEAVY_WAVES=4"],               # round 3: the pipelined heavy tile with four wavefronts per workgroup instead of eight
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
