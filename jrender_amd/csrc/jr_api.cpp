@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <unordered_map>
@@ -202,6 +203,9 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     if (jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8 && ctx->last_heavy >= 0 && ctx->last_B == p.B &&
         ctx->last_NF == p.NF && ctx->last_IS == p.IS && ctx->last_heavy * 16 * 8 <= jr::tune::fwd_heavy_waves8_budget)
         ws.heavy_waves = 8;
+    // JR_FWD_HEAVY_WAVES=4|8 (tests, diagnostics): the workgroup size whatever the policy says
+    static const int forced_waves = getenv("JR_FWD_HEAVY_WAVES") ? atoi(getenv("JR_FWD_HEAVY_WAVES")) : 0;
+    if (jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8 && (forced_waves == 4 || forced_waves == 8)) ws.heavy_waves = forced_waves;
     if (setup_faces(ctx, p, faces, textures, faces_info)) return 1;
     JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));     // k_bin_alloc_schedule has written the totals to h_counters
     auto enqueue = [&](bool again) {
