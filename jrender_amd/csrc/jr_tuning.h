@@ -66,6 +66,15 @@
 #ifndef JR_TUNE_FWD_HEAVY_WAVES8_BUDGET   // eight wavefronts per heavy tile while (heavy tiles of the previous forward) x 8 wavefronts stay below this (the GPU holds 4096 at 16 per CU)
 #define JR_TUNE_FWD_HEAVY_WAVES8_BUDGET 2048
 #endif
+#ifndef JR_TUNE_FWD_PIPE_LIST_DEPTH   // pipelined heavy tile: list chunks requested ahead of the one wavefront 3 is culling (1 = as the other kernels)
+#define JR_TUNE_FWD_PIPE_LIST_DEPTH 2
+#endif
+#ifndef JR_TUNE_FWD_PIPE8_CAP     // pipelined heavy tile with eight wavefronts: cells per round / record slots per batch (four wavefronts: 512 / 40 - what their LDS holds)
+#define JR_TUNE_FWD_PIPE8_CAP 768
+#endif
+#ifndef JR_TUNE_FWD_PIPE8_BATCH
+#define JR_TUNE_FWD_PIPE8_BATCH 64
+#endif
 #ifndef JR_TUNE_FWD_PIPE_CONSUMER_TASKS   // pipelined heavy tile: which applying wavefronts also take evaluate / mask tasks once their apply is done (bit 0: the K-buffer wavefront, bit 1: the colour wavefront)
 #define JR_TUNE_FWD_PIPE_CONSUMER_TASKS 3
 #endif
@@ -122,6 +131,8 @@ constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;
 constexpr bool fwd_heavy_pipe = JR_TUNE_FWD_HEAVY_PIPE != 0;
 constexpr int fwd_pipe_consumer_tasks = JR_TUNE_FWD_PIPE_CONSUMER_TASKS;
 constexpr int fwd_heavy_waves = JR_TUNE_FWD_HEAVY_WAVES;
+constexpr int fwd_pipe8_cap = JR_TUNE_FWD_PIPE8_CAP, fwd_pipe8_batch = JR_TUNE_FWD_PIPE8_BATCH;
+constexpr int fwd_pipe_list_depth = JR_TUNE_FWD_PIPE_LIST_DEPTH;
 constexpr long fwd_heavy_waves8_budget = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET;
 static_assert(fwd_heavy_waves == 4 || fwd_heavy_waves == 8, "JR_TUNE_FWD_HEAVY_WAVES");
 constexpr int bwd_split = JR_TUNE_BWD_SPLIT;

@@ -452,19 +452,31 @@ __device__ inline void store_pixel(const RasterParams& p, const TileGeom& t, con
 // raster only runs on a full batch: its trip count is the MAXIMUM number of faces any pixel
 // needs, and max/mean over 64 lanes shrinks with the batch (measured: 17 survivors per list chunk
 // -> 56 per batch), and the per-batch ballots are paid 4x less often.
-struct ListWalker {
+template <int DEPTH>                   // list chunks in flight ahead of the one in use (1: rounds 1-2; the pipelined heavy tile's lone walker: more)
+struct ListWalkerT {
     const unsigned long long* seg;
     const FaceGeo* gbase;
     const float* tbase;
     int n, sub, s0, cnt, rank;
     bool pending, keep;
     const FaceGeo* gp;
-    unsigned long long e_next;          // the list is read one chunk AHEAD of its use (head of a chain of dependent loads)
+    unsigned long long e_q[DEPTH];      // the list is read DEPTH chunks AHEAD of its use (head of a chain of dependent loads)
 
     __device__ inline void start(const unsigned long long* seg_, const FaceGeo* gbase_, const float* tbase_, int n_, int sub_, int lane) {
         seg = seg_; gbase = gbase_; tbase = tbase_; n = n_; sub = sub_;
         s0 = 0; cnt = 0; rank = 0; pending = false; keep = false; gp = gbase_;
-        e_next = lane < n ? seg[lane] : 0ull;
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) e_q[d] = d * CHUNK + lane < n ? seg[d * CHUNK + lane] : 0ull;
+    }
+    // the next chunk's entry of this lane; the chunk DEPTH ahead is requested
+    __device__ inline unsigned long long next_chunk(int lane) {
+        const unsigned long long e = e_q[0];
+        s0 += CHUNK;
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; d++) e_q[d] = e_q[d + 1];
+        const int at = s0 + (DEPTH - 1) * CHUNK + lane;
+        e_q[DEPTH - 1] = at < n ? seg[at] : 0ull;
+        return e;
     }
     // fills record slots [0, fill) of the next batch; 0 = the list is exhausted
     template <int BATCH>
@@ -472,9 +484,7 @@ struct ListWalker {
         int fill = 0;
         while (pending || s0 < n) {
             if (!pending) {
-                const unsigned long long e = e_next;
-                s0 += CHUNK;
-                e_next = s0 + lane < n ? seg[s0 + lane] : 0ull;
+                const unsigned long long e = next_chunk(lane);
                 // The entry's tile mask is exact per axis (binning.hip: pixel_range), i.e. the face's border box
                 // reaches a pixel column AND a pixel row of this tile: no box load, no second test here.
                 keep = (e >> sub) & 1ull;
@@ -520,9 +530,7 @@ struct ListWalker {
         int fill = 0;
         while (pending || s0 < n) {
             if (!pending) {
-                const unsigned long long e = e_next;
-                s0 += CHUNK;
-                e_next = s0 + lane < n ? seg[s0 + lane] : 0ull;
+                const unsigned long long e = next_chunk(lane);
                 keep = (e >> sub) & 1ull;
                 const unsigned long long surv = ballot(keep);
                 if (!surv) continue;
@@ -552,6 +560,8 @@ struct ListWalker {
         return fill;
     }
 };
+
+using ListWalker = ListWalkerT<1>;
 
 // ---- ballots + pre-cull: lane = slot -> per-pixel masks of the batch's faces ---------------------------------
 // Rows [R0, R1) of the tile: the lanes of those rows get the mask of THEIR pixel (the other lanes' result is
@@ -1043,8 +1053,8 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
 // NW wavefronts per workgroup (tune::fwd_heavy_waves): 4, or 8 - two apply, one stages / lists, five only take tasks; the
 // workgroup's LDS is what NW single-wavefront tiles use, so eight wavefronts also get longer rounds and batches.
 constexpr int PIPE_IN = 128;
-constexpr int pipe_batch(int nw) { return nw >= 8 ? 56 : 40; }
-constexpr int pipe_cap(int nw) { return nw >= 8 ? 1024 : 512; }
+constexpr int pipe_batch(int nw) { return nw >= 8 ? tune::fwd_pipe8_batch : 40; }
+constexpr int pipe_cap(int nw) { return nw >= 8 ? tune::fwd_pipe8_cap : 512; }
 constexpr int pipe_lds_bytes(int nw) {
     return 2 * pipe_batch(nw) * (int)sizeof(FaceRec) + 2 * pipe_cap(nw) * 16 + 64 * 8 + 2 * 64 * 8 + 3 * 64 * 8
            + 4 * pipe_batch(nw) * 12 + 64 * 4 + pipe_batch(nw) * 4 + 2 * pipe_cap(nw) * 2 + nw * PIPE_IN * 2;
@@ -1072,7 +1082,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
     const float xp = t.xp, yp = t.yp;
     const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
     PixelState<KCAP> s;                                  // the K-buffer lives in wavefront 0, the colour state in wavefront 1
-    ListWalker lw;
+    ListWalkerT<tune::fwd_pipe_list_depth> lw;   // wavefront 3 walks alone: several list chunks in flight
     SectionClock clk;            // instrumented builds only (wavefront 0): 0 barrier wait, 3 claimed tasks, 6 apply, 7 stores
     clk.start();
     if (wid == 1) init_colour_state<RGB>(p, s);

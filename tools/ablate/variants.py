@@ -60,6 +60,8 @@ VARIANTS = {
     "no_heavy_pipe": ["JR_TUNE_FWD_HEAVY_PIPE=0"],           # round 3: heavy tiles with the passes in sequence (tile_heavy) instead of the pipeline
     "pipe_ct2": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=2"], "pipe_ct0": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=0"],   # round 3: the K-buffer wavefront / both applying wavefronts take no evaluate tasks
     "pipe_nw4": ["JR_TUNE_FWD_HEAVY_WAVES=4"],               # round 3: the pipelined heavy tile with four wavefronts per workgroup instead of eight
+    "pipe_ld1": ["JR_TUNE_FWD_PIPE_LIST_DEPTH=1"], "pipe_ld4": ["JR_TUNE_FWD_PIPE_LIST_DEPTH=4"],   # round 3: list chunks in flight ahead of wavefront 3's cull (2 in the product)
+    "p8_c512b40": ["JR_TUNE_FWD_PIPE8_CAP=512", "JR_TUNE_FWD_PIPE8_BATCH=40"], "p8_c1024": ["JR_TUNE_FWD_PIPE8_CAP=1024"], "p8_c640": ["JR_TUNE_FWD_PIPE8_CAP=640"], "p8_c896": ["JR_TUNE_FWD_PIPE8_CAP=896"], "p8_b48": ["JR_TUNE_FWD_PIPE8_BATCH=48"], "p8_b56": ["JR_TUNE_FWD_PIPE8_BATCH=56"],   # round 3: round / batch sizes of the eight-wavefront pipeline
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
