@@ -42,3 +42,21 @@ def test_profile_jsons_feed_the_bench_line():
         assert {"busy", "lane_util", "valu_insts_per_launch", "source"} <= set(valu[k])
         assert k in traffic
     assert traffic["bwd_raster"] > 5e8 and n3["fwd"] > 1e8 and n3["bwd"] > 1e9
+
+
+def test_pipelined_heavy_tile_step_machine_model():
+    """tools/sim/heavy_pipe_model.py: wavefront 3's decisions of tile_heavy_pipe (softras_forward.hip) replayed with owner
+    tags on every double / triple buffer: each round evaluated once and applied once, in order, no buffer written
+    while a reader of the same step needs it, and the loop ends - for random batch / round structures including
+    one-round batches (bubbles) and a single batch."""
+    import importlib.util
+    import random
+    spec = importlib.util.spec_from_file_location("heavy_pipe_model", os.path.join(ROOT, "tools", "sim", "heavy_pipe_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = random.Random(3)
+    shapes = [[1], [1, 1, 1], [2, 1], [6, 6, 6, 6], [1, 4, 1, 4]] + [[rng.choice([1, 1, 2, 3, 4, 6]) for _ in range(rng.randint(1, 7))] for _ in range(3000)]
+    for rp in shapes:
+        ev, ap = m.run(rp)
+        want = [(b, r) for b in range(len(rp)) for r in range(rp[b])]
+        assert ev == want and ap == want, rp
