@@ -101,6 +101,9 @@
 #ifndef JR_TUNE_BWD_GROUP         // backward: lanes per work item (face, up to GROUP of its holders): 16 = a DPP row, 8 = half a row (two components per lane after the reduction)
 #define JR_TUNE_BWD_GROUP 16
 #endif
+#ifndef JR_TUNE_BWD_ONE_ATOMIC    // backward: grad_faces and grad_textures components of a flush in one atomic instruction (per-lane selected address)
+#define JR_TUNE_BWD_ONE_ATOMIC 1
+#endif
 #ifndef JR_TUNE_BWD_WAVES64       // backward at 32 < K <= 64: wavefronts per SIMD (3 -> 158 VGPRs; 4 -> 128 with 52 B of scratch)
 #define JR_TUNE_BWD_WAVES64 3
 #endif
@@ -140,6 +143,7 @@ constexpr long fwd_heavy_waves8_budget = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET;
 static_assert(fwd_heavy_waves == 4 || fwd_heavy_waves == 8, "JR_TUNE_FWD_HEAVY_WAVES");
 constexpr int bwd_split = JR_TUNE_BWD_SPLIT;
 constexpr int bwd_group = JR_TUNE_BWD_GROUP;
+constexpr bool bwd_one_atomic = JR_TUNE_BWD_ONE_ATOMIC != 0;
 constexpr long bwd_split_pixels = JR_TUNE_BWD_SPLIT_PIXELS;
 constexpr int fwd_waves32 = JR_TUNE_FWD_WAVES32;
 constexpr int fwd_waves64 = JR_TUNE_FWD_WAVES64;

@@ -413,7 +413,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         float acc = 0.f, acc1 = 0.f;                             // component li (G = 8: 2 li and 2 li + 1) of the group's current face, not yet in memory
         int acc_fn = -1;
         // component c of face fn: 0..8 vertex coordinates (grad_faces), 9..11 the single-texel colour (grad_textures)
+        // tune::bwd_one_atomic: the address is SELECTED per lane, so that the vertex and the colour components of a flush
+        // leave in ONE atomic instruction (an if / else over the two output buffers is two)
         auto add_component = [&](int fn, int c, float val) {
+            if (tune::bwd_one_atomic) {
+                float* at = c < 9 ? gfbase + (size_t)fn * 9 + c : gtbase + (size_t)fn * p.T * 3 + (c - 9);
+                if (val != 0.f && c < 9 + (ntex == 3 ? 3 : 0)) atomicAdd(at, val);
+                return;
+            }
             if (val == 0.f) return;
             if (c < 9) atomicAdd(gfbase + (size_t)fn * 9 + c, val);
             else if (c < 9 + (ntex == 3 ? 3 : 0)) atomicAdd(gtbase + (size_t)fn * p.T * 3 + (c - 9), val);
