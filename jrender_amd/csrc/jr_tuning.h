@@ -85,7 +85,7 @@
 #define JR_TUNE_FWD_PRIO 0
 #endif
 #ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert;
-                                 // backward: bit 2 no three-projection path, bit 3 no n-th-holder search, bit 4 no row reduction, bit 5 no atomics
+                                 // backward: bit 2 no three-projection path, bit 3 no n-th-holder search, bit 4 no row reduction, bit 5 no atomics, bit 7 atomics as plain stores
 #define JR_TUNE_DIAG 0
 #endif
 #ifndef JR_TUNE_BWD_ROW_RANGES   // backward: a row takes a contiguous quarter of the work items and adds up consecutive items of one face before its atomic

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         auto add_component = [&](int fn, int c, float val) {
             if (tune::bwd_one_atomic) {
                 float* at = c < 9 ? gfbase + (size_t)fn * 9 + c : gtbase + (size_t)fn * p.T * 3 + (c - 9);
-                if (val != 0.f && c < 9 + (ntex == 3 ? 3 : 0)) atomicAdd(at, val);
+                if (val != 0.f && c < 9 + (ntex == 3 ? 3 : 0)) { if (JR_TUNE_DIAG & 128) *at = val; else atomicAdd(at, val); }   // (diagnostic bit 7: plain stores - WRONG sums - what does the read-modify-write cost?)
                 return;
             }
             if (val == 0.f) return;

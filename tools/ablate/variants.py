@@ -64,6 +64,7 @@ VARIANTS = {
     "p8_c512b40": ["JR_TUNE_FWD_PIPE8_CAP=512", "JR_TUNE_FWD_PIPE8_BATCH=40"], "p8_c1024": ["JR_TUNE_FWD_PIPE8_CAP=1024"], "p8_c640": ["JR_TUNE_FWD_PIPE8_CAP=640"], "p8_c896": ["JR_TUNE_FWD_PIPE8_CAP=896"], "p8_b48": ["JR_TUNE_FWD_PIPE8_BATCH=48"], "p8_b56": ["JR_TUNE_FWD_PIPE8_BATCH=56"],   # round 3: round / batch sizes of the eight-wavefront pipeline
     "bwd_g8": ["JR_TUNE_BWD_GROUP=8"],                       # round 3, dead: backward work items of up to 8 holders per HALF row (trips -13.5 %, lanes 72 -> 84 %; two atomic instructions per flush: +-0)
     "bwd_two_atomics": ["JR_TUNE_BWD_ONE_ATOMIC=0"],         # round 3: one atomic instruction per output buffer and flush
+    "bdiag_stores": ["JR_TUNE_DIAG=128"],                    # WRONG results: the backward's atomics as plain stores
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
