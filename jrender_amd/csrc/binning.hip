@@ -265,7 +265,10 @@ __global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, co
     for (int t0 = 0; t0 < nbins_total; t0 += 1024) {         // (uniform trip count: the wavefront scans need every lane)
         const int t = t0 + (int)threadIdx.x;
         const int n = t < nbins_total ? bin_count[t] : 0;
-        if (t < nbins_total) atomicAdd(&s_hist[bucket(n)], 1);
+        // (empty bins are the most frequent bucket by far: one LDS atomic per wavefront for them instead of one per lane)
+        const unsigned long long zb = ballot(t < nbins_total && n <= 0);
+        if (t < nbins_total && n > 0) atomicAdd(&s_hist[bucket(n)], 1);
+        if (zb != 0ull && lane == (int)__builtin_ctzll(zb)) atomicAdd(&s_hist[0], (int)__builtin_popcountll(zb));
         int incl = n, mx = n;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -304,8 +307,20 @@ __global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, co
         for (int k = 0; k < 4; k++) { counters[k] = c[k]; host_counters[k] = c[k]; }
         __threadfence_system();
     }
-    for (int t = threadIdx.x; t < nbins_total; t += 1024)
-        bin_order[atomicAdd(&s_start[bucket(bin_count[t])], 1)] = t;
+    for (int t0 = 0; t0 < nbins_total; t0 += 1024) {
+        const int t = t0 + (int)threadIdx.x;
+        const int n = t < nbins_total ? bin_count[t] : 1;
+        const bool empty = t < nbins_total && n <= 0;
+        const unsigned long long zb = ballot(empty);
+        int zbase = 0;
+        if (zb != 0ull) {
+            const int leader = (int)__builtin_ctzll(zb);
+            if (lane == leader) zbase = atomicAdd(&s_start[0], (int)__builtin_popcountll(zb));
+            zbase = __shfl(zbase, leader);
+        }
+        if (empty) bin_order[zbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(zb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)zb, 0u))] = t;
+        else if (t < nbins_total) bin_order[atomicAdd(&s_start[bucket(n)], 1)] = t;
+    }
 }
 
 constexpr int SORT_LDS = 4096;   // 64-bit entries sortable in LDS by one workgroup (32 KB)
