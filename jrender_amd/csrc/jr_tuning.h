@@ -66,6 +66,9 @@
 #ifndef JR_TUNE_FWD_HEAVY_WAVES8_BUDGET   // eight wavefronts per heavy tile while (heavy tiles of the previous forward) x 8 wavefronts stay below this (the GPU holds 4096 at 16 per CU)
 #define JR_TUNE_FWD_HEAVY_WAVES8_BUDGET 2048
 #endif
+#ifndef JR_TUNE_FWD_LIST_DEPTH    // forward, one wavefront per tile (and the sequential heavy tile): list chunks requested ahead of the one being culled
+#define JR_TUNE_FWD_LIST_DEPTH 2
+#endif
 #ifndef JR_TUNE_FWD_PIPE_LIST_DEPTH   // pipelined heavy tile: list chunks requested ahead of the one wavefront 3 is culling (1 = as the other kernels)
 #define JR_TUNE_FWD_PIPE_LIST_DEPTH 2
 #endif
@@ -139,6 +142,7 @@ constexpr int fwd_pipe_consumer_tasks = JR_TUNE_FWD_PIPE_CONSUMER_TASKS;
 constexpr int fwd_heavy_waves = JR_TUNE_FWD_HEAVY_WAVES;
 constexpr int fwd_pipe8_cap = JR_TUNE_FWD_PIPE8_CAP, fwd_pipe8_batch = JR_TUNE_FWD_PIPE8_BATCH;
 constexpr int fwd_pipe_list_depth = JR_TUNE_FWD_PIPE_LIST_DEPTH;
+constexpr int fwd_list_depth = JR_TUNE_FWD_LIST_DEPTH;
 constexpr long fwd_heavy_waves8_budget = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET;
 static_assert(fwd_heavy_waves == 4 || fwd_heavy_waves == 8, "JR_TUNE_FWD_HEAVY_WAVES");
 constexpr int bwd_split = JR_TUNE_BWD_SPLIT;

@@ -561,7 +561,7 @@ struct ListWalkerT {
     }
 };
 
-using ListWalker = ListWalkerT<1>;
+using ListWalker = ListWalkerT<tune::fwd_list_depth>;
 
 // ---- ballots + pre-cull: lane = slot -> per-pixel masks of the batch's faces ---------------------------------
 // Rows [R0, R1) of the tile: the lanes of those rows get the mask of THEIR pixel (the other lanes' result is

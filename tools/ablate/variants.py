@@ -65,6 +65,7 @@ VARIANTS = {
     "bwd_g8": ["JR_TUNE_BWD_GROUP=8"],                       # round 3, dead: backward work items of up to 8 holders per HALF row (trips -13.5 %, lanes 72 -> 84 %; two atomic instructions per flush: +-0)
     "bwd_two_atomics": ["JR_TUNE_BWD_ONE_ATOMIC=0"],         # round 3: one atomic instruction per output buffer and flush
     "bdiag_stores": ["JR_TUNE_DIAG=128"],                    # WRONG results: the backward's atomics as plain stores
+    "fwd_ld1": ["JR_TUNE_FWD_LIST_DEPTH=1"], "fwd_ld3": ["JR_TUNE_FWD_LIST_DEPTH=3"],   # round 3: list chunks in flight ahead of a single-wavefront tile's cull (2 in the product)
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
