@@ -218,8 +218,15 @@ int jr_selftest_reciprocal(jr_ctx* ctx, uint64_t* mismatches);
  * [2]=max faces in a bin, [3]=bins per image */
 int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]);
 /* which paths the last launches took: [0]=1 when the last forward ran the multi-wavefront kernel (launches of up to 4 Mpixels),
- * [1]=bins whose tiles got a whole workgroup each in it, [2]=wavefronts per workgroup (4 or 8; 1 = one wavefront per tile), [3]=0 */
+ * [1]=bins whose tiles got a whole workgroup each in it, [2]=wavefronts per workgroup (4 or 8; 1 = one wavefront per tile),
+ * [3]=the heavy-bin threshold in force (listed faces) */
 int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]);
+/* Launch policy of the multi-wavefront kernels (no counterpart in the reference; results never depend on it, only which
+ * kernel organisation computes them).  heavy_min_faces: a 32x32 bin that lists more faces than this gets a whole
+ * workgroup per tile in forwards of up to 4 Mpixels (and four wavefronts per tile in small backwards); 0 = never,
+ * < 0 = the built-in default (512).  heavy_waves: 4 or 8 wavefronts per such workgroup, 0 = chosen per launch from the
+ * number of heavy tiles.  Environment JR_FWD_HEAVY_MIN / JR_FWD_HEAVY_WAVES set the same two values at jr_ctx_create. */
+int jr_softras_set_launch_policy(jr_ctx* ctx, int heavy_min_faces, int heavy_waves);
 /* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
  * previous call, [0..7] forward raster, [8..15] backward raster; all zero in the product build */
 int jr_debug_section_clocks(jr_ctx* ctx, uint64_t clocks[20]);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "jr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "jr_softras_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "jr_softras_last_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "jr_softras_set_launch_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "jr_debug_section_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "jr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "jr_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -299,7 +300,14 @@ class Context:
         """Which paths the last launches took (jr_softras_last_launch)."""
         s = (C.c_int64 * 4)()
         _check(load().jr_softras_last_launch(self.handle, s))
-        return dict(four_wavefront_kernel=bool(s[0]), heavy_bins=int(s[1]), wavefronts_per_workgroup=int(s[2]))
+        return dict(four_wavefront_kernel=bool(s[0]), heavy_bins=int(s[1]), wavefronts_per_workgroup=int(s[2]),
+                    heavy_min_faces=int(s[3]))
+
+    def set_launch_policy(self, heavy_min_faces=-1, heavy_waves=0):
+        """Which kernel organisation renders heavy tiles (never what they compute): bins listing more than
+        ``heavy_min_faces`` faces get a workgroup of ``heavy_waves`` (4 / 8; 0 = automatic) wavefronts per tile;
+        ``heavy_min_faces`` < 0 restores the default, 0 switches the multi-wavefront tiles off."""
+        _check(load().jr_softras_set_launch_policy(self.handle, int(heavy_min_faces), int(heavy_waves)))
 
     def close(self):
         if self.handle:

@@ -48,15 +48,45 @@ def rendezvous_path():
     st = os.stat(d)
     if st.st_uid != os.getuid() or (st.st_mode & 0o077):
         raise RuntimeError("rendezvous directory %s is not private to this user" % d)
-    run = "".join(ch if ch.isalnum() else "_" for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none"))[:48]
+    import hashlib
+    run = hashlib.sha1(os.fsencode(os.environ.get("TORCHELASTIC_RUN_ID", "none"))).hexdigest()[:12]   # (short: AF_UNIX paths end at 108 bytes)
     return os.path.join(d, "%s_%s_r%s_%d" % (os.environ.get("MASTER_PORT", "0"), run,
                                              os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid()))
 
 
-def _authkey(path):
-    """HostCommunicator connections are authenticated with a key derived from the (private) rendezvous path."""
-    import hashlib
-    return hashlib.sha256(b"jrender_amd.comm:" + os.fsencode(path)).digest()
+def _require_private_parent(path):
+    """The rendezvous files (RCCL id, socket, socket key) of a launch live in ONE directory that only this user can
+    write - whether the prefix came from rendezvous_path() or from the caller."""
+    d = os.path.dirname(os.path.abspath(path)) or "."
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise RuntimeError("rendezvous directory %s must belong to this user and not be group/world writable" % d)
+
+
+def _new_authkey(addr):
+    """Rank 0: a RANDOM key for this launch's HostCommunicator connections (multiprocessing.connection unpickles what it
+    receives, so the key is the only thing between a local user and code execution), published in a 0600 file next
+    to the socket BEFORE the socket exists."""
+    key = os.urandom(32)
+    tmp = "%s.key.tmp%d" % (addr, os.getpid())
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    try:
+        os.write(fd, key)
+    finally:
+        os.close(fd)
+    os.replace(tmp, addr + ".key")
+    return key
+
+
+def _read_authkey(addr, timeout):
+    _wait_for(addr + ".key", timeout)
+    st = os.stat(addr + ".key")
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("rendezvous: %s.key is not private to this user" % addr)
+    key = open(addr + ".key", "rb").read()
+    if len(key) != 32:
+        raise RuntimeError("rendezvous: %s.key holds %d bytes, expected 32" % (addr, len(key)))
+    return key
 
 
 def _wait_for(path, timeout):
@@ -121,6 +151,7 @@ class RcclCommunicator(_Base):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         lib = _ffi.load()
         idfile = (path or rendezvous_path()) + ".id"
+        _require_private_parent(idfile)
         buf = (C.c_char * ID_BYTES)()
         if self.rank == 0:
             _ffi._check(lib.jr_comm_unique_id(buf))
@@ -214,23 +245,36 @@ class HostCommunicator(_Base):
         self._peers, self._hub, self._listener = [], None, None
         if self.world == 1:
             return
+        _require_private_parent(addr)
+        if len(os.fsencode(addr)) > 100:
+            raise RuntimeError("rendezvous path %r is too long for an AF_UNIX socket (108 bytes): set JRENDER_RDZV to a "
+                               "short prefix inside a private directory" % addr)
         if self.rank == 0:
-            if os.path.exists(addr):
-                os.unlink(addr)
-            self._listener = Listener(addr, family="AF_UNIX", authkey=_authkey(addr))
+            for stale in (addr, addr + ".key"):
+                if os.path.exists(stale):
+                    os.unlink(stale)
+            key = _new_authkey(addr)
+            self._listener = Listener(addr, family="AF_UNIX", authkey=key)
+            from multiprocessing import AuthenticationError
             conns = {}
-            for _ in range(self.world - 1):
-                c = self._listener.accept()
+            while len(conns) < self.world - 1:
+                try:
+                    c = self._listener.accept()
+                except AuthenticationError:          # a connection that does not know this launch's key is not a rank
+                    continue
                 conns[c.recv()] = c
             self._peers = [conns[r] for r in range(1, self.world)]
         else:
-            _wait_for(addr, timeout)
+            from multiprocessing import AuthenticationError
+            _wait_for(addr, timeout)                  # (the key file is written before the socket exists)
             t0 = time.time()
             while True:
                 try:
-                    self._hub = Client(addr, family="AF_UNIX", authkey=_authkey(addr))
+                    # (key re-read on every attempt: a path reused by a later launch may still show the previous
+                    #  launch's files for a moment)
+                    self._hub = Client(addr, family="AF_UNIX", authkey=_read_authkey(addr, timeout))
                     break
-                except (ConnectionRefusedError, FileNotFoundError):
+                except (ConnectionRefusedError, FileNotFoundError, AuthenticationError):
                     if time.time() - t0 > timeout:
                         raise
                     time.sleep(0.01)
@@ -283,6 +327,10 @@ class HostCommunicator(_Base):
             self._hub.close()
         if self._listener is not None:
             self._listener.close()
+            try:
+                os.unlink(self._addr + ".key")
+            except OSError:
+                pass
         self._peers, self._hub, self._listener = [], None, None
 
 
@@ -302,6 +350,8 @@ def init_from_env(ctx=None, backend=None):
         backend = "rccl" if (ctx is not None and _ffi.device_count() >= local_world) else "host"
     if backend == "rccl":
         if ctx is None:
+            if world == 1:
+                return SingleCommunicator()
             raise ValueError("the RCCL communicator needs a Context")
         return RcclCommunicator(ctx, rank, world)
     if backend == "host":

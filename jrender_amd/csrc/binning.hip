@@ -385,7 +385,7 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, c
     const int nbins = p.B * p.bins_x * p.bins_y;
     (void)hipMemsetAsync(ws.bin_count, 0, sizeof(int) * (size_t)nbins, st);
     k_face_setup<<<(nfaces + SETUP_WG - 1) / SETUP_WG, SETUP_WG, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_count);
-    k_bin_alloc_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.bin_order, ws.counters, ws.host_counters, heavy_bucket());
+    k_bin_alloc_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.bin_order, ws.counters, ws.host_counters, heavy_bucket(ws.heavy_min));
 }
 
 // Every kernel here is guarded by "total pairs <= pool capacity" read from device memory, so that the

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <unordered_map>
@@ -56,7 +57,14 @@ struct jr_ctx {
     float bins_rad = 0.f;
     int64_t stats[4] = {0, 0, 0, 0};
     int64_t launch_info[4] = {0, 0, 0, 0};  // last forward: multi-wavefront kernel used, heavy bins, wavefronts per workgroup
-    int last_B = 0, last_NF = 0, last_IS = 0; int64_t last_heavy = -1;   // heavy bins the previous forward found (for the next one's workgroup size)
+    // What earlier forwards found, per shape (a small LRU): the number of heavy bins is known on the device only, and the
+    // next forward of the same shape sizes its multi-wavefront launch (workgroup size, heavy-tile workgroups) from it while
+    // the schedule kernel is still running.  A shape that is NOT in here launches its raster kernel after the host has read
+    // this forward's own totals, so that the first call of a shape takes the same path as the second.
+    struct ShapeHist { int B, NF, IS, heavy_min; int64_t heavy; uint64_t stamp; };
+    ShapeHist hist[8] = {};
+    uint64_t hist_clock = 0;
+    int forced_waves = 0;                    // jr_softras_set_launch_policy / JR_FWD_HEAVY_WAVES: 4 or 8 whatever the policy says; 0 = automatic
     unsigned long long* zkey = nullptr;     // n3mr z-buffer keys [B*IS*IS]
     size_t zkey_cap = 0;
     unsigned char* n3_scratch = nullptr;    // n3mr backward: packed per-pixel planes in both orientations
@@ -194,43 +202,55 @@ int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, cons
 int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
                      float* faces_info, float* aggrs_info, float* soft_colors, int32_t* faces_id_buffer) {
     jr::BinWorkspace& ws = ctx->ws;
+    const bool heavy_path = jr::forward_uses_heavy_path(p, ws);
     // Workgroup size of the multi-wavefront kernel.  Eight wavefronts per heavy tile cut a lone view's critical path
     // further (one 39k-face view: 0.33 -> 0.28 ms), but they and the eight light tiles per workgroup cost throughput as
-    // soon as the launch can fill the GPU (two views: 0.33 -> 0.37 ms).  How many heavy tiles a launch has is known on
-    // the device only, so the host uses what the PREVIOUS forward of the same shape found (an optimisation loop renders
-    // the same scene again and again): eight when those tiles' wavefronts fit a fraction of the GPU, else four.
-    ws.heavy_waves = 4;
-    if (jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8 && ctx->last_heavy >= 0 && ctx->last_B == p.B &&
-        ctx->last_NF == p.NF && ctx->last_IS == p.IS && ctx->last_heavy * 16 * 8 <= jr::tune::fwd_heavy_waves8_budget)
-        ws.heavy_waves = 8;
-    // JR_FWD_HEAVY_WAVES=4|8 (tests, diagnostics): the workgroup size whatever the policy says
-    static const int forced_waves = getenv("JR_FWD_HEAVY_WAVES") ? atoi(getenv("JR_FWD_HEAVY_WAVES")) : 0;
-    if (jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8 && (forced_waves == 4 || forced_waves == 8)) ws.heavy_waves = forced_waves;
+    // soon as the launch can fill the GPU (two views: 0.33 -> 0.37 ms): eight when the heavy tiles' wavefronts fit a
+    // fraction of the GPU, else four.  How many heavy tiles a launch has is known on the device only: a shape seen before
+    // is launched speculatively with what it found then (an optimisation loop renders the same scene again and again), a
+    // new shape waits for this forward's own count (the host reads the totals anyway).
+    auto waves_for = [&](int64_t heavy_bins) {
+        if (!(jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8)) return 4;
+        if (ctx->forced_waves == 4 || ctx->forced_waves == 8) return ctx->forced_waves;
+        return heavy_bins * 16 * 8 <= jr::tune::fwd_heavy_waves8_budget ? 8 : 4;
+    };
+    jr_ctx::ShapeHist* hist = nullptr;
+    for (auto& h : ctx->hist)
+        if (h.stamp && h.B == p.B && h.NF == p.NF && h.IS == p.IS && h.heavy_min == ws.heavy_min) hist = &h;
     if (setup_faces(ctx, p, faces, textures, faces_info)) return 1;
     JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));     // k_bin_alloc_schedule has written the totals to h_counters
-    auto enqueue = [&](bool again) {
-        {
-            ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
-            jr::launch_bin_fill_sort(ctx->stream, p, ws, again);
-        }
+    auto enqueue_lists = [&](bool again) {
+        ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
+        jr::launch_bin_fill_sort(ctx->stream, p, ws, again);
+    };
+    auto enqueue_raster = [&](int64_t heavy_bins, bool exact) {
+        ws.heavy_waves = waves_for(heavy_bins);
+        ws.heavy_bound = exact ? (long)heavy_bins : (long)(heavy_bins + heavy_bins / 4 + 16);
         ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
         jr::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
     };
-    const bool speculative = ws.pool != nullptr && ws.pool_cap > 0;
-    if (speculative) enqueue(false);
+    const bool spec_lists = ws.pool != nullptr && ws.pool_cap > 0;
+    const bool spec_raster = spec_lists && (!heavy_path || hist != nullptr);
+    if (spec_lists) enqueue_lists(false);
+    if (spec_raster) enqueue_raster(hist ? hist->heavy : 0, false);
     JR_HIP(hipEventSynchronize(ctx->ev_counters));
     const size_t pairs = (size_t)ctx->h_counters[0];
+    const int64_t heavy_now = (int64_t)ctx->h_counters[3];
     ctx->stats[0] = (int64_t)pairs;
     ctx->stats[1] = (int64_t)ctx->h_counters[1];
     ctx->stats[2] = (int64_t)ctx->h_counters[2];
     ctx->stats[3] = (int64_t)p.bins_x * p.bins_y;
-    ctx->launch_info[0] = jr::forward_uses_heavy_path(p) ? 1 : 0;
-    ctx->launch_info[1] = ctx->launch_info[0] ? (int64_t)ctx->h_counters[3] : 0;
-    ctx->launch_info[2] = ctx->launch_info[0] ? ws.heavy_waves : 1;
-    ctx->last_B = p.B; ctx->last_NF = p.NF; ctx->last_IS = p.IS; ctx->last_heavy = (int64_t)ctx->h_counters[3];
+    if (heavy_path) {                                            // remember what this shape found (least recently used slot)
+        if (!hist) {
+            hist = &ctx->hist[0];
+            for (auto& h : ctx->hist) if (h.stamp < hist->stamp) hist = &h;
+            hist->B = p.B; hist->NF = p.NF; hist->IS = p.IS; hist->heavy_min = ws.heavy_min;
+        }
+        hist->heavy = heavy_now; hist->stamp = ++ctx->hist_clock;
+    }
     if (pairs > 0x7fffffffULL)       // segment bases are 32-bit
         return fail("%zu (bin, face) pairs exceed the 2^31 - 1 the bin lists index: render fewer views per call", pairs);
-    if (!speculative || pairs > ws.pool_cap) {
+    if (!spec_lists || pairs > ws.pool_cap) {
         if (pairs > ws.pool_cap || !ws.pool) {
             JR_HIP(hipStreamSynchronize(ctx->stream));      // nobody may still read the old pool
             size_t c0 = ws.pool_cap, c1 = ws.pool_cap;
@@ -238,8 +258,14 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
             if (grow(ws.pool_scratch, c1, pairs > 0 ? pairs : 1, 1.25)) return 1;
             ws.pool_cap = c0;
         }
-        enqueue(speculative);
-    }
+        enqueue_lists(spec_lists);
+        enqueue_raster(heavy_now, true);
+    } else if (!spec_raster) enqueue_raster(heavy_now, true);
+    ctx->launch_info[0] = heavy_path ? 1 : 0;
+    ctx->launch_info[1] = heavy_path ? std::min<int64_t>(heavy_now, jr::heavy_bins_cap(ws, p.B * p.bins_x * p.bins_y)) : 0;
+    ctx->launch_info[2] = ws.heavy_waves_used;
+    ctx->launch_info[3] = ws.heavy_min;
+    ws.heavy_bound = heavy_now;      // the backward of this forward (token reuse) knows the exact count
     JR_HIP(hipGetLastError());
     return 0;
 }
@@ -268,8 +294,11 @@ int jr_ctx_create(int device, jr_ctx** out) {
     JR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     JR_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * 4, hipHostMallocMapped | hipHostMallocCoherent));
     JR_HIP(hipHostGetDevicePointer((void**)&c->ws.host_counters, c->h_counters, 0));
-    JR_HIP(hipMalloc((void**)&c->ws.counters, sizeof(unsigned long long) * 24));   // [0..3] bin totals, [4..23] section clocks (instrumented builds)
-    JR_HIP(hipMemset(c->ws.counters, 0, sizeof(unsigned long long) * 24));
+    JR_HIP(hipMalloc((void**)&c->ws.counters, sizeof(unsigned long long) * 32));   // [0..3] bin totals (live from a forward to its backward), [4..23] section clocks (instrumented builds), [24..] scratch of the self-tests
+    JR_HIP(hipMemset(c->ws.counters, 0, sizeof(unsigned long long) * 32));
+    // JR_FWD_HEAVY_MIN / JR_FWD_HEAVY_WAVES (tests, diagnostics): initial launch policy, see jr_softras_set_launch_policy
+    if (const char* e = getenv("JR_FWD_HEAVY_MIN")) c->ws.heavy_min = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("JR_FWD_HEAVY_WAVES")) c->forced_waves = (atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0;
     JR_HIP(hipEventCreateWithFlags(&c->ev_counters, hipEventDisableTiming));
     *out = c;
     return 0;
@@ -443,7 +472,10 @@ int jr_softras_backward_ex(jr_ctx* ctx, const float* face_vertices, const float*
     // faces_info write, no lists: the backward finds its faces through the id buffer).
     const bool reuse = forward_token != 0 && forward_token == ctx->geo_epoch && ctx->bins_B == B &&
                        ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad && ctx->bins_T == T;
-    if (!reuse && setup_faces(ctx, p, face_vertices, textures, nullptr)) return 1;
+    if (!reuse) {
+        if (setup_faces(ctx, p, face_vertices, textures, nullptr)) return 1;
+        ctx->ws.heavy_bound = -1;           // nobody read this schedule's totals: the pool-capacity bound
+    }
     {
         ProfScope ps(ctx, JR_PHASE_BWD_RASTER);
         jr::launch_softras_backward(ctx->stream, p, textures, soft_colors, aggrs_info, faces_id_buffer,
@@ -588,24 +620,27 @@ int jr_n3mr_image_backward(jr_ctx* ctx, const float* grad_out_nchw, float* grad_
 int jr_selftest_division(jr_ctx* ctx, uint64_t n, uint32_t seed, uint64_t* mismatches) {
     if (!ctx || !mismatches) return fail("NULL argument");
     JR_HIP(hipSetDevice(ctx->device));
-    JR_HIP(hipMemsetAsync(ctx->ws.counters, 0, sizeof(unsigned long long) * 4, ctx->stream));
-    jr::launch_selftest_div(ctx->stream, n, seed, ctx->ws.counters);
-    JR_HIP(hipMemcpyAsync(ctx->h_counters, ctx->ws.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                          ctx->stream));
+    // (own scratch word: counters[0..3] hold the schedule a token-reusing backward still reads)
+    unsigned long long* scratch = ctx->ws.counters + 24;
+    unsigned long long h = 0;
+    JR_HIP(hipMemsetAsync(scratch, 0, sizeof(unsigned long long), ctx->stream));
+    jr::launch_selftest_div(ctx->stream, n, seed, scratch);
+    JR_HIP(hipMemcpyAsync(&h, scratch, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     JR_HIP(hipStreamSynchronize(ctx->stream));
-    *mismatches = ctx->h_counters[0];
+    *mismatches = h;
     return 0;
 }
 
 int jr_selftest_reciprocal(jr_ctx* ctx, uint64_t* mismatches) {
     if (!ctx || !mismatches) return fail("NULL argument");
     JR_HIP(hipSetDevice(ctx->device));
-    JR_HIP(hipMemsetAsync(ctx->ws.counters, 0, sizeof(unsigned long long) * 4, ctx->stream));
-    jr::launch_selftest_rcp(ctx->stream, ctx->ws.counters);
-    JR_HIP(hipMemcpyAsync(ctx->h_counters, ctx->ws.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                          ctx->stream));
+    unsigned long long* scratch = ctx->ws.counters + 24;
+    unsigned long long h = 0;
+    JR_HIP(hipMemsetAsync(scratch, 0, sizeof(unsigned long long), ctx->stream));
+    jr::launch_selftest_rcp(ctx->stream, scratch);
+    JR_HIP(hipMemcpyAsync(&h, scratch, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     JR_HIP(hipStreamSynchronize(ctx->stream));
-    *mismatches = ctx->h_counters[0];
+    *mismatches = h;
     return 0;
 }
 
@@ -643,6 +678,18 @@ int jr_debug_section_clocks(jr_ctx* ctx, uint64_t clocks[20]) {
 int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]) {
     if (!ctx || !stats) return fail("NULL argument");
     memcpy(stats, ctx->stats, sizeof(ctx->stats));
+    return 0;
+}
+
+int jr_softras_set_launch_policy(jr_ctx* ctx, int heavy_min_faces, int heavy_waves) {
+    if (!ctx) return fail("NULL context");
+    if (heavy_waves != 0 && heavy_waves != 4 && heavy_waves != 8) return fail("jr_softras_set_launch_policy: heavy_waves must be 0 (automatic), 4 or 8");
+    if (heavy_min_faces > (1 << 24)) return fail("jr_softras_set_launch_policy: heavy_min_faces out of range");
+    ctx->ws.heavy_min = heavy_min_faces < 0 ? jr::tune::fwd_heavy : heavy_min_faces;
+    ctx->forced_waves = heavy_waves;
+    ctx->ws.heavy_bound = -1;
+    ctx->geo_epoch++;                        // the schedule in the workspace was built under the old threshold: no backward may reuse it
+    for (auto& h : ctx->hist) h.stamp = 0;
     return 0;
 }
 

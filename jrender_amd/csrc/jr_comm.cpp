@@ -46,6 +46,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -71,6 +73,8 @@ int load_rccl() {
     JR_SYM(GetUniqueId, "ncclGetUniqueId");
     JR_SYM(CommInitRank, "ncclCommInitRank");
     JR_SYM(CommDestroy, "ncclCommDestroy");
+    JR_SYM(CommCount, "ncclCommCount");
+    JR_SYM(CommUserRank, "ncclCommUserRank");
     JR_SYM(AllGather, "ncclAllGather");
     JR_SYM(AllReduce, "ncclAllReduce");
     JR_SYM(Broadcast, "ncclBroadcast");
@@ -134,6 +138,16 @@ int jr_comm_create(jr_ctx* ctx, const void* id_host, int nranks, int rank, jr_co
         return cfail("ncclCommInitRank(rank %d of %d, GPU %d) failed: %s", rank, nranks, jr_ctx_device(ctx),
                      g_rccl.GetErrorString(r));
     }
+    // What RCCL itself says about the communicator must be what the caller asked for: jr_comm_size / jr_comm_rank return
+    // THESE values (bench.py prints the size as `rccl_ranks`, so that a scaling record shows RCCL really saw N ranks).
+    int n_seen = -1, r_seen = -1;
+    if (g_rccl.CommCount(c->comm, &n_seen) != ncclSuccess || g_rccl.CommUserRank(c->comm, &r_seen) != ncclSuccess ||
+        n_seen != nranks || r_seen != rank) {
+        (void)g_rccl.CommDestroy(c->comm);
+        delete c;
+        return cfail("jr_comm_create: RCCL reports rank %d of %d for the communicator created as rank %d of %d", r_seen, n_seen, rank, nranks);
+    }
+    c->nranks = n_seen; c->rank = r_seen;
     // a communicator that cannot get its scratch words is torn down again: the peers must not be left holding a
     // half-created one, and neither the struct nor the live ncclComm may leak
     hipError_t he = hipMalloc((void**)&c->scratch, sizeof(double) * 2);
@@ -159,8 +173,17 @@ int jr_comm_destroy(jr_comm* c) {
     return 0;
 }
 
-int jr_comm_rank(const jr_comm* c) { return c ? c->rank : -1; }
-int jr_comm_size(const jr_comm* c) { return c ? c->nranks : 0; }
+// ncclCommUserRank / ncclCommCount of the live communicator (queried again: not the values stored at creation)
+int jr_comm_rank(const jr_comm* c) {
+    int r = -1;
+    if (!c || !c->comm || g_rccl.CommUserRank(c->comm, &r) != ncclSuccess) return -1;
+    return r;
+}
+int jr_comm_size(const jr_comm* c) {
+    int n = 0;
+    if (!c || !c->comm || g_rccl.CommCount(c->comm, &n) != ncclSuccess) return 0;
+    return n;
+}
 
 int jr_comm_all_gather(jr_comm* c, const void* send, void* recv, size_t bytes_per_rank) {
     if (!c) return cfail("jr_comm_all_gather: NULL communicator");

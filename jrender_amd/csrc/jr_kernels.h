@@ -22,15 +22,31 @@ struct BinWorkspace {
     unsigned long long* pool_scratch = nullptr;// [pool_cap] the same segments as filled (unordered)
     size_t faces_cap = 0, bins_cap = 0, pool_cap = 0;
     int heavy_waves = 4;                        // wavefronts per workgroup of the next forward's four-/eight-wavefront kernel (host policy, jr_api.cpp)
+    // Launch policy of the multi-wavefront kernels (jr_softras_set_launch_policy): bins that list more than heavy_min faces
+    // are HEAVY (a whole workgroup per tile in the forward, bwd_split wavefronts per tile in the backward); 0 = no heavy
+    // tiles.  heavy_bound: upper bound of the heavy bins the NEXT launch can find (what the same shape found before, or
+    // the exact count once the host has read the schedule's totals); < 0 = unknown, the pool-capacity bound is used.
+    int heavy_min = tune::fwd_heavy;
+    long heavy_bound = -1;
+    mutable int heavy_waves_used = 0;          // what the last forward launch really used (8 falls back to 4 when the LDS opt-in is refused)
+    mutable unsigned lds_optin_ok = 0, lds_optin_tried = 0;   // per (dist, rgb, K class) instantiation of the 8-wavefront kernel: > 64 KB of dynamic LDS granted on this device
 };
 
 // Launch order of the bins (k_bin_alloc_schedule): ~12 buckets per octave of the list length, heaviest first.  Bins in
 // buckets >= heavy_bucket() are the "heavy" prefix of the order (counters[3]) that the forward gives four
 // wavefronts per tile; every one of them lists at least fwd_heavy_floor() faces.
-inline int heavy_bucket() { return tune::fwd_heavy > 0 ? 1 + (int)(log2f((float)tune::fwd_heavy) * 12.f) : 1 << 30; }
-inline int fwd_heavy_floor() {
-    const int f = (int)(exp2f((float)(heavy_bucket() - 1) / 12.f) * 0.98f);
+inline int heavy_bucket(int heavy_min) { return heavy_min > 0 ? 1 + (int)(log2f((float)heavy_min) * 12.f) : 1 << 30; }
+inline int fwd_heavy_floor(int heavy_min) {
+    const int f = (int)(exp2f((float)(heavy_bucket(heavy_min) - 1) / 12.f) * 0.98f);
     return f > 1 ? f : 1;
+}
+// upper bound of counters[3] for a launch over nbins bins: every heavy bin holds >= fwd_heavy_floor() of the pool's
+// entries; tightened by what the host knows about this shape (ws.heavy_bound)
+inline int heavy_bins_cap(const BinWorkspace& ws, int nbins) {
+    if (ws.heavy_min <= 0) return 0;
+    long cap = (long)(ws.pool_cap / (unsigned long long)fwd_heavy_floor(ws.heavy_min)) + 8;
+    if (ws.heavy_bound >= 0 && ws.heavy_bound < cap) cap = ws.heavy_bound;
+    return (int)(cap < nbins ? cap : nbins);
 }
 
 void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, const float* textures,
@@ -40,8 +56,8 @@ void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& w
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
                             const BinWorkspace& ws, float* aggrs_info, float* soft_colors,
                             int32_t* faces_id_buffer);
-bool forward_uses_heavy_path(const RasterParams& p);   // launches of up to tune::fwd_heavy_pixels pixels: four wavefronts per tile of a heavy bin
-bool backward_splits_heavy_tiles(const RasterParams& p);   // launches of up to tune::bwd_split_pixels pixels: tune::bwd_split wavefronts per tile of a heavy bin, each with the face ids of one residue class
+bool forward_uses_heavy_path(const RasterParams& p, const BinWorkspace& ws);   // launches of up to tune::fwd_heavy_pixels pixels: four wavefronts per tile of a heavy bin
+bool backward_splits_heavy_tiles(const RasterParams& p, const BinWorkspace& ws);   // launches of up to tune::bwd_split_pixels pixels: tune::bwd_split wavefronts per tile of a heavy bin, each with the face ids of one residue class
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,
                              const float* soft_colors, const float* aggrs_info,
                              const int32_t* faces_id_buffer, const float* grad_soft_colors,

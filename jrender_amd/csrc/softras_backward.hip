@@ -542,11 +542,7 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
                      const float* grad_rgba, float* grad_faces, float* grad_textures) {
     const int nbins = ntiles / (SUBS * SUBS);
     // heavy bins' tiles by tune::bwd_split wavefronts each when the launch is too small to fill the GPU anyway
-    int heavy_cap = 0;
-    if (backward_splits_heavy_tiles(p)) {
-        const long hcap = (long)(ws.pool_cap / (unsigned long long)fwd_heavy_floor()) + 8;   // (bound of counters[3], as in the forward)
-        heavy_cap = (int)(hcap < nbins ? hcap : nbins);
-    }
+    const int heavy_cap = backward_splits_heavy_tiles(p, ws) ? heavy_bins_cap(ws, nbins) : 0;   // (bound of counters[3], as in the forward)
     const int grid = 8 * 16 * (tune::bwd_split * ((heavy_cap + 7) / 8) + (nbins + 7) / 8);   // whole bins (16 tiles) per XCD slot
     const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0);
 #define JR_BWD_K(KC) \
@@ -559,8 +555,8 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
 #undef JR_BWD_K
 }
 
-bool backward_splits_heavy_tiles(const RasterParams& p) {
-    return tune::bwd_split > 1 && tune::fwd_heavy > 0 && (long)p.B * p.IS * p.IS <= (long)tune::bwd_split_pixels;
+bool backward_splits_heavy_tiles(const RasterParams& p, const BinWorkspace& ws) {
+    return tune::bwd_split > 1 && ws.heavy_min > 0 && (long)p.B * p.IS * p.IS <= (long)tune::bwd_split_pixels;
 }
 
 // Both gradient outputs cleared by ONE launch (they are separate caller-owned buffers: two memsets were two launches,

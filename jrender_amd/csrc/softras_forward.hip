@@ -1353,8 +1353,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fwd_wav
                                              textures, geo, seg, counters, aggrs, rgba, ids);
 }
 
-bool forward_uses_heavy_path(const RasterParams& p) {
-    return tune::fwd_heavy > 0 && p.tex == 0 && (long)p.B * p.IS * p.IS <= (long)tune::fwd_heavy_pixels;
+bool forward_uses_heavy_path(const RasterParams& p, const BinWorkspace& ws) {
+    return ws.heavy_min > 0 && p.tex == 0 && (long)p.B * p.IS * p.IS <= (long)tune::fwd_heavy_pixels;
 }
 
 template <int DIST, int RGB, int KCAP>
@@ -1366,25 +1366,37 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
     // waiting wavefronts hold slots that a full GPU has better uses for (eight views: 0.89 -> 0.98 ms even when only the
     // bins above 1024 faces are heavy): the four-wavefront kernel takes launches of up to fwd_heavy_pixels pixels.
     // Heavy tiles need single-texel or per-texel surface colours (the cell has no room for three vertex colours).
-    if (forward_uses_heavy_path(p)) {
-        // upper bound of the heavy bins the device will find: their lists hold more than fwd_heavy_floor() entries each
-        const long hcap = (long)(ws.pool_cap / (unsigned long long)fwd_heavy_floor()) + 8;
-        const int heavy_cap = (int)(hcap < nbins ? hcap : nbins);
+    if (forward_uses_heavy_path(p, ws)) {
+        // upper bound of the heavy bins the device will find (their lists hold more than fwd_heavy_floor() entries each; the
+        // host tightens it with what it knows about the shape): the grid has a workgroup per tile of that many bins
+        const int heavy_cap = heavy_bins_cap(ws, nbins);
         auto launch = [&](auto nw_tag) {
             constexpr int NW = decltype(nw_tag)::value;
             const int per_xcd = 16 * ((heavy_cap + 7) / 8) + (16 / NW) * ((nbins + 7) / 8);
-            static const hipError_t lds_opt_in = mixed_lds_bytes(NW) > 65536      // (more than 64 KB of dynamic LDS per workgroup)
-                ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softras_forward_mixed<DIST, RGB, KCAP, NW>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, mixed_lds_bytes(NW)) : hipSuccess;
-            (void)lds_opt_in;
             k_softras_forward_mixed<DIST, RGB, KCAP, NW><<<8 * per_xcd, 64 * NW, mixed_lds_bytes(NW), st>>>(
                 p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
         };
         // (the sequential heavy tile is written for four wavefronts; eight only where the host's policy asks for them)
-        if (tune::fwd_heavy_pipe && tune::fwd_heavy_waves == 8 && ws.heavy_waves == 8) launch(std::integral_constant<int, 8>());
+        bool eight = tune::fwd_heavy_pipe && tune::fwd_heavy_waves == 8 && ws.heavy_waves == 8;
+        if (eight && mixed_lds_bytes(8) > 65536) {
+            // more than 64 KB of dynamic LDS per workgroup is an opt-in PER DEVICE and per kernel instantiation: asked once
+            // per context (= device) and instantiation; a refusal falls back to four wavefronts instead of a failed launch
+            const unsigned bit = 1u << ((DIST * 3 + RGB) * 3 + (KCAP <= 16 ? 0 : (KCAP <= 32 ? 1 : 2)));
+            if (!(ws.lds_optin_tried & bit)) {
+                ws.lds_optin_tried |= bit;
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softras_forward_mixed<DIST, RGB, KCAP, 8>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, mixed_lds_bytes(8)) == hipSuccess)
+                    ws.lds_optin_ok |= bit;
+                else (void)hipGetLastError();
+            }
+            eight = (ws.lds_optin_ok & bit) != 0;
+        }
+        ws.heavy_waves_used = eight ? 8 : 4;
+        if (eight) launch(std::integral_constant<int, 8>());
         else launch(std::integral_constant<int, 4>());
         return;
     }
+    ws.heavy_waves_used = 1;
     const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
     // JR_FWD_LDS_PAD (bytes, diagnostics only): more dynamic LDS per wavefront = fewer wavefronts per CU
     static const size_t pad = getenv("JR_FWD_LDS_PAD") ? (size_t)atol(getenv("JR_FWD_LDS_PAD")) : 0;
