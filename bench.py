@@ -48,13 +48,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def csrc_hash():
+    """Content hash of the kernel sources the running library was built from (jrender_amd/csrc/*.hip|*.h|*.cpp).  The
+    PMC figures attached to `roofline` (profiles/traffic_latest.json, valu_latest.json) carry the hash of the sources they
+    were collected on (tools/pmc_to_json.py): a mismatch prints `profile_stale: true` instead of passing old counters off
+    as the shipped kernels'.  (A hash of file contents, not a git object: the GPU box has no .git.)"""
+    import hashlib
+    d = os.path.join(ROOT, "jrender_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(B, NF, T, IS, K):
     """compulsory HBM traffic of one fwd+bwd, split per kernel phase."""
     P, F = B * IS * IS, B * NF
     fwd = 4 * (F * (9 + 27 + 3 * T) + P * (4 + 2 + K))           # faces+info+tex in, rgba+aggr+ids out
     bwd = 4 * (P * (4 + 4 + 2 + K) + F * (9 + 27 + 3 * T) + F * (9 + 3 * T))
     setup = 4 * (F * 9 + F * 27)                                  # faces in, faces_info out
-    read = 4 * (P * (4 + 4 + 2 + K) + 2 * F * (9 + 27 + 3 * T))   # what fwd+bwd must READ (north_star's wording)
+    read = 4 * (P * (10 + K) + F * (45 + 6 * T))                  # what fwd+bwd must READ (north_star's wording; SURVEY 8(d): faces_info is produced on chip for the forward)
     return dict(fwd_raster=fwd, bwd_raster=bwd, setup=setup, read=read,
                 step=4 * (P * (16 + 2 * K) + F * (81 + 9 * T)))
 
@@ -97,6 +111,11 @@ def cpu_baseline(NF, K, budget_s=20.0):
         IS *= 2
         t = run(IS)
     ips = 1.0 / (t * (1024.0 / IS) ** 2)
+    if kind == "reference":
+        try:
+            gradient_references(orc, last, cores)
+        except Exception as e:                      # never break the baseline
+            last["gradient_references_error"] = repr(e)
     return {"value": ips, "unit": "images/s", "cores": int(cores), "kind": kind,
             "sample": "1 view of the %d-face sphere at %dx%d fwd+bwd in %.1f s on %d threads, "
                       "scaled by pixel count to 1024x1024" % (NF, IS, IS, t, cores)}, last
@@ -117,6 +136,18 @@ def err_metrics(ours, ref):
             "nonfinite_mismatch": int((np.isfinite(np.asarray(ours, np.float64).ravel()) != fin).sum())}
 
 
+def gradient_references(orc, sample, cores):
+    """What the reference's OWN gradient is good to, measured on the sample view (oracle/_ref only): the float backward on
+    one thread against the same on all cores (order noise of its float atomics, cuda/soft_rasterize.py:1349-1358), both
+    against the exact sum of the same float terms (float atomics shadowed in double), and against the reference's backward
+    kernel instantiated for double (backward_soft_rasterize_cuda_kernel<scalar_t>, cuda/soft_rasterize.py:1177)."""
+    a, g = sample["saved"], sample["g"]
+    gf1, gt1 = orc.backward(a, g, nthreads=1)
+    gfS, gtS = orc.backward_exactsum(a, g, nthreads=cores)
+    gf64, gt64 = orc.backward_f64(a, g, nthreads=cores)
+    sample.update(gf_serial=gf1, gt_serial=gt1, gf_sum=gfS, gt_sum=gtS, gf_f64=gf64, gt_f64=gt64)
+
+
 def parity_vs_sample(ctx, sample, K, mesh_faces, NV):
     """The GPU path on the oracle's view: same inputs, same size, same upstream gradient."""
     from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
@@ -129,7 +160,29 @@ def parity_vs_sample(ctx, sample, K, mesh_faces, NV):
     fb = np.asarray(mesh_faces, np.int64).reshape(1, -1, 3)
     gv = lambda g: face_vertices_backward(np.asarray(g, np.float32).reshape(1, -1, 3, 3), fb, NV)
     covered = a["faces_id_buffer"][:, 0] >= 0
-    return {"view": "oracle view 0 at %dx%d (%s), the whole image" % (IS, IS, "same size as the timed batch" if IS == 1024 else "reduced: CPU budget"),
+    noise = None
+    if "gf_sum" in sample:
+        # gradients against references that carry NO order noise: `exact_sum` = the reference's float per-pair terms summed in
+        # double; `f64` = the reference's kernel in double (differs from its float self wherever a float decision - inside /
+        # outside, clipping - falls the other way: conditioning of the scene, not noise)
+        gfh, gth = gf.numpy(), gt.numpy()
+        well = np.abs(sample["gf_sum"] - sample["gf_f64"]).reshape(-1, 9).max(1) <= 1e-4 * np.abs(sample["gf_f64"]).max()
+        sel = lambda x: np.asarray(x).reshape(-1, 9)[well]
+        noise = {
+            "ref_self_noise": {"grad_faces_serial_vs_all_cores": err_metrics(sample["gf_serial"], sample["grad_faces"]),
+                               "grad_faces_all_cores_vs_exact_sum": err_metrics(sample["grad_faces"], sample["gf_sum"]),
+                               "grad_textures_all_cores_vs_exact_sum": err_metrics(sample["grad_textures"], sample["gt_sum"]),
+                               "vertex_grad_all_cores_vs_exact_sum": err_metrics(gv(sample["grad_faces"]), gv(sample["gf_sum"]))},
+            "vs_exact_sum": {"grad_faces": err_metrics(gfh, sample["gf_sum"]), "grad_textures": err_metrics(gth, sample["gt_sum"]),
+                             "vertex_grad": err_metrics(gv(gfh), gv(sample["gf_sum"]))},
+            "vs_f64": {"reference_f32_grad_faces": err_metrics(sample["gf_sum"], sample["gf_f64"]),
+                       "hip_grad_faces": err_metrics(gfh, sample["gf_f64"]),
+                       "faces_where_f32_and_f64_agree_to_1e-4_of_max": float(well.mean()),
+                       "reference_f32_grad_faces_on_those": err_metrics(sel(sample["gf_sum"]), sel(sample["gf_f64"])),
+                       "hip_grad_faces_on_those": err_metrics(sel(gfh), sel(sample["gf_f64"]))},
+            "what": "exact_sum = the reference's float per-pair gradient terms summed in double (its result without the order noise "
+                    "of the float atomics); f64 = the reference's backward kernel instantiated for double on the same saved tensors"}
+    return {"gradient_references": noise, "view": "oracle view 0 at %dx%d (%s), the whole image" % (IS, IS, "same size as the timed batch" if IS == 1024 else "reduced: CPU budget"),
             "ids_match_frac": float((ids == a["faces_id_buffer"]).all(axis=1).mean()),
             "ids_mismatching_pixels": int((~(ids == a["faces_id_buffer"]).all(axis=1)).sum()),
             "covered_pixel_frac": float(covered.mean()),
@@ -306,6 +359,11 @@ def secondary_lines(args, ctx, comm):
     m = measure_n3mr(ctx, comm, NF, IS, 20, 3)
     out["n3mr"] = {"workload": "NMR rgb+alpha+depth fwd+bwd, %d faces (fill_back x2), %dx%d, batch 1 (BASELINE configs[4])" % (m["NF2"], IS, IS),
                    "ms": percentiles(m["per_step"]), "phase_ms": m["phase_ms_per_step"], "roofline": m["roofline"]}
+    if not args.no_cpu_baseline:
+        try:                                        # the reference's NMR kernels on one host thread (their CUDA form is one thread per face), bounded sample
+            out["n3mr"]["cpu_baseline"] = n3mr_cpu_baseline(m["faces_h"], m["tex_h"], IS, budget_s=8.0)
+        except Exception as e:
+            out["n3mr"]["cpu_baseline"] = {"value": None, "unit": "ms", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     return out
 
 
@@ -372,8 +430,21 @@ def bench_softras(args, ctx, comm, rank, world):
     # HBM bytes and VALU counters of the dominant kernel come from the committed PMC passes of THIS
     # configuration (profiles/traffic_latest.json, profiles/valu_latest.json; tools/collect_profiles.sh)
     profiled = (args.scene, NF, IS, B, K) == ("sphere", 39000, 1024, 8, 16)
-    traffic = (load_json("traffic_latest.json") or {}).get(dom) if profiled else None
-    valu = (load_json("valu_latest.json") or {}).get(dom) if profiled else None
+    tj, vj = load_json("traffic_latest.json") or {}, load_json("valu_latest.json") or {}
+    traffic = tj.get(dom) if profiled else None
+    valu = dict(vj.get(dom) or {}) if profiled and vj.get(dom) else None
+    here = csrc_hash()
+    profile_stale = None
+    if profiled:
+        profile_stale = not (tj.get("csrc_hash") == here and vj.get("csrc_hash") == here)
+    if valu and per_launch[dom] > 0:
+        # issue-slot occupancy against THIS run's launch time (the counters are per launch; the duration is measured live):
+        # VALU wavefront-instructions x the mean issue cost of the kernel's opcode mix / (SIMDs x cycles), see tools/pmc_to_json.py
+        cyc = per_launch[dom] * 1e-3 * valu.get("clock_ghz", 2.4) * 1e9 * valu.get("simds", 1024)
+        raw = valu["valu_insts_per_launch"] * valu.get("mean_issue_cycles", 4.0) / cyc
+        valu["busy_raw"] = raw
+        valu["busy"] = min(1.0, raw)
+        valu["useful_lane_frac"] = valu["busy"] * valu["lane_util"]
     out = {
         "metric": "SoftRas fwd+bwd images/s @1024x1024, 39k faces",
         "value": world * B / (elapsed / args.steps),
@@ -400,20 +471,33 @@ def bench_softras(args, ctx, comm, rank, world):
                                % (args.steps, bracketed_ms),
                      "step_frac": ab["step"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "hbm_read_frac": ab["read"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "valu": valu},
+                     "valu": valu, "profile_stale": profile_stale, "csrc_hash": here,
+                     "profile_csrc_hash": tj.get("csrc_hash") if profiled else None},
         "phase_ms_per_step": {k: v[0] / args.steps for k, v in phases.items()},
         "exchange": {"kind": exchange, "backend": comm.backend, "ms_per_step": percentiles(ex_ms)["median"] if ex_ms else 0.0},
         "tile_stats": ctx.last_stats(),
     }
-    out["rccl_ranks"] = comm.size if comm.backend == "rccl" else None     # what RCCL itself reports (jr_comm_size)
-    if world == 1 and not args.no_secondary:
+    out["rccl_ranks"] = comm.size if comm.backend == "rccl" else None     # ncclCommCount of the live communicator (jr_comm_size)
+    if comm.backend == "rccl" and out["rccl_ranks"] != world:
+        sys.exit("bench.py: RCCL reports %s ranks for a launch of %d" % (out["rccl_ranks"], world))
+    # Everything below is measured by rank 0 on its own GPU AFTER the timed region, at any world size (north_star: latency
+    # and vertex-gradient error "reported at 1/2/4/8 GPUs"); the other ranks have left, so nothing here talks to them.
+    from jrender_amd.comm import SingleCommunicator
+    solo = SingleCommunicator()
+    if not args.no_secondary:
         try:
-            sec = secondary_lines(args, ctx, comm)
-            out["latency_ms_b1"] = sec["b1"]["ms"]["median"]
-            out["secondary"] = sec
+            if world == 1:
+                sec = secondary_lines(args, ctx, solo)
+                out["latency_ms_b1"] = sec["b1"]["ms"]["median"]
+                out["secondary"] = sec
+            else:                                   # N > 1: the single-image latency only (K = 32 / 64, soup, NMR are N = 1 records)
+                fv1, tex1 = syn.sphere_views(NF, 1) if args.scene == "sphere" else syn.triangle_soup(NF, 1, seed=100)
+                st, ph = fwd_bwd_ms(ctx, solo, fv1, tex1, IS, K)
+                out["latency_ms_b1"] = st["median"]
+                out["secondary"] = {"b1": {"workload": "ONE %d-face view %dx%d fwd+bwd, K=%d, on rank 0's GPU" % (NF, IS, IS, K), "ms": st, "phase_ms": ph}}
         except Exception as e:                      # never break the headline line
             out["secondary"] = {"error": repr(e)}
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"], sample = cpu_baseline(NF, K)
             if args.scene == "sphere":
@@ -522,6 +606,9 @@ def main():
                     help="exchange step at the end of every step (default: allreduce_vertex_grads when N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline + parity)")
     ap.add_argument("--no-secondary", action="store_true", help="skip latency_ms_b1 / secondary (K=32, K=64, soup, NMR)")
+    ap.add_argument("--allow-shared-gpus", action="store_true",
+                    help="plumbing runs only: let ranks share GPUs over the host communicator when fewer GPUs than ranks are "
+                         "visible (without it such a launch exits non-zero: an N-rank line must mean N GPUs)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -536,7 +623,11 @@ def main():
     ndev = _ffi.device_count()
     if ndev < 1:
         sys.exit("bench.py: no HIP device visible (there is no CPU fallback)")
-    ctx = _ffi.Context(local_rank % ndev)       # fewer GPUs than ranks: plumbing run, ranks share GPUs (host communicator)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if ndev < local_world and not args.allow_shared_gpus:
+        sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible - an N-rank line must mean N GPUs "
+                 "(--allow-shared-gpus runs the plumbing over the host communicator instead)" % (local_world, ndev))
+    ctx = _ffi.Context(local_rank % ndev)       # --allow-shared-gpus: plumbing run, ranks share GPUs (host communicator)
     comm = jcomm.init_from_env(ctx)
     try:
         if args.workload == "n3mr":

@@ -98,6 +98,12 @@
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
 
+#ifndef JR_TUNE_FWD_EXACT         // forward colour path in the reference's own (slow) arithmetic: bit 0 coverage sigmoid, bit 1 softmax exponential (A/B for tools/grad_parity.py)
+#define JR_TUNE_FWD_EXACT 0
+#endif
+#ifndef JR_TUNE_BWD_EXACT         // backward: bit 0 coverage sigmoid, bit 1 softmax exponential, bit 2 IEEE divisions by ssum / D / (1 - D), bit 3 IEEE divisions by sigma / gamma / (near - far)
+#define JR_TUNE_BWD_EXACT 0
+#endif
 #ifndef JR_TUNE_BWD_BATCH         // backward: faces per batch (LDS record slots per wavefront), <= 64; 40 slots + tables = 7.6 KB -> 20 wavefronts per CU
 #define JR_TUNE_BWD_BATCH 40
 #endif
@@ -130,6 +136,7 @@ namespace jr {
 namespace tune {
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
+constexpr int fwd_exact = JR_TUNE_FWD_EXACT, bwd_exact = JR_TUNE_BWD_EXACT;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;

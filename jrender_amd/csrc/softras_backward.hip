@@ -128,7 +128,7 @@ struct PixelGrad {           // per-pixel inputs of the backward (SRK:1230-1231,
 
 // x / c for gradient-only quantities: reciprocal multiply when the constant is in the safe range
 __device__ inline float gdiv(float x, float c, float rc, const RasterParams& p) {
-    return p.consts_safe ? x * rc : x / c;
+    return (p.consts_safe && !(tune::bwd_exact & 8)) ? x * rc : x / c;
 }
 
 // Contribution of one (pixel, face) pair: gv = d/d(x0 y0 z0 x1 y1 z1 x2 y2 z2); the colour gradient is tgs * upstream
@@ -151,16 +151,17 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     Dist dd;
     dd.sign = 0.f; dd.dx = 0.f; dd.dy = 0.f; dd.t0 = 0.f; dd.t1 = 0.f; dd.t2 = 0.f;
     if (DIST == 0) D = 1.f;                                               // SRK:1258-1270
-    else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_fast(-dis, p); }
+    else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_fast<tune::bwd_exact>(-dis, p); }
     else {
         // nothing is decided from the projection parameter here (sign and region come from the exact w)
         dd = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : TV_IEEE>(r, meta, w, xp, yp);
         dis = dd.dx * dd.dx + dd.dy * dd.dy;
-        D = coverage_fast(-dd.sign * dis, p);
+        D = coverage_fast<tune::bwd_exact>(-dd.sign * dis, p);
     }
     float ca = px.g3;                                                     // SRK:1281-1291
     if (p.alpha == 1) ca /= p.NF;
-    else if (p.alpha == 2) ca = ca * (1 - px.o3) * __builtin_amdgcn_rcpf(fmaxf(1 - D, 1e-6f));
+    else if (p.alpha == 2) ca = (tune::bwd_exact & 4) ? ca * ((1 - px.o3) / fmaxf(1 - D, 1e-6f))
+                                                      : ca * (1 - px.o3) * __builtin_amdgcn_rcpf(fmaxf(1 - D, 1e-6f));
     float cxy = ca;
     const Bary wc = barycentric_clip<FAST>(w);                            // SRK:1294-1296
     const float zp = depth_of<FAST>(r, wc);
@@ -171,7 +172,8 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
         if ((float)fn == px.smax) { tgs = 1.f; tex_on = true; }
     } else if (RGB == 1) {                                                // SRK:1308-1332
         const float zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
-        const float zs = D * exp_over_gamma(zn - px.smax, p) * px.r_ssum;
+        const float zs = (tune::bwd_exact & 4) ? D * exp_over_gamma<tune::bwd_exact>(zn - px.smax, p) / px.ssum
+                                               : D * exp_over_gamma<tune::bwd_exact>(zn - px.smax, p) * px.r_ssum;
         tgs = zs; tex_on = true;
         float k0, k1, k2;
         if (p.tex == 0) {
@@ -190,7 +192,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
         crgb += px.g1 * (k1 - px.o1);
         crgb += px.g2 * (k2 - px.o2);
         crgb *= zs;
-        cxy += crgb * __builtin_amdgcn_rcpf(D);
+        cxy += (tune::bwd_exact & 4) ? crgb / D : crgb * __builtin_amdgcn_rcpf(D);
         const float cz = gdiv(gdiv(crgb, p.gamma, p.r_gamma, p), p.near_minus_far, p.r_near_minus_far, p) * zp * zp;
         gv[2] = cz * wc.w0 * r.rz[0] * r.rz[0];
         gv[5] = cz * wc.w1 * r.rz[1] * r.rz[1];

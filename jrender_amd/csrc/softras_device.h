@@ -406,11 +406,18 @@ __device__ inline float over_sigma(float x, const RasterParams& p) {
 // base are ONE multiply by the precomputed log2(e) / gamma (argument error <= 2 ulp: relative error of the weight
 // 1.2e-7 * |x / gamma|).  zn itself keeps the reference's exact bits (div_known at the call sites): differences of
 // it are divided by gamma, an ulp there would be 6e-4 of the weight.
+// EX (tune::fwd_exact / tune::bwd_exact, bit 1): the reference's own form - IEEE quotient, libm exponential - for the
+// A/B that prices what the approximation costs in gradient parity (tools/grad_parity.py).
+template <int EX = 0>
 __device__ inline float exp_over_gamma(float x, const RasterParams& p) {
+    if (EX & 2) return expf(x / p.gamma);
     return p.consts_safe ? __builtin_amdgcn_exp2f(x * p.rg_log2e) : fast_exp(x / p.gamma);
 }
 // sigmoid coverage 1/(1+exp(neg_num/sigma)) (SRK:338, :344; the reference adds and divides in double)
+// EX bit 0: the reference's own form, (float)(1. / (1. + (double)expf(x / sigma)))
+template <int EX = 0>
 __device__ inline float coverage_fast(float neg_num, const RasterParams& p) {
+    if (EX & 1) return (float)(1.0 / (1.0 + (double)expf(neg_num / p.sigma)));
     const float e = p.consts_safe ? __builtin_amdgcn_exp2f(neg_num * p.rs_log2e) : fast_exp(neg_num / p.sigma);
     return __builtin_amdgcn_rcpf(1.0f + e);
 }

@@ -180,14 +180,14 @@ __device__ inline void softmax_accumulate(const RasterParams& p, const FaceRec& 
         // ONE v_exp of -|zn - smax| and two selects give the same two values, bit for bit
         const float x = zn - s.smax;
         const bool up = x > 0.f;                       // zn > smax (NaN: false, like the reference's compare)
-        const float e = exp_over_gamma(-fabsf(x), p);  // (neg / abs are operand modifiers)
+        const float e = exp_over_gamma<tune::fwd_exact>(-fabsf(x), p);  // (neg / abs are operand modifiers)
         ed = up ? e : 1.f;
         ez = up ? 1.f : e;
         s.smax = fmaxf(s.smax, zn);                    // (a NaN zn leaves smax alone, like the compare)
     } else {
         ed = 1.f;
-        if (zn > s.smax) { ed = exp_over_gamma(s.smax - zn, p); s.smax = zn; }
-        ez = exp_over_gamma(zn - s.smax, p);
+        if (zn > s.smax) { ed = exp_over_gamma<tune::fwd_exact>(s.smax - zn, p); s.smax = zn; }
+        ez = exp_over_gamma<tune::fwd_exact>(zn - s.smax, p);
     }
     float k0, k1, k2;
     sample_colour<FAST>(p, r, vc, tbase, wc, zp, k0, k1, k2);
@@ -248,14 +248,14 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
         const float dis = barycentric_dist(w);
         if (-dis >= p.thr) return false;
         neg_num = -dis;
-        D = coverage_fast(neg_num, p);
+        D = coverage_fast<tune::fwd_exact>(neg_num, p);
     } else if (tune::fwd_defer_inside) {                                       // SRK:340-344
         deferred = strictly_inside_t<FAST>(w);
         if (!deferred) {
             const float dis = euclidean_outside_dis<FAST>(r, meta, w, xp, yp);
             if (dis >= p.thr) return false;
             neg_num = dis;
-            D = coverage_fast(neg_num, p);
+            D = coverage_fast<tune::fwd_exact>(neg_num, p);
         }
     } else {
         float sign, dis;
@@ -267,7 +267,7 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
         }
         if (sign < 0 && dis >= p.thr) return false;
         neg_num = -sign * dis;
-        D = coverage_fast(neg_num, p);
+        D = coverage_fast<tune::fwd_exact>(neg_num, p);
     }
     // alpha aggregation happens before the depth cull (SRK:350-358)
     if (!deferred) alpha_accumulate<DIST, FAST>(p, neg_num, D, s);
@@ -296,7 +296,7 @@ __device__ inline void forward_pair_inside(const RasterParams& p, const FaceRec&
                                            PixelState<KCAP>& s) {
     const Bary w = barycentric(r, xp, yp);
     const float neg_num = -euclidean_inside_dis<FAST>(r, w);
-    const float D = coverage_fast(neg_num, p);
+    const float D = coverage_fast<tune::fwd_exact>(neg_num, p);
     alpha_accumulate<2, FAST>(p, neg_num, D, s);
     if (RGB == 1 && (face_front(r.meta) || p.double_side)) {
         const Bary wc = barycentric_clip<FAST>(w);
@@ -764,7 +764,7 @@ __device__ inline float4 evaluate_pair(const RasterParams& p, const FaceRec& r, 
         const float dis = barycentric_dist(w);
         live = !(-dis >= p.thr);
         neg_num = -dis;
-        D = coverage_fast(neg_num, p);
+        D = coverage_fast<tune::fwd_exact>(neg_num, p);
     } else {                                                                   // SRK:340-344
         deferred = strictly_inside_t<FAST>(w);
         live = true;
@@ -772,7 +772,7 @@ __device__ inline float4 evaluate_pair(const RasterParams& p, const FaceRec& r, 
             const float dis = euclidean_outside_dis<FAST>(r, meta, w, xp, yp);
             live = !(dis >= p.thr);
             neg_num = dis;
-            D = coverage_fast(neg_num, p);
+            D = coverage_fast<tune::fwd_exact>(neg_num, p);
         }
     }
     unsigned aux = slot;
@@ -800,7 +800,7 @@ template <bool FAST>
 __device__ inline float2 evaluate_inside(const RasterParams& p, const FaceRec& r, float xp, float yp, unsigned aux) {
     const Bary w = barycentric(r, xp, yp);
     const float neg_num = -euclidean_inside_dis<FAST>(r, w);
-    const float D = coverage_fast(neg_num, p);
+    const float D = coverage_fast<tune::fwd_exact>(neg_num, p);
     if (p.alpha == 0) {
         const float x = (neg_num == 0.f || in_fast_range(neg_num)) ? div_known<FAST>(neg_num, p.sigma, p.r_sigma) : neg_num / p.sigma;
         if (x < -8.940696716308594e-08f) aux |= CELL_AHARD;
@@ -845,7 +845,7 @@ __device__ inline void apply_colour(const RasterParams& p, const float4 cell, co
                                                             : div_known<false>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
         const float x = zn - s.smax;
         const bool up = x > 0.f;
-        const float e = exp_over_gamma(-fabsf(x), p);
+        const float e = exp_over_gamma<tune::fwd_exact>(-fabsf(x), p);
         const float ed = up ? e : 1.f, ez = up ? 1.f : e;
         s.smax = fmaxf(s.smax, zn);
         const float t = ez * D;

@@ -167,6 +167,52 @@ class Oracle:
             raise RuntimeError("oracle backward failed rc=%d" % rc)
         return gf.reshape(B, NF, 3, 3), gt
 
+    def backward_exactsum(self, saved, grad_soft_colors, nthreads=0):
+        """The reference's FLOAT backward with its float atomics also summed in double (kind='reference' only) ->
+        float64 (grad_faces, grad_textures) = the exact sum of the reference's float per-pair terms: its gradient
+        without the order noise of the float atomics."""
+        if self.kind != "reference":
+            raise ValueError("the shadowed run exists for kind='reference' only")
+        p, s = _scalars({k: v for k, v in saved["params"].items()})
+        fv, tex = saved["face_vertices"], saved["textures"]
+        B, NF, T = fv.shape[0], fv.shape[1], tex.shape[2]
+        IS, K = int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+        g = np.ascontiguousarray(grad_soft_colors, np.float32).reshape(B, 4, IS, IS)
+        gf, gt = np.empty((B, NF, 9), np.float32), np.empty((B, NF, T, 3), np.float32)
+        gf64, gt64 = np.empty((B, NF, 9), np.float64), np.empty((B, NF, T, 3), np.float64)
+        ids = np.ascontiguousarray(saved["faces_id_buffer"].transpose(0, 2, 3, 1))            # SRW:108
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        rc = self.lib.ref_softras_backward_exactsum(
+            _fp(fv), _fp(tex), _fp(saved["soft_colors"]), _fp(saved["faces_info"]), _fp(saved["aggrs_info"]), _ip(ids),
+            _fp(g), _fp(gf), _fp(gt), dp(gf64), dp(gt64), B, NF, T, IS, K, s["near"], s["far"], s["eps"], s["sigma"],
+            s["dist"], s["dist_eps"], s["gamma"], s["rgb"], s["alpha"], s["tex"], s["ds"], int(nthreads))
+        if rc:
+            raise RuntimeError("oracle backward_exactsum failed rc=%d" % rc)
+        return gf64.reshape(B, NF, 3, 3), gt64
+
+    def backward_f64(self, saved, grad_soft_colors, nthreads=0):
+        """The reference's backward kernel instantiated for DOUBLE on the same saved tensors (oracle/ref_driver.cpp:
+        ref_softras_backward_f64; kind='reference' only) -> float64 (grad_faces [B,NF,3,3], grad_textures): the truth
+        that the float instantiation and the HIP kernels are both measured against."""
+        if self.kind != "reference":
+            raise ValueError("the double instantiation exists for kind='reference' only")
+        p, s = _scalars({k: v for k, v in saved["params"].items()})
+        fv, tex = saved["face_vertices"], saved["textures"]
+        B, NF, T = fv.shape[0], fv.shape[1], tex.shape[2]
+        IS, K = int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+        g = np.ascontiguousarray(grad_soft_colors, np.float32).reshape(B, 4, IS, IS)
+        gf = np.empty((B, NF, 9), np.float64)
+        gt = np.empty((B, NF, T, 3), np.float64)
+        ids = np.ascontiguousarray(saved["faces_id_buffer"].transpose(0, 2, 3, 1))            # SRW:108
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        rc = self.lib.ref_softras_backward_f64(
+            _fp(fv), _fp(tex), _fp(saved["soft_colors"]), _fp(saved["faces_info"]), _fp(saved["aggrs_info"]), _ip(ids),
+            _fp(g), dp(gf), dp(gt), B, NF, T, IS, K, s["near"], s["far"], s["eps"], s["sigma"], s["dist"],
+            s["dist_eps"], s["gamma"], s["rgb"], s["alpha"], s["tex"], s["ds"], int(nthreads))
+        if rc:
+            raise RuntimeError("oracle backward_f64 failed rc=%d" % rc)
+        return gf.reshape(B, NF, 3, 3), gt
+
     # ---- pixel-subset variants (port only): full-size parity checks in seconds ----
     def forward_subset(self, face_vertices, textures, pixels, **kw):
         """Oracle outputs for the listed global pixel indices (b*IS*IS + row*IS + col) only.

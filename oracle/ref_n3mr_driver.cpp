@@ -18,6 +18,7 @@
 
 thread_local uint3_shim blockIdx, threadIdx;
 thread_local dim3 blockDim, gridDim;
+atomic_shadow g_atomic_shadow[2] = {{nullptr, 0, nullptr}, {nullptr, 0, nullptr}};   /* unused here (ref_shim) */
 
 static inline int atomicCAS(int32_t* addr, int cmp, int val) {
     int old = *addr;

@@ -53,8 +53,30 @@ static inline double max(double a, float b)  { return fmax(a, (double)b); }
 static inline int    min(int a, int b)       { return a < b ? a : b; }
 static inline int    max(int a, int b)       { return a > b ? a : b; }
 
+/* Optional double-precision SHADOW of up to two float accumulator arrays (ref_softras_backward_exactsum): every
+ * atomicAdd into a registered array is also added, in double, to its shadow.  The shadow is the exact sum (to double
+ * rounding) of the float terms the reference's kernel produces - the reference's result without the order noise of its
+ * float atomics. */
+struct atomic_shadow { float* base; size_t len; double* sum; };
+extern atomic_shadow g_atomic_shadow[2];
 static inline float atomicAdd(float* addr, float v) {
+    for (int i = 0; i < 2; i++) {
+        const atomic_shadow& s = g_atomic_shadow[i];
+        if (s.sum && addr >= s.base && addr < s.base + s.len) {
+            double* d = s.sum + (addr - s.base);
+#pragma omp atomic
+            *d += (double)v;
+        }
+    }
     float old;
+#pragma omp atomic capture
+    { old = *addr; *addr += v; }
+    return old;
+}
+/* the reference's backward kernel is a template over scalar_t: its double instantiation (ref_softras_backward_f64,
+ * the truth both float implementations are measured against) needs the double overload CUDA has since sm_60 */
+static inline double atomicAdd(double* addr, double v) {
+    double old;
 #pragma omp atomic capture
     { old = *addr; *addr += v; }
     return old;

@@ -22,6 +22,7 @@
 
 thread_local uint3_shim blockIdx, threadIdx;
 thread_local dim3 blockDim, gridDim;
+atomic_shadow g_atomic_shadow[2] = {{nullptr, 0, nullptr}, {nullptr, 0, nullptr}};   /* unused here (ref_shim) */
 
 /* fmod / round on float arguments resolve to the <cmath> float overloads, like CUDA's */
 

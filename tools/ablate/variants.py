@@ -67,6 +67,9 @@ VARIANTS = {
     "bdiag_stores": ["JR_TUNE_DIAG=128"],                    # WRONG results: the backward's atomics as plain stores
     "fwd_ld1": ["JR_TUNE_FWD_LIST_DEPTH=1"], "fwd_ld3": ["JR_TUNE_FWD_LIST_DEPTH=3"],   # round 3: list chunks in flight ahead of a single-wavefront tile's cull (2 in the product)
     "w5b40": ["JR_TUNE_FWD_BATCH=40"], "w5b44": ["JR_TUNE_FWD_BATCH=44"], "w4b56h0": ["JR_TUNE_FWD_WAVES16=4", "JR_TUNE_FWD_BATCH=56"],   # round 3, after the list prefetch: batch sizes around the product's 46 slots / 5 wavefronts per SIMD
+    # round 4: what do the colour-path / gradient-only approximations cost in gradient parity (tools/grad_parity.py)?  The reference's own arithmetic instead:
+    "bx1": ["JR_TUNE_BWD_EXACT=1"], "bx2": ["JR_TUNE_BWD_EXACT=2"], "bx4": ["JR_TUNE_BWD_EXACT=4"], "bx8": ["JR_TUNE_BWD_EXACT=8"], "bx15": ["JR_TUNE_BWD_EXACT=15"],
+    "fx1": ["JR_TUNE_FWD_EXACT=1"], "fx2": ["JR_TUNE_FWD_EXACT=2"], "fx3": ["JR_TUNE_FWD_EXACT=3"], "xall": ["JR_TUNE_FWD_EXACT=3", "JR_TUNE_BWD_EXACT=15"],
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
