@@ -5,7 +5,8 @@
 // parity tests on every variant) - except JR_TUNE_BWD_TV_RCP, kept to reproduce the measurement that rules it out.
 // Switches that were measured dead in round 2 (K-buffer ids in LDS, SALU slot masks, tile box test, several tiles
 // per wavefront, refinement quotient for the projection parameter, bank-masked DPP reduction) left the kernels:
-// tools/ablate/patches/dead_switches_r03.patch restores them.
+// tools/ablate/patches/dead_switches_r03.patch restores them; round 3's dead ones (inside pairs in a second loop,
+// s_setprio for heavy bins, 8-lane backward work items): dead_switches_r04.patch.
 #pragma once
 
 #ifndef JR_TUNE_FWD_DIS_ONLY     // forward: carry only (sign, dis) out of the distance machinery
@@ -40,10 +41,6 @@
 #endif
 #ifndef JR_TUNE_FWD_FILL_SHIFT   // forward: K-buffer appends shift the depth registers (KCAP v_mov) instead of writing a per-lane slot (KCAP v_cmp + v_cndmask)
 #define JR_TUNE_FWD_FILL_SHIFT 1
-#endif
-#ifndef JR_TUNE_FWD_DEFER_INSIDE // single-wavefront tiles: inside pairs do their coverage-dependent part (3 edge projections, alpha, softmax) in a second loop per batch
-                                 // (measured r03: VALU instructions -6.7 %, time +2.6 % at B = 8 and +0.6 % at B = 32: off)
-#define JR_TUNE_FWD_DEFER_INSIDE 0
 #endif
 #ifndef JR_TUNE_FWD_EXP1         // forward: one v_exp per softmax update instead of two (the other one is exp(0))
 #define JR_TUNE_FWD_EXP1 1
@@ -84,9 +81,6 @@
 #ifndef JR_TUNE_FWD_HEAVY_PIXELS // forward: launches of up to this many pixels (B x IS x IS) use the four-wavefront kernel, larger ones one wavefront per tile
 #define JR_TUNE_FWD_HEAVY_PIXELS 4194304
 #endif
-#ifndef JR_TUNE_FWD_PRIO         // forward: s_setprio(3) for the wavefronts of bins with more than this many listed faces (0 = off)
-#define JR_TUNE_FWD_PRIO 0
-#endif
 #ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert;
                                  // backward: bit 2 no three-projection path, bit 3 no n-th-holder search, bit 4 no row reduction, bit 5 no atomics, bit 7 atomics as plain stores
 #define JR_TUNE_DIAG 0
@@ -106,9 +100,6 @@
 #endif
 #ifndef JR_TUNE_BWD_BATCH         // backward: faces per batch (LDS record slots per wavefront), <= 64; 40 slots + tables = 7.6 KB -> 20 wavefronts per CU
 #define JR_TUNE_BWD_BATCH 40
-#endif
-#ifndef JR_TUNE_BWD_GROUP         // backward: lanes per work item (face, up to GROUP of its holders): 16 = a DPP row, 8 = half a row (two components per lane after the reduction)
-#define JR_TUNE_BWD_GROUP 16
 #endif
 #ifndef JR_TUNE_BWD_ONE_ATOMIC    // backward: grad_faces and grad_textures components of a flush in one atomic instruction (per-lane selected address)
 #define JR_TUNE_BWD_ONE_ATOMIC 1
@@ -153,7 +144,6 @@ constexpr int fwd_list_depth = JR_TUNE_FWD_LIST_DEPTH;
 constexpr long fwd_heavy_waves8_budget = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET;
 static_assert(fwd_heavy_waves == 4 || fwd_heavy_waves == 8, "JR_TUNE_FWD_HEAVY_WAVES");
 constexpr int bwd_split = JR_TUNE_BWD_SPLIT;
-constexpr int bwd_group = JR_TUNE_BWD_GROUP;
 constexpr bool bwd_one_atomic = JR_TUNE_BWD_ONE_ATOMIC != 0;
 constexpr long bwd_split_pixels = JR_TUNE_BWD_SPLIT_PIXELS;
 constexpr int fwd_waves32 = JR_TUNE_FWD_WAVES32;
@@ -162,9 +152,7 @@ constexpr long fwd_heavy_pixels = JR_TUNE_FWD_HEAVY_PIXELS;
 constexpr bool fwd_ids_global = JR_TUNE_FWD_IDS_GLOBAL != 0;
 constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
 constexpr bool fwd_empty_bins = JR_TUNE_FWD_EMPTY_BINS != 0;
-constexpr bool fwd_defer_inside = JR_TUNE_FWD_DEFER_INSIDE != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
-constexpr int fwd_prio = JR_TUNE_FWD_PRIO;
 constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY;
 constexpr bool fwd_heavy_defer_copy = JR_TUNE_FWD_HEAVY_DEFER_COPY != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;

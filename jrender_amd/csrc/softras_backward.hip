@@ -53,19 +53,6 @@ __device__ inline float row_transpose_reduce(const float (&v)[16], int li) {
     return (h1 ? c[1] : c[0]) + dpp_f<0xB1>(h1 ? c[0] : c[1]);
 }
 
-// The same over the 8 lanes of a HALF row (tune::bwd_group = 8): the first exchange is left out and the last one too, so
-// lane i of the half row ends up with the totals of v[2i] and v[2i + 1] (12 components live in lanes 0..5).
-__device__ inline void half_row_transpose_reduce(const float (&v)[16], int li, float& s0, float& s1) {
-    float a[8], b[4];
-    const bool h4 = li & 4, h2 = li & 2, h1 = li & 1;
-#pragma unroll
-    for (int j = 0; j < 8; j++) a[j] = (h4 ? v[j + 8] : v[j]) + dpp_f<0x141>(h4 ? v[j] : v[j + 8]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) b[j] = (h2 ? a[j + 4] : a[j]) + dpp_f<0x1B>(h2 ? a[j] : a[j + 4]);
-    s0 = (h1 ? b[2] : b[0]) + dpp_f<0xB1>(h1 ? b[0] : b[2]);
-    s1 = (h1 ? b[3] : b[1]) + dpp_f<0xB1>(h1 ? b[1] : b[3]);
-}
-
 // smallest value over the wavefront, uniform (all lanes active)
 __device__ inline int wave_min(int v) {
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -267,14 +254,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
     if (col0 >= p.IS || row0 >= p.IS) return;
 
-    // Work items are (face, up to G of its holders) and G lanes take one: G = 16 (a DPP row; rounds 1-3) or 8 (half a row).
-    // With 8 a face with few holders in the tile wastes fewer lanes: on the headline scene 32 % of the (tile, face) pairs have
-    // <= 8 holders, the trips of a tile fall by 13.5 % and the lanes in use from 72 % to 84 % (replay of the oracle's index
-    // buffer); the price is two components per lane after the reduction = two atomic instructions per flush, and twice as
-    // many groups that look up their items - measured +-0 on the sphere (0.788 against 0.786 ms), +2.4 % on the triangle
-    // soup: 16 stays (gpurun call 40; parity of the 8-lane form green, 102 tests).
-    constexpr int G = tune::bwd_group, NG = 64 / G, GSH = G == 16 ? 4 : 3;
-    static_assert(G == 16 || G == 8, "JR_TUNE_BWD_GROUP");
+    // Work items are (face, up to 16 of its holders) and the 16 lanes of a DPP row take one.  (Half rows of 8 were built and
+    // measured: trips -13.5 %, lanes in use 72 -> 84 %, time +-0 / +2.4 % - two components per lane after the reduction are
+    // two atomic instructions per flush; tools/ablate/patches/dead_switches_r04.patch.)
+    constexpr int G = 16, NG = 64 / G, GSH = 4;
     const int lane = threadIdx.x, li = lane & (G - 1), blk = lane >> GSH;
     const int col = col0 + (lane & 7), row = row0 + (lane >> 3);
     const bool valid = col < p.IS && row < p.IS;
@@ -412,7 +395,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             nth = (item0 - s_ioff[j]) * G + li;
             hs = s_has[j];
         }
-        float acc = 0.f, acc1 = 0.f;                             // component li (G = 8: 2 li and 2 li + 1) of the group's current face, not yet in memory
+        float acc = 0.f;                                         // component li of the row's current face, not yet in memory
         int acc_fn = -1;
         // component c of face fn: 0..8 vertex coordinates (grad_faces), 9..11 the single-texel colour (grad_textures)
         // tune::bwd_one_atomic: the address is SELECTED per lane, so that the vertex and the colour components of a flush
@@ -428,10 +411,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             else if (c < 9 + (ntex == 3 ? 3 : 0)) atomicAdd(gtbase + (size_t)fn * p.T * 3 + (c - 9), val);
         };
         auto flush = [&]() {
-            if (acc_fn >= 0) {
-                if (G == 16) add_component(acc_fn, li, acc);
-                else { add_component(acc_fn, 2 * li, acc); add_component(acc_fn, 2 * li + 1, acc1); }
-            }
+            if (acc_fn >= 0) add_component(acc_fn, li, acc);
         };
         const int ntrips = RANGES ? per_row : (nitems + NG - 1) / NG;
         for (int trip = 0; trip < ntrips; trip++) {
@@ -497,19 +477,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                     hs = s_has[j];
                 }
             }
-            float s = 0.f, s1 = 0.f;                             // G = 16: lane li holds component li summed over the row; G = 8: 2 li and 2 li + 1
-            if (JR_TUNE_DIAG & 16) { s = v[li & 15]; s1 = v[(li + 1) & 15]; }     // (diagnostic bit 4: no reduction)
-            else if (G == 16) s = row_transpose_reduce(v, li);
-            else half_row_transpose_reduce(v, li, s, s1);
+            float s;                                             // lane li holds component li summed over the row
+            if (JR_TUNE_DIAG & 16) s = v[li & 15];               // (diagnostic bit 4: no reduction)
+            else s = row_transpose_reduce(v, li);
             if (RANGES) {
                 if (ractc) {                                     // SRK:1349-1358 does one atomic per pixel and component
-                    if (fn != acc_fn) { if (!(JR_TUNE_DIAG & 32)) flush(); acc = s; acc1 = s1; acc_fn = fn; }
-                    else { acc += s; acc1 += s1; }
+                    if (fn != acc_fn) { if (!(JR_TUNE_DIAG & 32)) flush(); acc = s; acc_fn = fn; }
+                    else acc += s;
                 }
-            } else if (!(JR_TUNE_DIAG & 32) && ractc) {          // (diagnostic bit 5: no atomics)
-                if (G == 16) add_component(fn, li, s);
-                else { add_component(fn, 2 * li, s); add_component(fn, 2 * li + 1, s1); }
-            }
+            } else if (!(JR_TUNE_DIAG & 32) && ractc) add_component(fn, li, s);   // (diagnostic bit 5: no atomics)
             if (ntex == 9) {                                     // vertex colours: 9 more components
                 float u[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -519,15 +495,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                     u[3 * jv + 2] = tw * (wcw[jv] * q.g2);
                 }
                 float* gtf = gtbase + (size_t)fn * p.T * 3;
-                if (G == 16) {
-                    const float st = row_transpose_reduce(u, li);
-                    if (ractc && li < 9 && st != 0.f) atomicAdd(gtf + li, st);
-                } else {
-                    float t0, t1;
-                    half_row_transpose_reduce(u, li, t0, t1);
-                    if (ractc && 2 * li < 9 && t0 != 0.f) atomicAdd(gtf + 2 * li, t0);
-                    if (ractc && 2 * li + 1 < 9 && t1 != 0.f) atomicAdd(gtf + 2 * li + 1, t1);
-                }
+                const float st = row_transpose_reduce(u, li);
+                if (ractc && li < 9 && st != 0.f) atomicAdd(gtf + li, st);
             }
             clk.lap(5);
         }

@@ -365,7 +365,7 @@ __device__ inline void euclidean_sign_dis(const FaceGeo& r, int meta, const Bary
     }
 }
 
-// The two halves of euclidean_sign_dis for callers that know the class of the pair (tune::fwd_defer_inside):
+// The two halves of euclidean_sign_dis for callers that know the class of the pair (the heavy tile's evaluate passes):
 // an OUTSIDE pixel's squared distance (SRK:107-146; sign = -1), decided from exactly ...
 template <bool FAST>
 __device__ inline float euclidean_outside_dis(const FaceGeo& r, int meta, const Bary& b, float xp, float yp) {

@@ -226,38 +226,24 @@ __device__ inline void alpha_accumulate(const RasterParams& p, float neg_num, fl
     }
 }
 
-// One (pixel, face) pair of the raster loop.  Returns true when the pair was DEFERRED (tune::fwd_defer_inside,
-// euclidean distance only): the pixel lies strictly inside the face.  Such a pair is never culled by distance and its
-// coverage needs three edge projections instead of one; 8 % of the pairs are inside, but with 64 lanes on 64
-// different faces nearly every trip of the loop had one, so the whole wavefront paid the 60 extra instructions
-// at 8 % lane use.  Everything that is ORDER dependent (depth cull, K-buffer insert, 'hard' rgb) does not
-// depend on the coverage and happens here, in face order; what depends on it — the alpha product and the softmax
-// sums — commutes (1e-4 colour path) and is added by forward_pair_inside in a second loop over the batch's
-// deferred pairs, where all active lanes are inside.
+// One (pixel, face) pair of the raster loop (SRK:316-419).  (Handling the pairs whose pixel lies strictly inside the face -
+// three edge projections instead of one, 8 % of the pairs but present in nearly every trip - in a second loop per batch
+// was built and measured: VALU instructions -6.7 %, time +2.6 %; tools/ablate/patches/dead_switches_r04.patch.)
 template <int DIST, int RGB, bool FAST, int KCAP>
-__device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
+__device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
                                     const float* __restrict__ tbase, float xp, float yp,
                                     PixelState<KCAP>& s) {
     const Bary w = barycentric(r, xp, yp);
     const int meta = r.meta;
     float D = 1.f, neg_num = -1.f;
-    bool deferred = false;
     if (DIST == 0) {                                                           // SRK:331-333
-        if (!pixel_inside(w)) return false;
+        if (!pixel_inside(w)) return;
     } else if (DIST == 1) {                                                    // SRK:335-338
         const float dis = barycentric_dist(w);
-        if (-dis >= p.thr) return false;
+        if (-dis >= p.thr) return;
         neg_num = -dis;
         D = coverage_fast<tune::fwd_exact>(neg_num, p);
-    } else if (tune::fwd_defer_inside) {                                       // SRK:340-344
-        deferred = strictly_inside_t<FAST>(w);
-        if (!deferred) {
-            const float dis = euclidean_outside_dis<FAST>(r, meta, w, xp, yp);
-            if (dis >= p.thr) return false;
-            neg_num = dis;
-            D = coverage_fast<tune::fwd_exact>(neg_num, p);
-        }
-    } else {
+    } else {                                                                   // SRK:340-344
         float sign, dis;
         if (tune::fwd_dis_only) euclidean_sign_dis<FAST>(r, meta, w, xp, yp, sign, dis);
         else {
@@ -265,16 +251,16 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
             sign = dd.sign;
             dis = dd.dx * dd.dx + dd.dy * dd.dy;
         }
-        if (sign < 0 && dis >= p.thr) return false;
+        if (sign < 0 && dis >= p.thr) return;
         neg_num = -sign * dis;
         D = coverage_fast<tune::fwd_exact>(neg_num, p);
     }
     // alpha aggregation happens before the depth cull (SRK:350-358)
-    if (!deferred) alpha_accumulate<DIST, FAST>(p, neg_num, D, s);
+    alpha_accumulate<DIST, FAST>(p, neg_num, D, s);
 
     const Bary wc = barycentric_clip<FAST>(w);
     const float zp = depth_of<FAST>(r, wc);
-    if (zp < p.near_ || zp > p.far_) return deferred;                         // SRK:365
+    if (zp < p.near_ || zp > p.far_) return;                                  // SRK:365
     const int fn = face_id(meta);
     s.q.insert(fn, zp, p.K);
 
@@ -284,25 +270,7 @@ __device__ inline bool forward_pair(const RasterParams& p, const FaceRec& r, con
             sample_colour<FAST>(p, r, vc, tbase, wc, zp, s.c0, s.c1, s.c2);
         }
     } else if (RGB == 1) {                                                     // SRK:399-419
-        if (!deferred && (face_front(meta) || p.double_side)) softmax_accumulate<FAST>(p, r, vc, tbase, wc, zp, D, s);
-    }
-    return deferred;
-}
-
-// The coverage-dependent part of a deferred inside pair: three edge projections -> coverage -> alpha, softmax.
-template <int RGB, bool FAST, int KCAP>
-__device__ inline void forward_pair_inside(const RasterParams& p, const FaceRec& r, const float* vc,
-                                           const float* __restrict__ tbase, float xp, float yp,
-                                           PixelState<KCAP>& s) {
-    const Bary w = barycentric(r, xp, yp);
-    const float neg_num = -euclidean_inside_dis<FAST>(r, w);
-    const float D = coverage_fast<tune::fwd_exact>(neg_num, p);
-    alpha_accumulate<2, FAST>(p, neg_num, D, s);
-    if (RGB == 1 && (face_front(r.meta) || p.double_side)) {
-        const Bary wc = barycentric_clip<FAST>(w);
-        const float zp = depth_of<FAST>(r, wc);
-        if (zp < p.near_ || zp > p.far_) return;                              // SRK:365
-        softmax_accumulate<FAST>(p, r, vc, tbase, wc, zp, D, s);
+        if (face_front(meta) || p.double_side) softmax_accumulate<FAST>(p, r, vc, tbase, wc, zp, D, s);
     }
 }
 
@@ -683,31 +651,13 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
         unsigned long long M = pixel_masks<DIST, 0, 8>(p, s_rec, fill, lane, xp, yp);   // the faces that pass this pixel's border test (and pre-cull)
         if (!t.valid) M = 0ull;
         clk.lap(2);
-        unsigned long long Mdef = 0ull;        // this pixel's deferred (inside) pairs of the batch
         while (M) {
             const int j = __builtin_ctzll(M);
-            const unsigned long long rest = M & (M - 1);
+            M &= M - 1;
             const FaceRec& r = s_rec[j];
             const float* vc = s_vcol + j * 9;
-            bool deferred;
-            if (face_safe(r.meta) && p.consts_safe)
-                deferred = forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
-            else
-                deferred = forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
-            if (DIST == 2 && tune::fwd_defer_inside && deferred) Mdef |= M ^ rest;
-            M = rest;
-        }
-        if (DIST == 2 && tune::fwd_defer_inside) {
-            while (Mdef) {
-                const int j = __builtin_ctzll(Mdef);
-                Mdef &= Mdef - 1;
-                const FaceRec& r = s_rec[j];
-                const float* vc = s_vcol + j * 9;
-                if (face_safe(r.meta) && p.consts_safe)
-                    forward_pair_inside<RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
-                else
-                    forward_pair_inside<RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
-            }
+            if (face_safe(r.meta) && p.consts_safe) forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
+            else forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
         }
         wave_sync<WAVE_IS_WG>();                // readers are done with s_rec before it is refilled
         clk.lap(3);
@@ -1302,8 +1252,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     if (brank * 16 >= ntiles_total) return;
     const int bin = bin_order[brank];                    // ... heaviest first (k_bin_alloc_schedule)
     const int n = bin_count[bin];
-    // tune::fwd_prio: issue priority for the wavefronts of the heaviest bins (measured: no effect)
-    if (tune::fwd_prio > 0 && n > tune::fwd_prio) __builtin_amdgcn_s_setprio(3);
     if (tune::fwd_empty_bins && n == 0 && (p.IS & (BIN - 1)) == 0) {    // empty bin: tile 0's wavefront writes all 16 tiles
         if ((k & 15) == 0) store_empty_bin<RGB, KCAP>(p, bin, threadIdx.x, aggrs, rgba, ids);
         return;

@@ -31,11 +31,9 @@ VARIANTS = {
     "ids_regs": ["JR_TUNE_FWD_IDS_GLOBAL=0"],                # K-buffer ids in registers (round-2 start)
     "no_shift": ["JR_TUNE_FWD_FILL_SHIFT=0"],                # round 3: K-buffer appends by per-lane slot select instead of the register shift
     "no_exp1": ["JR_TUNE_FWD_EXP1=0"],                       # round 3: two v_exp per softmax update
-    "defer": ["JR_TUNE_FWD_DEFER_INSIDE=1"],                 # round 3, dead: inside pairs of single-wavefront tiles in a second loop per batch
     "h128": ["JR_TUNE_FWD_HEAVY=128"], "h256": ["JR_TUNE_FWD_HEAVY=256"], "h384": ["JR_TUNE_FWD_HEAVY=384"],
     "h64": ["JR_TUNE_FWD_HEAVY=64"], "h768": ["JR_TUNE_FWD_HEAVY=768"], "h1024": ["JR_TUNE_FWD_HEAVY=1024"],
     "h1024all": ["JR_TUNE_FWD_HEAVY=1024", "JR_TUNE_FWD_HEAVY_PIXELS=1000000000"],
-    "prio256": ["JR_TUNE_FWD_PRIO=256", "JR_TUNE_FWD_HEAVY=0"],     # dead: s_setprio(3) for the wavefronts of heavy bins (no effect)
     "diag_nosoftmax": ["JR_TUNE_DIAG=1", "JR_TUNE_FWD_HEAVY=0"],   # WRONG results: cost probes of the single-wavefront path
     "diag_nokbuf": ["JR_TUNE_DIAG=2", "JR_TUNE_FWD_HEAVY=0"],
     "diag_neither": ["JR_TUNE_DIAG=3", "JR_TUNE_FWD_HEAVY=0"],
@@ -62,7 +60,6 @@ VARIANTS = {
     "pipe_nw4": ["JR_TUNE_FWD_HEAVY_WAVES=4"],               # round 3: the pipelined heavy tile with four wavefronts per workgroup instead of eight
     "pipe_ld1": ["JR_TUNE_FWD_PIPE_LIST_DEPTH=1"], "pipe_ld4": ["JR_TUNE_FWD_PIPE_LIST_DEPTH=4"],   # round 3: list chunks in flight ahead of wavefront 3's cull (2 in the product)
     "p8_c512b40": ["JR_TUNE_FWD_PIPE8_CAP=512", "JR_TUNE_FWD_PIPE8_BATCH=40"], "p8_c1024": ["JR_TUNE_FWD_PIPE8_CAP=1024"], "p8_c640": ["JR_TUNE_FWD_PIPE8_CAP=640"], "p8_c896": ["JR_TUNE_FWD_PIPE8_CAP=896"], "p8_b48": ["JR_TUNE_FWD_PIPE8_BATCH=48"], "p8_b56": ["JR_TUNE_FWD_PIPE8_BATCH=56"],   # round 3: round / batch sizes of the eight-wavefront pipeline
-    "bwd_g8": ["JR_TUNE_BWD_GROUP=8"],                       # round 3, dead: backward work items of up to 8 holders per HALF row (trips -13.5 %, lanes 72 -> 84 %; two atomic instructions per flush: +-0)
     "bwd_two_atomics": ["JR_TUNE_BWD_ONE_ATOMIC=0"],         # round 3: one atomic instruction per output buffer and flush
     "bdiag_stores": ["JR_TUNE_DIAG=128"],                    # WRONG results: the backward's atomics as plain stores
     "fwd_ld1": ["JR_TUNE_FWD_LIST_DEPTH=1"], "fwd_ld3": ["JR_TUNE_FWD_LIST_DEPTH=3"],   # round 3: list chunks in flight ahead of a single-wavefront tile's cull (2 in the product)
