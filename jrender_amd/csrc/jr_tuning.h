@@ -119,6 +119,16 @@
 #endif
 
 
+#ifndef JR_TUNE_N3_PIXMAP_ALL     // NMR backward: all six (edge, axis) passes of a face in the lanes at once, out-walks four at a time (0: one pass after the other, one out-walk at a time)
+#define JR_TUNE_N3_PIXMAP_ALL 1
+#endif
+
+#ifndef JR_TUNE_N3_PIXMAP_WAVES   // NMR pixel-map gradient: wavefronts per SIMD asked of the register allocator
+#define JR_TUNE_N3_PIXMAP_WAVES 4
+#endif
+#ifndef JR_TUNE_N3_XCD_GROUP      // NMR backward: runs of this many consecutive workgroups (4 faces each) go to one XCD (0: round-robin, the hardware's order)
+#define JR_TUNE_N3_XCD_GROUP 32
+#endif
 #ifndef JR_TUNE_PROFILE_SECTIONS  // instrumented build: per-section shader-clock totals of the raster kernels (tools/ablate)
 #define JR_TUNE_PROFILE_SECTIONS 0
 #endif
@@ -126,6 +136,8 @@
 namespace jr {
 namespace tune {
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
+constexpr bool n3_pixmap_all = JR_TUNE_N3_PIXMAP_ALL != 0;
+constexpr int n3_xcd_group = JR_TUNE_N3_XCD_GROUP;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr int fwd_exact = JR_TUNE_FWD_EXACT, bwd_exact = JR_TUNE_BWD_EXACT;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_n3mr_pack(
     N3Params p, const int32_t* __restrict__ face_index_map, const float* __restrict__ rgb_map,
     const float* __restrict__ alpha_map, const float* __restrict__ grad_rgb_map,
     const float* __restrict__ grad_alpha_map, float4* __restrict__ sg, float* __restrict__ gb,
-    float4* __restrict__ sg_t, float* __restrict__ gb_t, int32_t* __restrict__ fidx_t) {
+    float4* __restrict__ sg_t, float* __restrict__ gb_t, int32_t* __restrict__ fidx_r, int32_t* __restrict__ fidx_t) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long pp = (long)p.IS * p.IS;
     if (i >= p.B * pp) return;
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void k_n3mr_pack(
     const long bn = i / pp, r = i - bn * pp;
     const int y = (int)(r / p.IS), x = (int)(r - (long)y * p.IS);
     const long it = bn * pp + (long)x * p.IS + y;
-    sg_t[it] = v; gb_t[it] = g[2]; fidx_t[it] = face_index_map[i];
+    const int32_t fi = face_index_map[i];
+    sg_t[it] = v; gb_t[it] = g[2]; fidx_r[i] = fi; fidx_t[it] = fi;
 }
 
 struct N3Ref { float a, c0, c1, c2; };       // the reference pixel of a walk (alpha, r, g, b)
@@ -364,6 +365,208 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_pixel_map(
     }
 }
 
+// ---- round 4: the same gradient with ALL SIX (edge, axis) passes of a face in the lanes at once --------------------------
+// k_n3mr_backward_pixel_map above runs the six (edge, axis) passes of a face one after the other: each sets up with
+// 5 of 64 lanes busy (a face of the 39k-face sphere spans ~5 scan positions per edge), does its short "in" walks, and
+// then takes its out-walks ONE scan line at a time - a chain of dependent load round trips (2 - 8 per walk) that only
+// other wavefronts can hide: ~7 000 wavefront-instructions per face, VALU 57 % busy, the rest waiting.  Here
+//   * lane = (edge, axis, scan position) over all six passes: one set-up, one round of "in" walks (loads issued
+//     unconditionally at clamped addresses so that they overlap), ~30 lanes busy instead of 5;
+//   * the out-walks of the whole face form ONE list and are taken FOUR at a time: the four lines' loads of a walk step
+//     are independent and issued together (4x the memory-level parallelism per wavefront), their parameters are
+//     wave-uniform (v_readlane from the scan lane that owns the line);
+//   * planes: [0] row-major, [1] column-major copies of (S, g_alpha, g_r, g_g | g_b | face index) in ONE buffer each, so
+//     that "the orientation in which this walk is contiguous" is an index offset, not a pointer select.
+// Same arithmetic per visited pixel (n3_diff / n3_push); only the order of the float sums differs.
+__device__ inline float n3_wave_sum(float v) {            // all lanes active; result uniform
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+    return (n3_bcast(v, 0) + n3_bcast(v, 16)) + (n3_bcast(v, 32) + n3_bcast(v, 48));
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JR_TUNE_N3_PIXMAP_WAVES))) void k_n3mr_backward_pixel_map_all(
+    N3Params p, const float* __restrict__ faces, const int32_t* __restrict__ face_index_map,
+    const float* __restrict__ rgb_map, const float* __restrict__ alpha_map,
+    const float4* __restrict__ sg2, const float* __restrict__ gb2, const int32_t* __restrict__ fidx2,
+    float* __restrict__ grad_faces) {
+    // XCD-aware order (tune::n3_xcd_group = G): workgroup ids go round-robin to the 8 XCDs, so with faces in launch order
+    // every XCD walks rows and columns all over the image and its 4 MB L2 keeps missing.  Neighbouring faces of a mesh walk
+    // the same rows / columns: runs of G consecutive workgroups (4 G faces) go to ONE XCD.  (One contiguous eighth of the
+    // faces per XCD is 1.8x SLOWER: with fill_back half of the face array is back-facing and four XCDs get nothing to do.)
+    int wg = (int)blockIdx.x;
+    if (tune::n3_xcd_group > 0) {
+        constexpr int G = tune::n3_xcd_group > 0 ? tune::n3_xcd_group : 1;
+        const int xcd = wg & 7, k = wg >> 3;                 // k-th workgroup of its XCD
+        wg = ((k / G) * 8 + xcd) * G + (k % G);              // (beyond the last face: those wavefronts exit)
+    }
+    const int wave = (wg * (int)blockDim.x + (int)threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= p.B * p.NF) return;
+    const int bn = wave / p.NF, fn = wave - bn * p.NF;
+    const int is = p.IS;
+    const float* face = faces + (size_t)wave * 9;
+    if ((face[7] - face[1]) * (face[3] - face[0]) < (face[4] - face[1]) * (face[6] - face[0])) return;
+    const size_t P = (size_t)p.B * is * is, mbase = (size_t)bn * is * is;
+    const float two_over_is = 2.f / is;
+    const bool use_rgb = p.return_rgb, use_a = p.return_alpha;
+    float pp_[3][2];                                        // vertices in pixel coordinates (N3K:381-386)
+#pragma unroll
+    for (int n = 0; n < 3; n++)
+#pragma unroll
+        for (int d = 0; d < 2; d++) pp_[n][d] = 0.5f * (face[3 * n + d] * is + is - 1);
+    // scan ranges of the six passes, c = 2 * edge + axis (N3K:413-414)
+    int first[6], off[7];
+    off[0] = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const int e = c >> 1, ax = c & 1, e1 = (e + 1) % 3;
+        const float a = pp_[e][ax], b = pp_[e1][ax];
+        const int d0_from = (int)fmax((double)ceilf(fminf(a, b)), 0.);
+        const int d0_to = (int)fmin((double)fmaxf(a, b), is - 1.);
+        first[c] = d0_from;
+        off[c + 1] = off[c] + max(d0_to - d0_from + 1, 0);
+    }
+    const int total = off[6];
+    float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add_uniform = [&](int k, float v) {                // k is wave-uniform
+        switch (k) {
+            case 0: g[0] += v; break; case 1: g[1] += v; break; case 2: g[2] += v; break;
+            case 3: g[3] += v; break; case 4: g[4] += v; break; case 5: g[5] += v; break;
+            case 6: g[6] += v; break; case 7: g[7] += v; break; default: g[8] += v; break;
+        }
+    };
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        // ---- lane = (pass, scan position) ----
+        const int t = t0 + lane;
+        const bool have = t < total;
+        int c = 0;
+#pragma unroll
+        for (int k = 1; k < 6; k++) c += t >= off[k] ? 1 : 0;
+        if (!have) c = 0;
+        int cfirst = first[0], coff = off[0];
+#pragma unroll
+        for (int k = 1; k < 6; k++) { cfirst = c == k ? first[k] : cfirst; coff = c == k ? off[k] : coff; }
+        const int d0 = have ? cfirst + (t - coff) : 0;
+        const int edge = c >> 1, axis = c & 1;
+        const int pi0 = edge, pi1 = edge == 2 ? 0 : edge + 1, pi2 = edge == 0 ? 2 : edge - 1;
+        auto coord = [&](int v, int d) {                    // pp_[v][d] for per-lane v, d
+            const float x = v == 0 ? pp_[0][0] : (v == 1 ? pp_[1][0] : pp_[2][0]);
+            const float y = v == 0 ? pp_[0][1] : (v == 1 ? pp_[1][1] : pp_[2][1]);
+            return d == 0 ? x : y;
+        };
+        // the edge's two vertices and the opposite one, walking axis second (N3K:398-405)
+        const float q00 = coord(pi0, axis), q01 = coord(pi0, 1 - axis), q10 = coord(pi1, axis), q11 = coord(pi1, 1 - axis),
+                    q20 = coord(pi2, axis), q21 = coord(pi2, 1 - axis);
+        const int direction = axis == 0 ? (q00 < q10 ? -1 : 1) : (q00 < q10 ? 1 : -1);         // N3K:407-411
+        const float e10 = q10 - q00;
+        const float slope = (q11 - q01) / e10;
+        const float s20 = (q21 - q01) / (q20 - q00), s12 = (q11 - q21) / (q10 - q20);
+        const float d1_cross = slope * (d0 - q00) + q01;
+        const int d1_in = 0 < direction ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+        const int d1_out = d1_in + direction;
+        const bool ok = have && !(d1_in < 0 || is <= d1_in) && !(d1_out < 0 || is <= d1_out);
+        const bool ha = q10 != d0, hb = q00 != d0;
+        const float ta = e10 / (q10 - d0), tb = e10 / (d0 - q00);
+        N3Ref rin = {0.f, 0.f, 0.f, 0.f}, rout = {0.f, 0.f, 0.f, 0.f};
+        int fin = -1, from = 1, to = 0;
+        if (ok) {
+            const size_t idx_in = mbase + (axis == 0 ? (size_t)d1_in * is + d0 : (size_t)d0 * is + d1_in);
+            const size_t idx_out = mbase + (axis == 0 ? (size_t)d1_out * is + d0 : (size_t)d0 * is + d1_out);
+            fin = face_index_map[idx_in];
+            if (use_a) { rin.a = alpha_map[idx_in]; rout.a = alpha_map[idx_out]; }
+            if (use_rgb) {
+                rin.c0 = rgb_map[idx_in * 3]; rin.c1 = rgb_map[idx_in * 3 + 1]; rin.c2 = rgb_map[idx_in * 3 + 2];
+                rout.c0 = rgb_map[idx_out * 3]; rout.c1 = rgb_map[idx_out * 3 + 1]; rout.c2 = rgb_map[idx_out * 3 + 2];
+            }
+            const float cross2 = ((d0 - q00) * (d0 - q20) < 0) ? s20 * (d0 - q00) + q01 : s12 * (d0 - q20) + q21;
+            const int d1_limit = 0 < direction ? (int)ceilf(cross2) : (int)floorf(cross2);    // N3K:520-528
+            from = max(min(d1_in, d1_limit), 0);
+            to = min(max(d1_in, d1_limit), is - 1);
+        }
+        float acc_a = 0.f, acc_b = 0.f;
+        const int ia = pi0 * 3 + (1 - axis), ib = pi1 * 3 + (1 - axis);     // the two vertices of this lane's edge, coordinate 1 - axis (N3K:496-505)
+        // ---- "in" walks: every lane walks its own scan line, in the orientation in which neighbouring scan positions
+        //      are contiguous (plane `axis`) ----
+        const size_t in_base = (size_t)axis * P + mbase + (size_t)d0;
+        for (int k = 0; ballot(from + k <= to) != 0ull; k++) {
+            const int d1 = from + k;
+            const bool act = d1 <= to;
+            const size_t m = in_base + (size_t)(act ? d1 : from) * is;      // (from is 1 for idle lanes: a valid element)
+            const int fm = fidx2[m];
+            const float4 v = sg2[m];
+            const float gv = gb2[m];
+            if (!act || fm != fn) continue;
+            const float diff = n3_diff(v, gv, rout);
+            if (diff <= 0) continue;
+            n3_push(diff, d1, d1_cross, ta, tb, ha, hb, two_over_is, p.eps, acc_a, acc_b);
+        }
+        // ---- "out" walks (N3K:470-507): the lines of all six passes, four at a time, the pixel walk spread over the lanes ----
+        unsigned long long vis = ballot(ok && fin == fn);
+        const unsigned long long ha_m = ballot(ha), hb_m = ballot(hb);
+        while (vis) {
+            int s[4], len[4], wf[4], ia_u[4], ib_u[4];
+            size_t base[4];
+            float cross[4], bta[4], btb[4];
+            N3Ref r[4];
+            bool bha[4], bhb[4];
+            int maxlen = -1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool valid = vis != 0ull;
+                s[u] = valid ? __builtin_ctzll(vis) : s[0];
+                vis &= vis - 1;                              // (0 stays 0)
+                const int bd0 = __builtin_amdgcn_readlane(d0, s[u]), bax = __builtin_amdgcn_readlane(axis, s[u]);
+                const int bdir = __builtin_amdgcn_readlane(direction, s[u]), b_out = __builtin_amdgcn_readlane(d1_out, s[u]);
+                ia_u[u] = __builtin_amdgcn_readlane(ia, s[u]); ib_u[u] = __builtin_amdgcn_readlane(ib, s[u]);
+                cross[u] = n3_bcast(d1_cross, s[u]); bta[u] = n3_bcast(ta, s[u]); btb[u] = n3_bcast(tb, s[u]);
+                bha[u] = (ha_m >> s[u]) & 1ull; bhb[u] = (hb_m >> s[u]) & 1ull;
+                r[u] = {n3_bcast(rin.a, s[u]), n3_bcast(rin.c0, s[u]), n3_bcast(rin.c1, s[u]), n3_bcast(rin.c2, s[u])};
+                const int d1_limit = 0 < bdir ? is - 1 : 0;
+                wf[u] = max(min(b_out, d1_limit), 0);
+                const int wt = min(max(b_out, d1_limit), is - 1);
+                len[u] = valid ? wt - wf[u] : -1;
+                maxlen = max(maxlen, len[u]);
+                base[u] = (size_t)(1 - bax) * P + mbase + (size_t)bd0 * is + wf[u];   // the orientation in which this walk is contiguous
+            }
+            float pa[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int o = lane; o <= maxlen; o += 64) {
+                float4 v[4];
+                float gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {                // eight independent loads in flight
+                    const size_t m = base[u] + (size_t)min(o, max(len[u], 0));
+                    v[u] = sg2[m];
+                    gv[u] = gb2[m];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (o > len[u]) continue;
+                    const float diff = n3_diff(v[u], gv[u], r[u]);
+                    if (diff <= 0) continue;
+                    n3_push(diff, wf[u] + o, cross[u], bta[u], btb[u], bha[u], bhb[u], two_over_is, p.eps, pa[u], pb[u]);
+                }
+            }
+            // the walk's per-lane partial sums go straight into the face's nine per-lane accumulators: which two of them is
+            // wave-uniform (the pass of the scan lane that owns the line), so this is a scalar branch, not a reduction
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (len[u] < 0) continue;                    // uniform
+                add_uniform(ia_u[u], pa[u]);
+                add_uniform(ib_u[u], pb[u]);
+            }
+        }
+        // ---- this lane's own ("in" walk) sums ----
+#pragma unroll
+        for (int k = 0; k < 9; k++) g[k] += (have && ia == k ? acc_a : 0.f) + (have && ib == k ? acc_b : 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const float v = n3_wave_sum(g[k]);
+        if (lane == 0) grad_faces[(size_t)wave * 9 + k] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_n3mr_backward_textures(
     N3Params p, const int32_t* __restrict__ face_index_map, const float* __restrict__ sampling_weight_map,
     const int32_t* __restrict__ sampling_index_map, const float* __restrict__ grad_rgb_map,
@@ -432,6 +635,9 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
     const int is = p.IS, ts = p.TS, ntex = p.return_rgb ? ts * ts * ts * 3 : 0;
     float* acc = s_tex[wl];
     for (int k = lane; k < ntex; k += 64) acc[k] = 0.f;
+    float treg[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) treg[k] = 0.f;
     const float* f = faces + (size_t)wave * 9;
     float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool front = !((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]));   // N3K:63
@@ -470,12 +676,40 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
             }
             if (p.return_rgb) {                                                            // N3K:685-692
                 const float g0 = grad_rgb_map[3 * i], g1 = grad_rgb_map[3 * i + 1], g2 = grad_rgb_map[3 * i + 2];
+                const float4* wq = reinterpret_cast<const float4*>(sampling_weight_map + 8 * i);
+                const int4* iq = reinterpret_cast<const int4*>(sampling_index_map + 8 * i);
+                const float4 w0 = wq[0], w1 = wq[1];
+                const int4 i0 = iq[0], i1 = iq[1];
+                const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                const int ix[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+                // texture_size 2: every pixel samples the cube's eight corners, corner pn -> texel bitreverse3(pn) (N3K:275-284
+                // with (int)t = 0).  ds_add_f32 retires about one lane per clock, so 24 LDS atomics per pixel were this
+                // kernel's time; the corners are summed in 24 registers per lane instead and reduced once per face.  Any other
+                // index (larger cubes; a coordinate clamped to exactly ts - 1 when eps = 0) takes the LDS atomics.
+                bool corner = ts == 2;
 #pragma unroll
-                for (int pn = 0; pn < 8; pn++) {
-                    const float w = sampling_weight_map[8 * i + pn];
-                    float* t = acc + sampling_index_map[8 * i + pn] * 3;
-                    atomicAdd(t, w * g0); atomicAdd(t + 1, w * g1); atomicAdd(t + 2, w * g2);
+                for (int pn = 0; pn < 8; pn++) corner = corner && ix[pn] == (((pn & 1) << 2) | (pn & 2) | ((pn >> 2) & 1));
+                if (corner) {
+#pragma unroll
+                    for (int pn = 0; pn < 8; pn++) {
+                        const int tx = (((pn & 1) << 2) | (pn & 2) | ((pn >> 2) & 1)) * 3;
+                        treg[tx] += w[pn] * g0; treg[tx + 1] += w[pn] * g1; treg[tx + 2] += w[pn] * g2;
+                    }
+                } else {
+#pragma unroll
+                    for (int pn = 0; pn < 8; pn++) {
+                        float* t = acc + ix[pn] * 3;
+                        atomicAdd(t, w[pn] * g0); atomicAdd(t + 1, w[pn] * g1); atomicAdd(t + 2, w[pn] * g2);
+                    }
                 }
+            }
+        }
+        if (p.return_rgb && ts == 2) {                       // (uniform) the register sums join the LDS accumulators
+            __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+            for (int k = 0; k < 24; k++) {
+                const float v = n3_wave_sum(treg[k]);
+                if (lane == 0) acc[k] += v;
             }
         }
     }
@@ -519,7 +753,7 @@ void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textur
                                                                sampling_index_map, sampling_weight_map);
 }
 
-size_t n3mr_backward_scratch_bytes(int B, int IS) { return (size_t)B * IS * IS * (2 * 16 + 2 * 4 + 4); }
+size_t n3mr_backward_scratch_bytes(int B, int IS) { return (size_t)B * IS * IS * (2 * 16 + 2 * 4 + 2 * 4); }
 
 void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* face_index_map,
                           const float* weight_map, const float* depth_map, const float* face_inv_map,
@@ -531,17 +765,24 @@ void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* fac
     const long P = (long)B * IS * IS, waves = (long)B * NF;
     (void)hipMemsetAsync(grad_faces, 0, sizeof(float) * (size_t)B * NF * 9, st);
     if (rrgb || ralpha) {
-        // scratch (n3mr_backward_scratch_bytes): [sg | sg_t] float4, [gb | gb_t] float, fidx_t int32
+        // scratch (n3mr_backward_scratch_bytes): [sg | sg_t] float4, [gb | gb_t] float, [fidx | fidx_t] int32 - row-major | column-major
         float4* sg = static_cast<float4*>(scratch);
         float4* sg_t = sg + P;
         float* gb = reinterpret_cast<float*>(sg_t + P);
         float* gb_t = gb + P;
-        int32_t* fidx_t = reinterpret_cast<int32_t*>(gb_t + P);
+        int32_t* fidx_r = reinterpret_cast<int32_t*>(gb_t + P);
+        int32_t* fidx_t = fidx_r + P;
         k_n3mr_pack<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(p, face_index_map, rgb_map, alpha_map, grad_rgb_map,
-                                                                grad_alpha_map, sg, gb, sg_t, gb_t, fidx_t);
-        const N3Planes rowmajor = {sg, gb, face_index_map}, colmajor = {sg_t, gb_t, fidx_t};
-        k_n3mr_backward_pixel_map<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(
-            p, faces, face_index_map, rgb_map, alpha_map, rowmajor, colmajor, grad_faces);
+                                                                grad_alpha_map, sg, gb, sg_t, gb_t, fidx_r, fidx_t);
+        if (tune::n3_pixmap_all) {
+            constexpr long GG = 8 * (tune::n3_xcd_group > 0 ? tune::n3_xcd_group : 1);        // whole runs for every XCD
+            k_n3mr_backward_pixel_map_all<<<(unsigned)(((waves * 64 + 255) / 256 + GG - 1) / GG * GG), 256, 0, st>>>(
+                p, faces, face_index_map, rgb_map, alpha_map, sg, gb, fidx_r, grad_faces);
+        } else {
+            const N3Planes rowmajor = {sg, gb, face_index_map}, colmajor = {sg_t, gb_t, fidx_t};
+            k_n3mr_backward_pixel_map<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(
+                p, faces, face_index_map, rgb_map, alpha_map, rowmajor, colmajor, grad_faces);
+        }
     }
     if (!rrgb && !rdepth) return;
     if (!rrgb || (size_t)TS * TS * TS * 3 <= (size_t)N3_TEX_LDS) {

@@ -421,10 +421,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
             const bool act = nth < __builtin_popcountll(hs);
             const int src = (JR_TUNE_DIAG & 8) ? lane : (act ? select_bit(hs, nth) : lane);    // the pixel (lane) this pair belongs to (diagnostic bit 3: no search)
             PixelGrad q;
+            if (JR_TUNE_DIAG & 256) q = px;              // (diagnostic bit 8, WRONG results: what do the 13 ds_bpermute gathers cost?)
+            else {
             q.g0 = gather(px.g0, src); q.g1 = gather(px.g1, src); q.g2 = gather(px.g2, src); q.g3 = gather(px.g3, src);
             q.o0 = gather(px.o0, src); q.o1 = gather(px.o1, src); q.o2 = gather(px.o2, src); q.o3 = gather(px.o3, src);
             q.ssum = gather(px.ssum, src); q.smax = gather(px.smax, src); q.r_ssum = gather(px.r_ssum, src);
-            const float qx = gather(xp, src), qy = gather(yp, src);
+            }
+            const float qx = (JR_TUNE_DIAG & 256) ? xp : gather(xp, src), qy = (JR_TUNE_DIAG & 256) ? yp : gather(yp, src);
             if (tune::profile_sections) { __builtin_amdgcn_s_waitcnt(0); clk.lap(3); }
             const FaceRec& fr = s_rec[jc];
             float v[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -67,6 +67,10 @@ VARIANTS = {
     # round 4: what do the colour-path / gradient-only approximations cost in gradient parity (tools/grad_parity.py)?  The reference's own arithmetic instead:
     "bx1": ["JR_TUNE_BWD_EXACT=1"], "bx2": ["JR_TUNE_BWD_EXACT=2"], "bx4": ["JR_TUNE_BWD_EXACT=4"], "bx8": ["JR_TUNE_BWD_EXACT=8"], "bx15": ["JR_TUNE_BWD_EXACT=15"],
     "fx1": ["JR_TUNE_FWD_EXACT=1"], "fx2": ["JR_TUNE_FWD_EXACT=2"], "fx3": ["JR_TUNE_FWD_EXACT=3"], "xall": ["JR_TUNE_FWD_EXACT=3", "JR_TUNE_BWD_EXACT=15"],
+    "n3_seq": ["JR_TUNE_N3_PIXMAP_ALL=0"],                  # round 4: NMR pixel-map gradient one (edge, axis) pass and one out-walk at a time (rounds 1-3)
+    "bdiag_nogather": ["JR_TUNE_DIAG=256"], "bdiag_nogather_nosearch": ["JR_TUNE_DIAG=264"],   # WRONG results: the backward without its 13 ds_bpermute gathers (and without the n-th-holder search)
+    "n3_rr": ["JR_TUNE_N3_XCD_GROUP=0"], "n3_g8": ["JR_TUNE_N3_XCD_GROUP=8"], "n3_g128": ["JR_TUNE_N3_XCD_GROUP=128"], "n3_g512": ["JR_TUNE_N3_XCD_GROUP=512"],   # round 4: NMR pixel-map gradient: runs of G workgroups per XCD (0 = round-robin)
+    "n3_w5": ["JR_TUNE_N3_PIXMAP_WAVES=5"], "n3_w6": ["JR_TUNE_N3_PIXMAP_WAVES=6"],   # round 4: NMR pixel-map gradient at 5 / 6 wavefronts per SIMD (12 / 72 B of scratch; product: 4, none)
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
