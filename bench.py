@@ -148,6 +148,27 @@ def gradient_references(orc, sample, cores):
     sample.update(gf_serial=gf1, gt_serial=gt1, gf_sum=gfS, gt_sum=gtS, gf_f64=gf64, gt_f64=gt64)
 
 
+def reference_platform_envelope(NF, K, IS=256):
+    """How far the reference moves from ITSELF under a legitimate recompile: its own kernel sources compiled with
+    floating-point contraction on (-ffp-contract=fast -mfma, oracle/_ref/libsoftras_ref_fma.so - what nvcc does by
+    default, --fmad=true) against the -ffp-contract=off build that parity is pinned to, same view, reduced size.  The
+    HIP path reproduces the latter bit for bit in the index buffer; the CUDA build of the reference would not."""
+    from oracle import Oracle
+    from jrender_amd import synthetic as syn
+    a, b = Oracle("reference", nthreads=0), Oracle("reference_fma", nthreads=0)
+    fv, tex = syn.sphere_views(NF, 1)
+    g = np.random.default_rng(11).uniform(-1, 1, (1, 4, IS, IS)).astype(np.float32)
+    ra = a.forward(fv, tex, image_size=IS, max_faces_per_pixel_for_grad=K)
+    rb = b.forward(fv, tex, image_size=IS, max_faces_per_pixel_for_grad=K)
+    ga, gb = a.backward_exactsum(ra, g)[0], b.backward_exactsum(rb, g)[0]
+    bad = (ra["faces_id_buffer"] != rb["faces_id_buffer"]).any(1)
+    return {"what": "reference kernels built with -ffp-contract=fast -mfma (nvcc's default contraction) vs -ffp-contract=off, "
+                    "one %d-face view at %dx%d" % (NF, IS, IS),
+            "ids_mismatching_pixels": int(bad.sum()), "ids_mismatch_frac": float(bad.mean()),
+            "faces_info_words_differing": int((ra["faces_info"].view(np.uint32) != rb["faces_info"].view(np.uint32)).sum()),
+            "rgba": err_metrics(rb["soft_colors"], ra["soft_colors"]), "grad_faces": err_metrics(gb, ga)}
+
+
 def parity_vs_sample(ctx, sample, K, mesh_faces, NV):
     """The GPU path on the oracle's view: same inputs, same size, same upstream gradient."""
     from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
@@ -502,6 +523,11 @@ def bench_softras(args, ctx, comm, rank, world):
             out["cpu_baseline"], sample = cpu_baseline(NF, K)
             if args.scene == "sphere":
                 out["parity"] = parity_vs_sample(ctx, sample, K, mesh_faces, NV)
+                if out["cpu_baseline"]["kind"] == "reference":
+                    try:
+                        out["parity"]["reference_platform_envelope"] = reference_platform_envelope(NF, K)
+                    except Exception as e:
+                        out["parity"]["reference_platform_envelope"] = {"error": repr(e)}
         except Exception as e:                      # the baseline must never break the bench line
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}

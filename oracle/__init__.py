@@ -104,11 +104,18 @@ class Oracle:
         if kind == "port":
             self.lib = C.CDLL(make_port())
             self.lib.orc_ub_events.restype = C.c_long
-        elif kind == "reference":
-            path = make_ref()
+        elif kind in ("reference", "reference_fma"):
+            # "reference_fma": the same sources with floating-point contraction on (what nvcc does by default) - a
+            # measuring stick for the reference's own platform sensitivity, never an oracle (build_ref.build_fma)
+            if kind == "reference":
+                path = make_ref()
+            else:
+                import importlib
+                path = importlib.import_module(__name__ + ".build_ref").build_fma()
             if path is None or not os.path.exists(path):
                 raise FileNotFoundError("oracle/_ref not built and /root/reference not mounted")
             self.lib = C.CDLL(path)
+            self.kind = "reference"
         else:
             raise ValueError(kind)
 

