@@ -19,7 +19,7 @@ import pytest
 from oracle import Oracle
 from jrender_amd import _ffi, synthetic as syn
 from jrender_amd.renderer.dr.softras import SoftRasterizeFunction
-from tests.test_gpu_parity import check_against
+from tests.test_gpu_parity import ELEMENTWISE_TOL, ELEMENTWISE_TOL_BARYCENTRIC, check_against
 from tests.util import bits_equal
 
 pytestmark = pytest.mark.gpu
@@ -63,7 +63,8 @@ def run_forced(ctx, port, fv, tex, waves, expect_heavy=True, seed=0, **kw):
     else:
         assert not info["four_wavefront_kernel"] and info["wavefronts_per_workgroup"] == 1, info
     g = np.random.default_rng(seed).uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
-    check_against(ref, fn, g, port.backward(ref, g))
+    check_against(ref, fn, g, port.backward(ref, g),
+                  ELEMENTWISE_TOL_BARYCENTRIC if kw.get("dist_func") == "barycentric" else ELEMENTWISE_TOL)
     return ref, fn
 
 

@@ -37,7 +37,14 @@ def port():
     return Oracle("port", nthreads=0)
 
 
-def check_against(ref, fn, g, ref_grads):
+# element-wise gradient bound |a-b| / (|b| + 1e-3 max|b|) of the small curated scenes (it was 1e-2 until round 4).  'barycentric'
+# distance keeps 1e-2: with dis = w^2 up to 1 and sigma 1e-4 the coverage saturates to 1 within an ulp, so (1 - D) and the
+# (1 - alpha) factor of the 'prod' gradient are the forward's last bit - the reference's own float gradient is only within
+# 3e-4 ... 1 (!) of its double instantiation on these scenes (oracle.backward_f64), measured in profiles/r04_experiments.md.
+ELEMENTWISE_TOL, ELEMENTWISE_TOL_BARYCENTRIC = 2e-3, 1e-2
+
+
+def check_against(ref, fn, g, ref_grads, elementwise_tol=ELEMENTWISE_TOL):
     fv, tex, rgba, info, aggr, ids = [x.numpy() for x in fn.save_vars]
     assert bits_equal(info, ref["faces_info"]), "faces_info not bit-exact"
     assert bits_equal(ids, ref["faces_id_buffer"]), \
@@ -51,7 +58,7 @@ def check_against(ref, fn, g, ref_grads):
             assert np.nanmax(np.abs(a)) == 0, name
             continue
         assert grad_err(a, b) <= GRAD_TOL, (name, grad_err(a, b))
-        assert grad_err_elementwise(a, b) <= 2e-3, (name, grad_err_elementwise(a, b))   # element-wise with a 1e-3 floor: small scenes, sums of a few float atomics in another order (it was 1e-2 until round 4)
+        assert grad_err_elementwise(a, b) <= elementwise_tol, (name, grad_err_elementwise(a, b))
 
 
 def run_case(ctx, port, fv, tex, seed=0, **kw):
@@ -61,7 +68,8 @@ def run_case(ctx, port, fv, tex, seed=0, **kw):
     fn = SoftRasterizeFunction(ctx=ctx, **kw)
     fn(fv, tex)
     g = np.random.default_rng(seed).uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
-    check_against(ref, fn, g, port.backward(ref, g))
+    check_against(ref, fn, g, port.backward(ref, g),
+                  ELEMENTWISE_TOL_BARYCENTRIC if kw.get("dist_func") == "barycentric" else ELEMENTWISE_TOL)
     return ref, fn
 
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# The round's evidence in ONE gpurun call, on the sources as they are: tools/round_end.sh <tag>
+#   GPU tests, kernel trace + PMC passes of the headline batch and of one view, NMR trace + PMC, profiles/*_latest.json
+#   regenerated FROM THIS RUN (stamped with the hash of the kernel sources), then the plain bench line (which therefore
+#   prints roofline.profile_stale = false), the gradient-parity table and the other BASELINE configurations.
+# Everything lands in gpurun_out/<tag>/; copy into profiles/ (tools/README.md).
+tag=$1
+out=gpurun_out/$tag
+mkdir -p $out
+(timeout 1200 python -m pytest tests -m gpu -q > $out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_pytest_gpu.log)
+tools/collect_profiles.sh $tag trace fetch write sq
+cp gpurun_out/profiles_$tag/${tag}_* $out/ 2>/dev/null
+python tools/pmc_to_json.py gpurun_out/profiles_$tag $tag > $out/${tag}_pmc_to_json.log 2>&1
+BENCH_ARGS="--batch 1" tools/collect_profiles.sh ${tag}_b1 trace sq
+cp gpurun_out/profiles_${tag}_b1/${tag}_b1_* $out/ 2>/dev/null
+rm -rf gpurun_out/n3mr_prof; tools/collect_profiles_n3mr.sh
+for f in gpurun_out/n3mr_prof/n3mr_*; do cp $f $out/${tag}_$(basename $f); done
+python tools/pmc_n3mr_to_json.py gpurun_out/n3mr_prof $tag > $out/${tag}_pmc_n3mr_to_json.log 2>&1
+cp profiles/traffic_latest.json profiles/valu_latest.json profiles/traffic_n3mr_latest.json $out/
+timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 300 python bench.py --scene soup --no-secondary > $out/${tag}_bench_soup.json 2>> $out/${tag}_bench.err
+timeout 400 python tools/grad_parity.py > $out/${tag}_grad_parity.txt 2>&1
+timeout 400 python tools/time_configs.py > $out/${tag}_time_configs.txt 2>&1
+rm -rf gpurun_out/profiles_$tag gpurun_out/profiles_${tag}_b1 gpurun_out/n3mr_prof
+tail -3 $out/${tag}_pytest_gpu.log; tail -c 400 $out/${tag}_bench.json
