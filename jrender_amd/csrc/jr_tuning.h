@@ -82,7 +82,8 @@
 #define JR_TUNE_FWD_HEAVY_PIXELS 4194304
 #endif
 #ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert;
-                                 // backward: bit 2 no three-projection path, bit 3 no n-th-holder search, bit 4 no row reduction, bit 5 no atomics, bit 7 atomics as plain stores
+                                 // backward: bit 2 no three-projection path, bit 3 no n-th-holder search, bit 4 no row reduction, bit 5 no atomics, bit 7 atomics as plain stores, bit 8 no gathers;
+                                 // multi-wavefront forward: bit 9 heavy tiles only, bit 10 light tiles only
 #define JR_TUNE_DIAG 0
 #endif
 #ifndef JR_TUNE_BWD_ROW_RANGES   // backward: a row takes a contiguous quarter of the work items and adds up consecutive items of one face before its atomic
@@ -133,8 +134,13 @@
 #define JR_TUNE_PROFILE_SECTIONS 0
 #endif
 
+#ifndef JR_TUNE_SECTIONS_WAVE     // instrumented build 2: which wavefront of the pipelined heavy tile's workgroup keeps the section clocks (0 K-buffer, 1 colour, 2 tasks, 3 stager)
+#define JR_TUNE_SECTIONS_WAVE 0
+#endif
+
 namespace jr {
 namespace tune {
+constexpr int sections_wave = JR_TUNE_SECTIONS_WAVE;
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
 constexpr bool n3_pixmap_all = JR_TUNE_N3_PIXMAP_ALL != 0;
 constexpr int n3_xcd_group = JR_TUNE_N3_XCD_GROUP;

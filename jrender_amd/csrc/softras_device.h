@@ -448,6 +448,13 @@ struct SectionClock {
             t = n;
         }
     }
+    __device__ inline void flush0(unsigned long long* out, int base) {       // the caller picks the lane
+        if (tune::profile_sections) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (acc[i]) atomicAdd(out + base + i, acc[i]);
+        }
+    }
     __device__ inline void flush(unsigned long long* out, int base) {
         if (tune::profile_sections && threadIdx.x == 0) {
 #pragma unroll

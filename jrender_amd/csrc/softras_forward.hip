@@ -1033,7 +1033,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
     const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
     PixelState<KCAP> s;                                  // the K-buffer lives in wavefront 0, the colour state in wavefront 1
     ListWalkerT<tune::fwd_pipe_list_depth> lw;   // wavefront 3 walks alone: several list chunks in flight
-    SectionClock clk;            // instrumented builds only (wavefront 0): 0 barrier wait, 3 claimed tasks, 6 apply, 7 stores
+    SectionClock clk;            // instrumented builds only (wavefront tune::sections_wave): 0 barrier wait, 3 claimed tasks (wavefront 3: + staging / lists), 6 apply, 7 stores
     clk.start();
     if (wid == 1) init_colour_state<RGB>(p, s);
     if (wid == 0) {
@@ -1127,7 +1127,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
             const int e_batch = st[PS_BATCH], e_total = st[PS_TOTAL];
             const bool offer = st[PS_MASKS] != 0;
             if (st[PS_DONE] && !a_valid) break;
-            if (wid == 0) clk.lap(0);
+            if (wid == tune::sections_wave) clk.lap(0);
             // ---- apply round step-1: lane = pixel, K-buffer | colour ----
             if (wid <= 1 && a_valid) {
                 const int2 span = s_span[((step + 2) % 3) * 64 + lane];                        // (step - 1) % 3
@@ -1142,7 +1142,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                     else apply_colour<RGB, KCAP>(p, cur, colb, tbase, s);
                     cur = nxt;
                 }
-                if (wid == 0) clk.lap(6);
+                if (wid == tune::sections_wave) clk.lap(6);
             }
             // ---- wavefront 3: the batch after, the next round's list, the next step's state ----
             if (wid == 3) {
@@ -1220,17 +1220,17 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                     }
                 }
                 if (DIST == 2 && n_in > 0) run_inside(0, n_in);
-                if (wid == 0) clk.lap(3);
+                if (wid == tune::sections_wave) clk.lap(3);
             }
             a_valid = e_valid; a_batch = e_batch;
             __syncthreads();
         }
     }
     if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
-    if (wid == 0) {
-        store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+    if (wid == 0) store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+    if (wid == tune::sections_wave) {
         clk.lap(7);
-        if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2]) clk.flush(counters, 4);   // the 16 tiles of the heaviest bin
+        if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2] && lane == 0) clk.flush0(counters, 4);   // the 16 tiles of the heaviest bin
     }
 }
 
@@ -1293,6 +1293,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fwd_wav
     TileGeom t;
     if (!tile_geom(p, bin, sub, n, lane, t)) return;     // (a heavy tile: uniform for the workgroup)
     const unsigned long long* seg = pool + bin_base[bin];
+    if ((JR_TUNE_DIAG & 512) && !heavy) return;          // (diagnostic bits 9 / 10, WRONG images: the makespan of the heavy / of the light tiles alone)
+    if ((JR_TUNE_DIAG & 1024) && heavy) return;
     if (heavy) {
         if (tune::fwd_heavy_pipe) tile_heavy_pipe<DIST, RGB, KCAP, NW>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);
         else if (NW == 4) tile_heavy<DIST, RGB, KCAP>(p, t, wid, lane, s_dyn, textures, geo, seg, counters, aggrs, rgba, ids);

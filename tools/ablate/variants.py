@@ -37,6 +37,8 @@ VARIANTS = {
     "diag_nosoftmax": ["JR_TUNE_DIAG=1", "JR_TUNE_FWD_HEAVY=0"],   # WRONG results: cost probes of the single-wavefront path
     "diag_nokbuf": ["JR_TUNE_DIAG=2", "JR_TUNE_FWD_HEAVY=0"],
     "diag_neither": ["JR_TUNE_DIAG=3", "JR_TUNE_FWD_HEAVY=0"],
+    "sh_w1": ["JR_TUNE_PROFILE_SECTIONS=2", "JR_TUNE_SECTIONS_WAVE=1"], "sh_w2": ["JR_TUNE_PROFILE_SECTIONS=2", "JR_TUNE_SECTIONS_WAVE=2"], "sh_w3": ["JR_TUNE_PROFILE_SECTIONS=2", "JR_TUNE_SECTIONS_WAVE=3"],   # ... of the colour / a task / the staging wavefront
+    "diag_heavy_only": ["JR_TUNE_DIAG=512"], "diag_light_only": ["JR_TUNE_DIAG=1024"],   # WRONG images: the multi-wavefront forward with only its heavy / only its light tiles (their makespans)
     "sections_heavy": ["JR_TUNE_PROFILE_SECTIONS=2"],       # instrumented: wavefront 0 of the heaviest bin's tiles (tools/ablate/sections.py --heavy)
     "r2fwd": ["JR_TUNE_FWD_FILL_SHIFT=0", "JR_TUNE_FWD_EXP1=0", "JR_TUNE_FWD_HEAVY=0", "JR_TUNE_FWD_BATCH=56", "JR_TUNE_FWD_WAVES16=4"],   # the round-2 forward
     "h0": ["JR_TUNE_FWD_HEAVY=0"],                           # round 3: one wavefront per tile whatever the size of the launch
