@@ -440,6 +440,12 @@ def bench_softras(args, ctx, comm, rank, world):
     phases = ctx.profile_collect()
     ctx.profile_enable(False)
     comm.barrier()
+    # The communicator's work is done: every rank reads what RCCL says about it and tears it down HERE, together, while all
+    # ranks are alive - rank 0 then goes on alone (latency, CPU baseline, parity) for about a minute, and a communicator whose
+    # peers have exited is not something to find out about in an N-GPU run that cannot be rehearsed on this pool.
+    rccl_ranks = comm.size if comm.backend == "rccl" else None            # ncclCommCount of the live communicator (jr_comm_size)
+    backend = comm.backend
+    comm.close()
     if rank != 0:
         return
 
@@ -481,7 +487,7 @@ def bench_softras(args, ctx, comm, rank, world):
                                % ("UV-sphere" if args.scene == "sphere" else "random-triangle soup", NF, B, IS, IS, K),
                    "faces": NF, "image_size": IS, "batch_per_gpu": B, "global_batch": B * world,
                    "parallelism": "batch-sharded x%d, one process per GPU, exchange=%s over %s"
-                                  % (world, exchange, comm.backend)},
+                                  % (world, exchange, backend)},
         "roofline": {"bound": "hbm", "binding_resource": "valu_issue",
                      "kernel": "k_softras_%s" % ("forward" if dom == "fwd_raster" else "backward"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -495,12 +501,12 @@ def bench_softras(args, ctx, comm, rank, world):
                      "valu": valu, "profile_stale": profile_stale, "csrc_hash": here,
                      "profile_csrc_hash": tj.get("csrc_hash") if profiled else None},
         "phase_ms_per_step": {k: v[0] / args.steps for k, v in phases.items()},
-        "exchange": {"kind": exchange, "backend": comm.backend, "ms_per_step": percentiles(ex_ms)["median"] if ex_ms else 0.0},
+        "exchange": {"kind": exchange, "backend": backend, "ms_per_step": percentiles(ex_ms)["median"] if ex_ms else 0.0},
         "tile_stats": ctx.last_stats(),
     }
-    out["rccl_ranks"] = comm.size if comm.backend == "rccl" else None     # ncclCommCount of the live communicator (jr_comm_size)
-    if comm.backend == "rccl" and out["rccl_ranks"] != world:
-        sys.exit("bench.py: RCCL reports %s ranks for a launch of %d" % (out["rccl_ranks"], world))
+    out["rccl_ranks"] = rccl_ranks
+    if backend == "rccl" and rccl_ranks != world:
+        sys.exit("bench.py: RCCL reports %s ranks for a launch of %d" % (rccl_ranks, world))
     # Everything below is measured by rank 0 on its own GPU AFTER the timed region, at any world size (north_star: latency
     # and vertex-gradient error "reported at 1/2/4/8 GPUs"); the other ranks have left, so nothing here talks to them.
     from jrender_amd.comm import SingleCommunicator
