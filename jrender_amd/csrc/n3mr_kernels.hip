@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JR_TUNE_N3_
         // ---- "in" walks: every lane walks its own scan line, in the orientation in which neighbouring scan positions
         //      are contiguous (plane `axis`) ----
         const size_t in_base = (size_t)axis * P + mbase + (size_t)d0;
-        for (int k = 0; ballot(from + k <= to) != 0ull; k++) {
+        for (int k = 0; !(JR_TUNE_DIAG & 4096) && ballot(from + k <= to) != 0ull; k++) {      // (diagnostic bit 12: no "in" walks)
             const int d1 = from + k;
             const bool act = d1 <= to;
             const size_t m = in_base + (size_t)(act ? d1 : from) * is;      // (from is 1 for idle lanes: a valid element)
@@ -502,17 +502,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JR_TUNE_N3_
             n3_push(diff, d1, d1_cross, ta, tb, ha, hb, two_over_is, p.eps, acc_a, acc_b);
         }
         // ---- "out" walks (N3K:470-507): the lines of all six passes, four at a time, the pixel walk spread over the lanes ----
-        unsigned long long vis = ballot(ok && fin == fn);
+        unsigned long long vis = (JR_TUNE_DIAG & 2048) ? 0ull : ballot(ok && fin == fn);             // (diagnostic bit 11: no "out" walks)
         const unsigned long long ha_m = ballot(ha), hb_m = ballot(hb);
         while (vis) {
-            int s[4], len[4], wf[4], ia_u[4], ib_u[4];
-            size_t base[4];
-            float cross[4], bta[4], btb[4];
-            N3Ref r[4];
-            bool bha[4], bhb[4];
+            constexpr int NL = tune::n3_walks;                     // out-walks in flight
+            int s[NL], len[NL], wf[NL], ia_u[NL], ib_u[NL];
+            size_t base[NL];
+            float cross[NL], bta[NL], btb[NL];
+            N3Ref r[NL];
+            bool bha[NL], bhb[NL];
             int maxlen = -1;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < NL; u++) {
                 const bool valid = vis != 0ull;
                 s[u] = valid ? __builtin_ctzll(vis) : s[0];
                 vis &= vis - 1;                              // (0 stays 0)
@@ -529,18 +530,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JR_TUNE_N3_
                 maxlen = max(maxlen, len[u]);
                 base[u] = (size_t)(1 - bax) * P + mbase + (size_t)bd0 * is + wf[u];   // the orientation in which this walk is contiguous
             }
-            float pa[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int o = lane; o <= maxlen; o += 64) {
-                float4 v[4];
-                float gv[4];
+            float pa[NL], pb[NL];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {                // eight independent loads in flight
+            for (int u = 0; u < NL; u++) { pa[u] = 0.f; pb[u] = 0.f; }
+            for (int o = lane; o <= maxlen; o += 64) {
+                float4 v[NL];
+                float gv[NL];
+#pragma unroll
+                for (int u = 0; u < NL; u++) {                // eight independent loads in flight
                     const size_t m = base[u] + (size_t)min(o, max(len[u], 0));
                     v[u] = sg2[m];
                     gv[u] = gb2[m];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < NL; u++) {
                     if (o > len[u]) continue;
                     const float diff = n3_diff(v[u], gv[u], r[u]);
                     if (diff <= 0) continue;
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JR_TUNE_N3_
             // the walk's per-lane partial sums go straight into the face's nine per-lane accumulators: which two of them is
             // wave-uniform (the pass of the scan lane that owns the line), so this is a scalar branch, not a reduction
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < NL; u++) {
                 if (len[u] < 0) continue;                    // uniform
                 add_uniform(ia_u[u], pa[u]);
                 add_uniform(ib_u[u], pb[u]);

@@ -73,6 +73,8 @@ VARIANTS = {
     "bdiag_nogather": ["JR_TUNE_DIAG=256"], "bdiag_nogather_nosearch": ["JR_TUNE_DIAG=264"],   # WRONG results: the backward without its 13 ds_bpermute gathers (and without the n-th-holder search)
     "n3_rr": ["JR_TUNE_N3_XCD_GROUP=0"], "n3_g8": ["JR_TUNE_N3_XCD_GROUP=8"], "n3_g128": ["JR_TUNE_N3_XCD_GROUP=128"], "n3_g512": ["JR_TUNE_N3_XCD_GROUP=512"],   # round 4: NMR pixel-map gradient: runs of G workgroups per XCD (0 = round-robin)
     "n3_w5": ["JR_TUNE_N3_PIXMAP_WAVES=5"], "n3_w6": ["JR_TUNE_N3_PIXMAP_WAVES=6"],   # round 4: NMR pixel-map gradient at 5 / 6 wavefronts per SIMD (12 / 72 B of scratch; product: 4, none)
+    "n3_walks2": ["JR_TUNE_N3_WALKS=2"], "n3_walks8": ["JR_TUNE_N3_WALKS=8"], "n3_walks1": ["JR_TUNE_N3_WALKS=1"],   # round 4: NMR out-walks in flight per wavefront (product: 4)
+    "n3diag_noout": ["JR_TUNE_DIAG=2048"], "n3diag_noin": ["JR_TUNE_DIAG=4096"], "n3diag_nowalks": ["JR_TUNE_DIAG=6144"],   # WRONG gradients: the NMR pixel-map kernel without its out / in walks
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
