@@ -125,10 +125,16 @@
 #endif
 
 #ifndef JR_TUNE_N3_PIXMAP_WAVES   // NMR pixel-map gradient: wavefronts per SIMD asked of the register allocator
-#define JR_TUNE_N3_PIXMAP_WAVES 4
+#define JR_TUNE_N3_PIXMAP_WAVES 7
 #endif
 #ifndef JR_TUNE_N3_WALKS          // NMR pixel-map gradient: out-walks of a face taken at a time (their loads are independent)
 #define JR_TUNE_N3_WALKS 4
+#endif
+#ifndef JR_TUNE_N3_LINE_WALKS     // NMR pixel-map gradient: the out-walks regrouped by scan line and run from an LDS copy of the line (0: every face walks its own lines through the L2s)
+#define JR_TUNE_N3_LINE_WALKS 1
+#endif
+#ifndef JR_TUNE_N3_LINE_PARTS     // NMR line walks: sub-lists (= workgroups of the walk kernel) per scan line; power of two, 1024 crossings per line in total
+#define JR_TUNE_N3_LINE_PARTS 8
 #endif
 #ifndef JR_TUNE_N3_XCD_GROUP      // NMR backward: runs of this many consecutive workgroups (4 faces each) go to one XCD (0: round-robin, the hardware's order)
 #define JR_TUNE_N3_XCD_GROUP 32
@@ -148,6 +154,8 @@ constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
 constexpr bool n3_pixmap_all = JR_TUNE_N3_PIXMAP_ALL != 0;
 constexpr int n3_xcd_group = JR_TUNE_N3_XCD_GROUP;
 constexpr int n3_walks = JR_TUNE_N3_WALKS;
+constexpr bool n3_line_walks = JR_TUNE_N3_LINE_WALKS != 0;
+constexpr int n3_line_parts = JR_TUNE_N3_LINE_PARTS;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr int fwd_exact = JR_TUNE_FWD_EXACT, bwd_exact = JR_TUNE_BWD_EXACT;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;

@@ -365,6 +365,86 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_pixel_map(
     }
 }
 
+__device__ inline float n3_wave_sum(float v) {            // all lanes active; result uniform
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+    return (n3_bcast(v, 0) + n3_bcast(v, 16)) + (n3_bcast(v, 32) + n3_bcast(v, 48));
+}
+
+// ---- out-walks per SCAN LINE (tune::n3_line_walks, round 4) ------------------------------------------------------------------
+// The out-walks of the pixel-map gradient are 0.375 ms of the NMR backward and move 2.45 GB through the L2s (6.5 TB/s: every one
+// of the ~120 M pixel visits fetches its 20 bytes from behind them; profiles/r04_experiments.md calls 7, 18) although the two
+// packed planes are 40 MB: a walk runs along ONE image column or row, and the ~140 walks that run along the same line are
+// spread over faces all around the mesh.  So the walks are regrouped by line: the per-face kernel appends a 36-byte crossing
+// record to its line's list (one atomic), and here one workgroup per line copies the line's 20 B x image_size into LDS once
+// and runs all its crossings from there - one crossing per wavefront at a time, lanes along the walk - adding the two sums
+// of a crossing to the face's gradient with float atomics (the per-face kernel has stored its part before, on the same stream).
+// A line's list is N3_LINE_PARTS sub-lists, chosen by the low bits of the face index: a line through the middle of the object
+// takes several hundred appends, and same-address atomics retire one at a time; a workgroup of the walk kernel takes ONE sub-list,
+// so the lines with the most crossings (and the longest walks) are also spread over N3_LINE_PARTS workgroups.
+constexpr int N3_LINE_PARTS = tune::n3_line_parts;      // power of two
+constexpr int N3_LINE_CAP = 1024 / N3_LINE_PARTS;       // crossings a sub-list holds; what it turns away is walked by the per-face kernel
+static_assert((N3_LINE_PARTS & (N3_LINE_PARTS - 1)) == 0 && N3_LINE_PARTS <= 16, "JR_TUNE_N3_LINE_PARTS");
+struct N3Crossing {
+    int packed;                                  // d1_out (13 bits) | direction > 0 (bit 13) | ha, hb (14, 15) | output component of the edge's two vertices (16-19, 20-23)
+    int face;                                    // bn * NF + fn
+    float cross, ta, tb, ra, r0, r1, r2;         // crossing point, N3K:496-505's slopes, the reference pixel (alpha, r, g, b)
+};
+static_assert(sizeof(N3Crossing) == 36, "crossing record");
+
+__global__ __launch_bounds__(256) void k_n3mr_backward_line_walks(
+    N3Params p, int nsub, const float4* __restrict__ sg2, const float* __restrict__ gb2, const int* __restrict__ line_count,
+    const N3Crossing* __restrict__ line_rec, float* __restrict__ grad_faces) {
+    extern __shared__ float4 s_line[];           // [is] (S, g_alpha, g_r, g_g), then [is] g_b
+    // the sub-lists of ONE line go to one XCD (workgroup ids are dealt round-robin to the eight): its L2 serves the line once
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int S = ((k / N3_LINE_PARTS) * 8 + xcd) * N3_LINE_PARTS + (k % N3_LINE_PARTS), L = S / N3_LINE_PARTS, is = p.IS;   // sub-list S of scan line L
+    if (S >= nsub) return;
+    const int n = min(line_count[S], N3_LINE_CAP);
+    if (n <= 0) return;
+    float* s_gbl = reinterpret_cast<float*>(s_line + is);
+    const int d0 = L % is, axis = (L / is) & 1, bn = L / (2 * is);
+    const size_t P = (size_t)p.B * is * is;
+    const size_t base = (size_t)(1 - axis) * P + (size_t)bn * is * is + (size_t)d0 * is;   // the orientation in which the walks of this line are contiguous
+    for (int i = threadIdx.x; i < is; i += 256) { s_line[i] = sg2[base + i]; s_gbl[i] = gb2[base + i]; }
+    __syncthreads();
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float two_over_is = 2.f / is;
+    const int* words = reinterpret_cast<const int*>(line_rec + (size_t)S * N3_LINE_CAP);
+    constexpr int cstep = 4;
+    int w = wid < n && lane < 9 ? words[wid * 9 + lane] : 0;              // the record of this wavefront's first crossing, one word per lane
+    for (int c = wid; c < n; c += cstep) {
+        const int packed = __builtin_amdgcn_readlane(w, 0), face = __builtin_amdgcn_readlane(w, 1);
+        const float cross = n3_bcast(__builtin_bit_cast(float, w), 2), ta = n3_bcast(__builtin_bit_cast(float, w), 3),
+                    tb = n3_bcast(__builtin_bit_cast(float, w), 4);
+        const N3Ref r = {n3_bcast(__builtin_bit_cast(float, w), 5), n3_bcast(__builtin_bit_cast(float, w), 6),
+                         n3_bcast(__builtin_bit_cast(float, w), 7), n3_bcast(__builtin_bit_cast(float, w), 8)};
+        w = c + cstep < n && lane < 9 ? words[(c + cstep) * 9 + lane] : 0;  // the next record is in flight during the walk
+        const int d1_out = packed & 0x1fff;
+        const bool up = packed & (1 << 13), ha = packed & (1 << 14), hb = packed & (1 << 15);
+        const int ia = (packed >> 16) & 15, ib = (packed >> 20) & 15;
+        const int d1_limit = up ? is - 1 : 0;
+        const int wf = max(min(d1_out, d1_limit), 0), wt = min(max(d1_out, d1_limit), is - 1);
+        // -= diff / (dist +- eps), dist = t * (d1 - cross) * 2 / is (N3K:496-505; the constant factors folded: one rounding apart)
+        const float fa = ta * two_over_is, fb = tb * two_over_is, eps = p.eps;
+        float pa = 0.f, pb = 0.f;
+        for (int d1 = wf + lane; d1 <= wt; d1 += 64) {
+            const float diff = n3_diff(s_line[d1], s_gbl[d1], r);
+            if (diff <= 0) continue;
+            const float dd = (float)d1 - cross;
+            if (ha) { float dist = fa * dd; dist += 0 < dist ? eps : -eps; pa -= diff * __builtin_amdgcn_rcpf(dist); }
+            if (hb) { float dist = fb * dd; dist += 0 < dist ? eps : -eps; pb -= diff * __builtin_amdgcn_rcpf(dist); }
+        }
+        const float sa = n3_wave_sum(pa), sb = n3_wave_sum(pb);
+        if (lane == 0) {
+            if (sa != 0.f) atomicAdd(grad_faces + (size_t)face * 9 + ia, sa);
+            if (sb != 0.f) atomicAdd(grad_faces + (size_t)face * 9 + ib, sb);
+        }
+    }
+}
+
 // ---- round 4: the same gradient with ALL SIX (edge, axis) passes of a face in the lanes at once --------------------------
 // k_n3mr_backward_pixel_map above runs the six (edge, axis) passes of a face one after the other: each sets up with
 // 5 of 64 lanes busy (a face of the 39k-face sphere spans ~5 scan positions per edge), does its short "in" walks, and
@@ -378,19 +458,12 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_pixel_map(
 //   * planes: [0] row-major, [1] column-major copies of (S, g_alpha, g_r, g_g | g_b | face index) in ONE buffer each, so
 //     that "the orientation in which this walk is contiguous" is an index offset, not a pointer select.
 // Same arithmetic per visited pixel (n3_diff / n3_push); only the order of the float sums differs.
-__device__ inline float n3_wave_sum(float v) {            // all lanes active; result uniform
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
-    return (n3_bcast(v, 0) + n3_bcast(v, 16)) + (n3_bcast(v, 32) + n3_bcast(v, 48));
-}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JR_TUNE_N3_PIXMAP_WAVES))) void k_n3mr_backward_pixel_map_all(
     N3Params p, const float* __restrict__ faces, const int32_t* __restrict__ face_index_map,
     const float* __restrict__ rgb_map, const float* __restrict__ alpha_map,
     const float4* __restrict__ sg2, const float* __restrict__ gb2, const int32_t* __restrict__ fidx2,
-    float* __restrict__ grad_faces) {
+    int* __restrict__ line_count, N3Crossing* __restrict__ line_rec, float* __restrict__ grad_faces) {
     // XCD-aware order (tune::n3_xcd_group = G): workgroup ids go round-robin to the 8 XCDs, so with faces in launch order
     // every XCD walks rows and columns all over the image and its 4 MB L2 keeps missing.  Neighbouring faces of a mesh walk
     // the same rows / columns: runs of G consecutive workgroups (4 G faces) go to ONE XCD.  (One contiguous eighth of the
@@ -501,11 +574,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JR_TUNE_N3_
             if (diff <= 0) continue;
             n3_push(diff, d1, d1_cross, ta, tb, ha, hb, two_over_is, p.eps, acc_a, acc_b);
         }
-        // ---- "out" walks (N3K:470-507): the lines of all six passes, four at a time, the pixel walk spread over the lanes ----
-        unsigned long long vis = (JR_TUNE_DIAG & 2048) ? 0ull : ballot(ok && fin == fn);             // (diagnostic bit 11: no "out" walks)
+        // ---- the walks that stay here: the lines of all six passes, four at a time, the pixel walk spread over the lanes ----
+        // ---- "out" walks (N3K:470-507).  tune::n3_line_walks: they are NOT run here.  Every walk is handed to the scan line it runs
+        //      along (a crossing record appended to the line's list); k_n3mr_backward_line_walks stages each line of the packed
+        //      planes in LDS ONCE and runs all its crossings from there.  A line whose list is full keeps its walk here.
+        bool walk_here = ok && fin == fn;
+        if (line_rec && walk_here) {
+            const int L = ((bn * 2 + axis) * is + d0) * N3_LINE_PARTS + (wave & (N3_LINE_PARTS - 1));
+            const int pos = atomicAdd(&line_count[L], 1);
+            if (pos < N3_LINE_CAP) {
+                N3Crossing c;
+                c.packed = d1_out | (0 < direction ? 1 << 13 : 0) | (ha ? 1 << 14 : 0) | (hb ? 1 << 15 : 0) | (ia << 16) | (ib << 20);
+                c.face = wave; c.cross = d1_cross; c.ta = ta; c.tb = tb;
+                c.ra = rin.a; c.r0 = rin.c0; c.r1 = rin.c1; c.r2 = rin.c2;
+                line_rec[(size_t)L * N3_LINE_CAP + pos] = c;
+                walk_here = false;
+            }
+        }
+        unsigned long long vis = (JR_TUNE_DIAG & 2048) ? 0ull : ballot(walk_here);                   // (diagnostic bit 11: no "out" walks)
         const unsigned long long ha_m = ballot(ha), hb_m = ballot(hb);
         while (vis) {
-            constexpr int NL = tune::n3_walks;                     // out-walks in flight
+            // out-walks in flight: with the per-line regrouping this loop only takes what a full line list turned away, and one
+            // at a time keeps the registers (68 instead of 97: 7 wavefronts per SIMD instead of 4) for the common path
+            constexpr int NL = tune::n3_line_walks ? 1 : tune::n3_walks;
             int s[NL], len[NL], wf[NL], ia_u[NL], ib_u[NL];
             size_t base[NL];
             float cross[NL], bta[NL], btb[NL];
@@ -756,7 +847,13 @@ void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textur
                                                                sampling_index_map, sampling_weight_map);
 }
 
-size_t n3mr_backward_scratch_bytes(int B, int IS) { return (size_t)B * IS * IS * (2 * 16 + 2 * 4 + 2 * 4); }
+// scan lines per launch of the line-walk kernel (two orientations per image); the LDS copy of a line is 20 B per pixel
+static bool n3_use_line_walks(int IS) { return tune::n3_line_walks && (size_t)IS * 20 <= 65536 && IS < (1 << 13); }
+size_t n3mr_backward_scratch_bytes(int B, int IS) {
+    size_t bytes = (size_t)B * IS * IS * (2 * 16 + 2 * 4 + 2 * 4);
+    if (n3_use_line_walks(IS)) bytes += (size_t)B * 2 * IS * N3_LINE_PARTS * (sizeof(int) + sizeof(N3Crossing) * N3_LINE_CAP) + 64;
+    return bytes;
+}
 
 void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* face_index_map,
                           const float* weight_map, const float* depth_map, const float* face_inv_map,
@@ -779,8 +876,19 @@ void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* fac
                                                                 grad_alpha_map, sg, gb, sg_t, gb_t, fidx_r, fidx_t);
         if (tune::n3_pixmap_all) {
             constexpr long GG = 8 * (tune::n3_xcd_group > 0 ? tune::n3_xcd_group : 1);        // whole runs for every XCD
+            int* line_count = nullptr;
+            N3Crossing* line_rec = nullptr;
+            const int nlines = B * 2 * IS * N3_LINE_PARTS;        // sub-lists
+            if (n3_use_line_walks(IS)) {
+                line_count = reinterpret_cast<int*>(fidx_t + P);
+                line_rec = reinterpret_cast<N3Crossing*>(line_count + ((nlines + 15) & ~15));     // (N3Crossing is 4-byte aligned)
+                (void)hipMemsetAsync(line_count, 0, sizeof(int) * (size_t)nlines, st);
+            }
             k_n3mr_backward_pixel_map_all<<<(unsigned)(((waves * 64 + 255) / 256 + GG - 1) / GG * GG), 256, 0, st>>>(
-                p, faces, face_index_map, rgb_map, alpha_map, sg, gb, fidx_r, grad_faces);
+                p, faces, face_index_map, rgb_map, alpha_map, sg, gb, fidx_r, line_count, line_rec, grad_faces);
+            if (line_rec)
+                k_n3mr_backward_line_walks<<<(unsigned)((nlines + 8 * N3_LINE_PARTS - 1) / (8 * N3_LINE_PARTS) * (8 * N3_LINE_PARTS)), 256, (size_t)IS * 20, st>>>(
+                    p, nlines, sg, gb, line_count, line_rec, grad_faces);
         } else {
             const N3Planes rowmajor = {sg, gb, face_index_map}, colmajor = {sg_t, gb_t, fidx_t};
             k_n3mr_backward_pixel_map<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(
