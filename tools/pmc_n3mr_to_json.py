@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gpurun_out/n3mr_prof (tools/collect_profiles_n3mr.sh) -> profiles/traffic_n3mr_latest.json: HBM-side bytes per launch of the
-NMR forward (k_n3mr_zbuffer + k_n3mr_resolve) and backward (k_n3mr_pack + k_n3mr_backward_pixel_map* + k_n3mr_backward_face),
+NMR forward (k_n3mr_zbuffer + k_n3mr_resolve) and backward (k_n3mr_pack + k_n3mr_backward_pixel_map* + k_n3mr_backward_line_walks + k_n3mr_backward_face),
 (2 * FETCH_SIZE + WRITE_SIZE) * 1024 as in tools/pmc_to_json.py, stamped with bench.csrc_hash().  usage: tools/pmc_n3mr_to_json.py <dir> <tag>"""
 import collections
 import csv
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from bench import csrc_hash                 # noqa: E402
 
 d, tag = sys.argv[1], sys.argv[2]
-FWD, BWD = ("k_n3mr_zbuffer", "k_n3mr_resolve"), ("k_n3mr_pack", "k_n3mr_backward_pixel_map", "k_n3mr_backward_face")
+FWD, BWD = ("k_n3mr_zbuffer", "k_n3mr_resolve"), ("k_n3mr_pack", "k_n3mr_backward_pixel_map", "k_n3mr_backward_line_walks", "k_n3mr_backward_face")
 
 
 def means(counter):
@@ -33,7 +33,7 @@ out = {"fwd": (2 * tot(fetch, FWD) + tot(write, FWD)) * 1024, "bwd": (2 * tot(fe
        "per_kernel_fetch_kb": {k.split("(")[0][-40:]: v for k, v in fetch.items() if "n3mr" in k},
        "csrc_hash": csrc_hash(),
        "note": "HBM-side bytes per launch of the NMR forward (k_n3mr_zbuffer + k_n3mr_resolve) and backward (k_n3mr_pack + "
-               "k_n3mr_backward_pixel_map_all + k_n3mr_backward_face) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB): "
+               "k_n3mr_backward_pixel_map_all + k_n3mr_backward_line_walks + k_n3mr_backward_face) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB): "
                "(2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH doubled per MI355X_MICROARCH.md. 78 000 faces, 1024^2, rgb+alpha+depth. "
                "Source: profiles/%s_n3mr_pmc_*.txt" % tag}
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic_n3mr_latest.json")
