@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void k_n3mr_zbuffer(N3Params p, const float* _
     if (wave >= p.B * p.NF) return;
     const int bn = wave / p.NF, fn = wave - bn * p.NF;
     const float* f = faces + (size_t)wave * 9;
-    if ((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0])) return;       // back side, N3K:63
+    if ((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0])) {               // back side, N3K:63
+        if (lane < 9) faces_inv[(size_t)wave * 9 + lane] = 0.f;                        // (the reference's output is pre-zeroed; no memset launch here)
+        return;
+    }
     float px[3], py[3], inv[9];
     n3_face_inv(f, p.IS, px, py, inv);
     if (lane < 9) faces_inv[(size_t)wave * 9 + lane] = inv[lane];
@@ -207,10 +210,13 @@ __global__ __launch_bounds__(256) void k_n3mr_pack(
     N3Params p, const int32_t* __restrict__ face_index_map, const float* __restrict__ rgb_map,
     const float* __restrict__ alpha_map, const float* __restrict__ grad_rgb_map,
     const float* __restrict__ grad_alpha_map, float4* __restrict__ sg, float* __restrict__ gb,
-    float4* __restrict__ sg_t, float* __restrict__ gb_t, int32_t* __restrict__ fidx_r, int32_t* __restrict__ fidx_t) {
+    float4* __restrict__ sg_t, float* __restrict__ gb_t, int32_t* __restrict__ fidx_r, int32_t* __restrict__ fidx_t,
+    int* __restrict__ line_count, int nsub) {
     __shared__ float4 s_v[N3_PACK_TILE][N3_PACK_TILE + 1];
     __shared__ float s_g[N3_PACK_TILE][N3_PACK_TILE + 1];
     __shared__ int32_t s_f[N3_PACK_TILE][N3_PACK_TILE + 1];
+    // (the crossing lists of the line-walk kernel start empty: cleared here instead of by a memset launch of their own)
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < nsub; c += gridDim.x * 256) line_count[c] = 0;
     const int is = p.IS, tiles = (is + N3_PACK_TILE - 1) / N3_PACK_TILE;
     const int bn = blockIdx.x / (tiles * tiles), tt = blockIdx.x - bn * tiles * tiles;
     const int y0 = (tt / tiles) * N3_PACK_TILE, x0 = (tt % tiles) * N3_PACK_TILE;
@@ -499,7 +505,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JR_TUNE_N3_
     const int bn = wave / p.NF, fn = wave - bn * p.NF;
     const int is = p.IS;
     const float* face = faces + (size_t)wave * 9;
-    if ((face[7] - face[1]) * (face[3] - face[0]) < (face[4] - face[1]) * (face[6] - face[0])) return;
+    if ((face[7] - face[1]) * (face[3] - face[0]) < (face[4] - face[1]) * (face[6] - face[0])) {
+        if (lane < 9) grad_faces[(size_t)wave * 9 + lane] = 0.f;      // (back face: no gradient; written here, there is no memset launch in front of this kernel)
+        return;
+    }
     const size_t P = (size_t)p.B * is * is, mbase = (size_t)bn * is * is;
     const float two_over_is = 2.f / is;
     const bool use_rgb = p.return_rgb, use_a = p.return_alpha;
@@ -754,6 +763,7 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
     for (int k = 0; k < 24; k++) treg[k] = 0.f;
     const float* f = faces + (size_t)wave * 9;
     float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool mine = false;                                   // this lane found a pixel the face owns
     const bool front = !((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]));   // N3K:63
     if (front) {
         float x_min = is, y_min = is, x_max = 0, y_max = 0;                               // N3K:89-99
@@ -774,6 +784,7 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
             const int yi = iy0 + (int)(idx / wid), xi = ix0 + (int)(idx % wid);           // lanes along rows
             const size_t i = mbase + (size_t)yi * is + xi;
             if (face_index_map[i] != fn) continue;
+            mine = true;
             if (p.return_depth) {                                                          // N3K:768-779
                 const float depth = depth_map[i], depth2 = depth * depth, gd = grad_depth_map[i];
                 const float* finv = face_inv_map + 9 * i;
@@ -818,7 +829,7 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
                 }
             }
         }
-        if (p.return_rgb && ts == 2) {                       // (uniform) the register sums join the LDS accumulators
+        if (p.return_rgb && ts == 2 && ballot(mine) != 0ull) {   // (uniform) the register sums join the LDS accumulators
             __builtin_amdgcn_s_waitcnt(0);
 #pragma unroll
             for (int k = 0; k < 24; k++) {
@@ -827,7 +838,9 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
             }
         }
     }
-    if (p.return_depth) {
+    // three faces out of four own no pixel here (back faces, hidden front faces): they skip the reductions (round 4)
+    const bool some = ballot(mine) != 0ull;
+    if (p.return_depth && some) {
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             float v = g[k];
@@ -859,7 +872,6 @@ void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textur
     const N3Params p = make_n3(B, NF, TS, IS, near_, far_, eps, bg, rrgb, ralpha, rdepth);
     const long P = (long)B * IS * IS;
     (void)hipMemsetAsync(zkey, 0xff, sizeof(unsigned long long) * P, st);
-    (void)hipMemsetAsync(faces_inv, 0, sizeof(float) * (size_t)B * NF * 9, st);
     const long waves = (long)B * NF;
     k_n3mr_zbuffer<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(p, faces, faces_inv, zkey);
     k_n3mr_resolve<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(p, faces, textures, faces_inv, zkey, face_index_map,
@@ -883,7 +895,8 @@ void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* fac
                           int B, int NF, int TS, int IS, float eps, int rrgb, int ralpha, int rdepth) {
     const N3Params p = make_n3(B, NF, TS, IS, 0.f, 0.f, eps, nullptr, rrgb, ralpha, rdepth);
     const long P = (long)B * IS * IS, waves = (long)B * NF;
-    (void)hipMemsetAsync(grad_faces, 0, sizeof(float) * (size_t)B * NF * 9, st);
+    // k_n3mr_backward_pixel_map_all writes every face's nine components itself (zeros for back faces)
+    if (!((rrgb || ralpha) && tune::n3_pixmap_all)) (void)hipMemsetAsync(grad_faces, 0, sizeof(float) * (size_t)B * NF * 9, st);
     if (rrgb || ralpha) {
         // scratch (n3mr_backward_scratch_bytes): [sg | sg_t] float4, [gb | gb_t] float, [fidx | fidx_t] int32 - row-major | column-major
         float4* sg = static_cast<float4*>(scratch);
@@ -893,21 +906,18 @@ void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* fac
         int32_t* fidx_r = reinterpret_cast<int32_t*>(gb_t + P);
         int32_t* fidx_t = fidx_r + P;
         const int ptiles = (IS + N3_PACK_TILE - 1) / N3_PACK_TILE;
+        const bool line_walks = tune::n3_pixmap_all && n3_use_line_walks(IS);
+        const int nlines = B * 2 * IS * N3_LINE_PARTS;            // sub-lists of the scan lines
+        int* line_count = reinterpret_cast<int*>(fidx_t + P);
+        N3Crossing* line_rec = reinterpret_cast<N3Crossing*>(line_count + ((nlines + 15) & ~15));     // (N3Crossing is 4-byte aligned)
         k_n3mr_pack<<<(unsigned)(B * ptiles * ptiles), 256, 0, st>>>(p, face_index_map, rgb_map, alpha_map, grad_rgb_map,
-                                                                grad_alpha_map, sg, gb, sg_t, gb_t, fidx_r, fidx_t);
+                                                                    grad_alpha_map, sg, gb, sg_t, gb_t, fidx_r, fidx_t,
+                                                                    line_count, line_walks ? nlines : 0);
         if (tune::n3_pixmap_all) {
             constexpr long GG = 8 * (tune::n3_xcd_group > 0 ? tune::n3_xcd_group : 1);        // whole runs for every XCD
-            int* line_count = nullptr;
-            N3Crossing* line_rec = nullptr;
-            const int nlines = B * 2 * IS * N3_LINE_PARTS;        // sub-lists
-            if (n3_use_line_walks(IS)) {
-                line_count = reinterpret_cast<int*>(fidx_t + P);
-                line_rec = reinterpret_cast<N3Crossing*>(line_count + ((nlines + 15) & ~15));     // (N3Crossing is 4-byte aligned)
-                (void)hipMemsetAsync(line_count, 0, sizeof(int) * (size_t)nlines, st);
-            }
             k_n3mr_backward_pixel_map_all<<<(unsigned)(((waves * 64 + 255) / 256 + GG - 1) / GG * GG), 256, 0, st>>>(
-                p, faces, face_index_map, rgb_map, alpha_map, sg, gb, fidx_r, line_count, line_rec, grad_faces);
-            if (line_rec)
+                p, faces, face_index_map, rgb_map, alpha_map, sg, gb, fidx_r, line_walks ? line_count : nullptr, line_walks ? line_rec : nullptr, grad_faces);
+            if (line_walks)
                 k_n3mr_backward_line_walks<<<(unsigned)((nlines + 8 * N3_LINE_PARTS - 1) / (8 * N3_LINE_PARTS) * (8 * N3_LINE_PARTS)), 256, (size_t)IS * 20, st>>>(
                     p, nlines, sg, gb, line_count, line_rec, grad_faces);
         } else {
