@@ -12,6 +12,12 @@ configs[3]) on the HIP SoftRas path, with the backward chain written out (no aut
 Without -i/-c (the reference's data files are not shipped here) the target is synthetic: silhouettes of a
 squashed, shifted ellipsoid seen from a ring of cameras.  With several ranks every rank renders its slice of
 the views; the vertex gradient (the mesh is shared by all views) is summed with one all-reduce.
+
+--front-end device (default): the 16 KB vertex set goes to the GPU once per iteration and everything between it and
+the vertex gradient stays there — camera kernel (one vertex set broadcast over the views), face gather, SoftRas
+forward, IoU loss + its gradient, SoftRas backward, scatter to the vertices, camera VJP summed over the views,
+RCCL all-reduce — and 16 KB come back.  --front-end host runs the same chain through the NumPy mirrors (the
+6 MB face arrays cross PCIe twice per iteration); both produce the same loss curve (tests/test_gpu_named_configs.py).
 """
 import argparse
 import os
@@ -85,6 +91,8 @@ def main(argv=None):
     ap.add_argument('--template-vertices', default=None, help=".obj, or .npz with 'vertices' / 'faces' (default: a 1 352-vertex UV sphere)")
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--gpus', type=int, default=1, help="spawn this many ranks (one process per GPU)")
+    ap.add_argument('--front-end', choices=['device', 'host'], default='device',
+                    help="where the camera / gather / loss steps around the rasteriser run (see the module docstring)")
     args = ap.parse_args(argv)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -121,24 +129,40 @@ def main(argv=None):
 
     t0 = time.time()
     history = []
+    nb = hi - lo
+    ctx = jr.Context.default()
+    target_d = ctx.array(np.ascontiguousarray(target[lo:hi], np.float32)) if args.front_end == 'device' and nb else None
     for it in range(args.iters):
         vertices = model.forward()                                            # [1,nv,3]
-        nb = hi - lo
-        mesh = jr.Mesh(np.repeat(vertices, nb, 0), np.repeat(model.faces, nb, 0))
-        pred = renderer.render_mesh(mesh, mode='silhouettes').numpy().reshape(nb, args.image_size, args.image_size)
-        # neg-IoU over ALL views: per-view IoUs are independent, so the local part is (1/B) * sum over local views
-        inter = (pred * target[lo:hi]).sum((1, 2))
-        union = (pred + target[lo:hi] - pred * target[lo:hi]).sum((1, 2)) + 1e-6
-        iou_sum = float((inter / union).sum())
-        g_sil = jr.neg_iou_loss_backward(pred, target[lo:hi]) * (nb / B)      # that helper averages over its own batch
-        g_v = renderer.grad_vertices(grad_silhouettes=g_sil.reshape(nb, 1, args.image_size, args.image_size)).sum(0, keepdims=True)
-        if comm is not None:
-            g_v = comm.all_reduce_sum_host(g_v)          # [1,nv,3]: the mesh is shared by all views
-            iou_sum = comm.all_reduce_scalar(iou_sum, "sum")
+        if args.front_end == 'device' and nb:
+            # ONE vertex set on the device; the camera step broadcasts it over this rank's eyes (demo2-deform.py:45
+            # materialises the copies with repeat())
+            mesh = jr.Mesh(ctx.array(vertices), model.faces)
+            pred = renderer.render_mesh(mesh, mode='silhouettes')             # DeviceArray [nb,IS,IS]
+            iou, g_sil = jr.neg_iou_loss_and_grad(pred, target_d, total_views=B)
+            iou_sum = float(iou.sum())
+            g_v = renderer.grad_vertices(grad_silhouettes=g_sil)              # DeviceArray [1,nv,3]: summed over the views
+            if comm is not None:
+                g_v = comm.all_reduce_sum(g_v)           # RCCL on the device buffer
+                iou_sum = comm.all_reduce_scalar(iou_sum, "sum")
+            g_v = g_v.numpy()
+        else:
+            mesh = jr.Mesh(np.repeat(vertices, nb, 0), np.repeat(model.faces, nb, 0))
+            pred = renderer.render_mesh(mesh, mode='silhouettes').numpy().reshape(nb, args.image_size, args.image_size)
+            # neg-IoU over ALL views: per-view IoUs are independent, so the local part is (1/B) * sum over local views
+            inter = (pred * target[lo:hi]).sum((1, 2))
+            union = (pred + target[lo:hi] - pred * target[lo:hi]).sum((1, 2)) + 1e-6
+            iou_sum = float((inter / union).sum())
+            g_sil = jr.neg_iou_loss_backward(pred, target[lo:hi]) * (nb / B)      # that helper averages over its own batch
+            g_v = renderer.grad_vertices(grad_silhouettes=g_sil.reshape(nb, 1, args.image_size, args.image_size)).sum(0, keepdims=True)
+            if comm is not None:
+                g_v = comm.all_reduce_sum_host(g_v)          # [1,nv,3]: the mesh is shared by all views
+                iou_sum = comm.all_reduce_scalar(iou_sum, "sum")
         lap = float(np.mean(model.laplacian_loss(vertices)))
-        flat = float(np.mean(model.flatten_loss(vertices)))
+        flat, g_flat = model.flatten_loss.value_and_grad(vertices)
+        flat = float(np.mean(flat))
         loss = (1.0 - iou_sum / B) + 0.03 * lap + 0.0003 * flat
-        g_v = g_v + 0.03 * model.laplacian_loss.backward(vertices) + 0.0003 * model.flatten_loss.backward(vertices)
+        g_v = g_v + 0.03 * model.laplacian_loss.backward(vertices) + 0.0003 * g_flat
         optimizer.step(model.backward(g_v))
         history.append(loss)
         if rank == 0 and not args.quiet and (it % 20 == 0 or it == args.iters - 1):

@@ -64,6 +64,9 @@ int jr_ctx_trim(jr_ctx* ctx);           /* hipFree everything cached by jr_free 
 int jr_memcpy_h2d(jr_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* blocking */
 int jr_memcpy_d2h(jr_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* blocking */
 int jr_memcpy_d2d(jr_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);  /* async   */
+/* `height` rows of `width` bytes, rows `*_pitch` bytes apart (channel selection out of [B,4,H,W] images); async */
+int jr_memcpy2d_d2d(jr_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t width,
+                    size_t height);
 int jr_memset(jr_ctx* ctx, void* dptr, int byte_value, size_t bytes);              /* async   */
 int jr_synchronize(jr_ctx* ctx);
 /* HIP events on the context's stream (benchmark timing) */
@@ -135,6 +138,22 @@ int jr_face_vertices_backward(jr_ctx* ctx, const float* grad_face_vertices, cons
 int jr_face_vertices_backward_shared(jr_ctx* ctx, const float* grad_face_vertices,
                                      const int32_t* faces, float* grad_vertices, int B, int NV,
                                      int NF);
+/* ---- the callers either side of the op, device-resident (BASELINE configs[3]) ----------
+ * Camera step of camera_mode 'look_at' / 'look' (jrender/renderer/transform/look_at.py:3-39, look.py:3-54) followed by
+ * perspective (perspective.py:4-17, kind 1, param = tan(viewing_angle)), orthogonal (orthogonal.py:3-16, kind 2,
+ * param = scale) or nothing (kind 0).  eye [B,3] and rot [B,9] (rows = camera x, y, z axes) are computed by the host
+ * (O(B)); vertices are [VB,NV,3] with VB == B, or VB == 1 for ONE vertex set seen by all B views (what
+ * demo2-deform.py:45 builds with repeat()).  out [B,NV,3].  The backward (was Jittor autograd) returns
+ * d/d(world vertices) [VB,NV,3]; with VB == 1 it is the sum over the views, added in view order (no atomics). */
+int jr_camera_forward(jr_ctx* ctx, const float* vertices, const float* eye, const float* rot, float* out,
+                      int B, int VB, int NV, int kind, float param);
+int jr_camera_backward(jr_ctx* ctx, const float* grad_out, const float* vertices, const float* eye,
+                       const float* rot, float* grad_vertices, int B, int VB, int NV, int kind, float param);
+/* neg_iou_loss (jrender/loss/iou_loss.py:1-9) per view: iou[b] = sum(p*t) / (sum(p + t - p*t) + 1e-6) over the n
+ * elements of view b (the loss is 1 - mean(iou)); grad_predict (may be NULL) = d(loss)/d(predict) with the mean
+ * taken over `divisor` views (the whole batch when the views are sharded over ranks). */
+int jr_neg_iou_loss(jr_ctx* ctx, const float* predict, const float* target, float* iou, float* grad_predict,
+                    int B, int n, float divisor);
 int jr_avgpool2x2_forward(jr_ctx* ctx, const float* in, float* out, int planes, int H, int W);
 int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, int planes, int H,
                            int W);

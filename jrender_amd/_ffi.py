@@ -38,6 +38,7 @@ SIGNATURES = {
     "jr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jr_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jr_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "jr_memcpy2d_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "jr_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "jr_synchronize": (C.c_int, [C.c_void_p]),
     "jr_event_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -51,6 +52,9 @@ SIGNATURES = {
     "jr_face_vertices_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3),
     "jr_face_vertices_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3),
     "jr_face_vertices_backward_shared": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3),
+    "jr_camera_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float]),
+    "jr_camera_backward": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float]),
+    "jr_neg_iou_loss": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_float]),
     "jr_avgpool2x2_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_avgpool2x2_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_n3mr_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float] * 3 + [c_float_p] + [C.c_int] * 3),

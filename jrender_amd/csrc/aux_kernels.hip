@@ -120,6 +120,128 @@ __global__ __launch_bounds__(256) void k_n3mr_image_bwd(const float* __restrict_
     }
 }
 
+// Camera step of the 'look_at' / 'look' modes on DEVICE vertices (jrender/renderer/transform/look_at.py:3-39, look.py:3-54,
+// then perspective.py:4-17 or orthogonal.py:3-16; Jittor tensor ops in the reference).  The rotation (rows = camera axes)
+// and the eye of every view are O(B) host work and arrive as two small arrays; vertices are [VB,NV,3] with VB = B, or
+// VB = 1 when all views share one vertex set (demo2-deform.py:45 repeats it over the batch: here it is broadcast).
+// KIND 0: rotation only, 1: perspective (param = tan(angle)), 2: orthogonal (param = scale).
+__device__ inline void camera_point(const float* __restrict__ v, const float* __restrict__ e,
+                                    const float* __restrict__ r, float c[3]) {
+    const float d0 = v[0] - e[0], d1 = v[1] - e[1], d2 = v[2] - e[2];
+    c[0] = (d0 * r[0] + d1 * r[1]) + d2 * r[2];
+    c[1] = (d0 * r[3] + d1 * r[4]) + d2 * r[5];
+    c[2] = (d0 * r[6] + d1 * r[7]) + d2 * r[8];
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void k_camera_fwd(const float* __restrict__ v, const float* __restrict__ eye,
+                                                    const float* __restrict__ rot, float* __restrict__ out,
+                                                    int B, int VB, int NV, float param) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (view, vertex)
+    if (i >= (long)B * NV) return;
+    const int b = (int)(i / NV), n = (int)(i - (long)b * NV);
+    float c[3];
+    camera_point(v + ((long)(VB == 1 ? 0 : b) * NV + n) * 3, eye + b * 3, rot + b * 9, c);
+    float* o = out + i * 3;
+    if (KIND == 1) { o[0] = c[0] / c[2] / param; o[1] = c[1] / c[2] / param; o[2] = c[2]; }
+    else if (KIND == 2) { o[0] = c[0] * param; o[1] = c[1] * param; o[2] = c[2]; }
+    else { o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; }
+}
+// VJP of the above w.r.t. the world-space vertices.  SHARED: one thread per vertex walks the B views in order and
+// writes their sum (deterministic: no atomics), else one thread per (view, vertex).
+template <int KIND>
+__device__ inline void camera_point_vjp(const float* __restrict__ g, const float* __restrict__ v,
+                                        const float* __restrict__ e, const float* __restrict__ r, float param,
+                                        float gw[3]) {
+    float gc[3] = {g[0], g[1], g[2]};
+    if (KIND == 1) {
+        float c[3];
+        camera_point(v, e, r, c);
+        gc[0] = g[0] / c[2] / param;
+        gc[1] = g[1] / c[2] / param;
+        gc[2] = g[2] - (g[0] * c[0] + g[1] * c[1]) / (c[2] * c[2]) / param;
+    } else if (KIND == 2) {
+        gc[0] = g[0] * param; gc[1] = g[1] * param;
+    }
+    gw[0] = (gc[0] * r[0] + gc[1] * r[3]) + gc[2] * r[6];
+    gw[1] = (gc[0] * r[1] + gc[1] * r[4]) + gc[2] * r[7];
+    gw[2] = (gc[0] * r[2] + gc[1] * r[5]) + gc[2] * r[8];
+}
+template <int KIND, bool SHARED>
+__global__ __launch_bounds__(256) void k_camera_bwd(const float* __restrict__ gout, const float* __restrict__ v,
+                                                    const float* __restrict__ eye, const float* __restrict__ rot,
+                                                    float* __restrict__ gv, int B, int NV, float param) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float gw[3];
+    if (SHARED) {
+        if (i >= NV) return;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int b = 0; b < B; b++) {
+            camera_point_vjp<KIND>(gout + ((long)b * NV + i) * 3, v + i * 3, eye + b * 3, rot + b * 9, param, gw);
+            s0 += gw[0]; s1 += gw[1]; s2 += gw[2];
+        }
+        gv[i * 3 + 0] = s0; gv[i * 3 + 1] = s1; gv[i * 3 + 2] = s2;
+    } else {
+        if (i >= (long)B * NV) return;
+        const int b = (int)(i / NV);
+        camera_point_vjp<KIND>(gout + i * 3, v + i * 3, eye + b * 3, rot + b * 9, param, gw);
+        gv[i * 3 + 0] = gw[0]; gv[i * 3 + 1] = gw[1]; gv[i * 3 + 2] = gw[2];
+    }
+}
+void launch_camera_forward(hipStream_t st, const float* v, const float* eye, const float* rot, float* out, int B,
+                           int VB, int NV, int kind, float param) {
+    const unsigned grid = (unsigned)(((long)B * NV + 255) / 256);
+    if (kind == 1) k_camera_fwd<1><<<grid, 256, 0, st>>>(v, eye, rot, out, B, VB, NV, param);
+    else if (kind == 2) k_camera_fwd<2><<<grid, 256, 0, st>>>(v, eye, rot, out, B, VB, NV, param);
+    else k_camera_fwd<0><<<grid, 256, 0, st>>>(v, eye, rot, out, B, VB, NV, param);
+}
+template <int KIND>
+static void launch_camera_backward_kind(hipStream_t st, const float* gout, const float* v, const float* eye,
+                                        const float* rot, float* gv, int B, int VB, int NV, float param) {
+    if (VB == 1 && B != 1)
+        k_camera_bwd<KIND, true><<<(unsigned)((NV + 255) / 256), 256, 0, st>>>(gout, v, eye, rot, gv, B, NV, param);
+    else
+        k_camera_bwd<KIND, false><<<(unsigned)(((long)B * NV + 255) / 256), 256, 0, st>>>(gout, v, eye, rot, gv, B, NV, param);
+}
+void launch_camera_backward(hipStream_t st, const float* gout, const float* v, const float* eye, const float* rot,
+                            float* gv, int B, int VB, int NV, int kind, float param) {
+    if (kind == 1) launch_camera_backward_kind<1>(st, gout, v, eye, rot, gv, B, VB, NV, param);
+    else if (kind == 2) launch_camera_backward_kind<2>(st, gout, v, eye, rot, gv, B, VB, NV, param);
+    else launch_camera_backward_kind<0>(st, gout, v, eye, rot, gv, B, VB, NV, param);
+}
+
+// neg_iou_loss (jrender/loss/iou_loss.py:1-9) and its gradient, one workgroup per view: I = sum(p*t),
+// U = sum(p + t - p*t) + 1e-6 (float terms like the reference's, summed in double), iou[b] = I / U;
+// grad = -(t*U - I*(1 - t)) / U^2 / divisor (divisor = the number of views the mean runs over).
+__global__ __launch_bounds__(256) void k_neg_iou(const float* __restrict__ predict, const float* __restrict__ target,
+                                                 float* __restrict__ iou, float* __restrict__ grad, int n,
+                                                 float divisor) {
+    __shared__ double s_i[256], s_u[256];
+    const float* p = predict + (long)blockIdx.x * n;
+    const float* t = target + (long)blockIdx.x * n;
+    double si = 0.0, su = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float pt = p[k] * t[k];
+        si += (double)pt;
+        su += (double)(p[k] + t[k] - pt);
+    }
+    s_i[threadIdx.x] = si; s_u[threadIdx.x] = su;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { s_i[threadIdx.x] += s_i[threadIdx.x + w]; s_u[threadIdx.x] += s_u[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    const float I = (float)s_i[0];
+    const float U = (float)s_u[0] + 1e-6f;
+    if (threadIdx.x == 0) iou[blockIdx.x] = I / U;
+    if (!grad) return;
+    float* g = grad + (long)blockIdx.x * n;
+    for (int k = threadIdx.x; k < n; k += 256) g[k] = -(t[k] * U - I * (1.f - t[k])) / (U * U) / divisor;
+}
+void launch_neg_iou_loss(hipStream_t st, const float* predict, const float* target, float* iou, float* grad, int B,
+                         int n, float divisor) {
+    k_neg_iou<<<(unsigned)B, 256, 0, st>>>(predict, target, iou, grad, n, divisor);
+}
+
 void launch_n3mr_image_forward(hipStream_t st, const float* in, float* out, int B, int H, int W, int C, int pool) {
     const long total = (long)B * (H / pool) * (W / pool);
     const unsigned grid = (unsigned)((total + 255) / 256);

@@ -387,6 +387,15 @@ int jr_memcpy_d2d(jr_ctx* ctx, void* dst, const void* src, size_t bytes) {
     JR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
+int jr_memcpy2d_d2d(jr_ctx* ctx, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width,
+                    size_t height) {
+    if (!ctx) return fail("NULL context");
+    if (width > dst_pitch || width > src_pitch) return fail("jr_memcpy2d_d2d: width exceeds a pitch");
+    if (!width || !height) return 0;
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, height, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
 int jr_memset(jr_ctx* ctx, void* dptr, int value, size_t bytes) {
     if (!ctx) return fail("NULL context");
     JR_HIP(hipSetDevice(ctx->device));
@@ -539,6 +548,37 @@ int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, i
     if (planes < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail("jr_avgpool2x2: H and W must be even");
     JR_HIP(hipSetDevice(ctx->device));
     jr::launch_avgpool2x2_backward(ctx->stream, grad_out, grad_in, planes, H, W);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_camera_forward(jr_ctx* ctx, const float* vertices, const float* eye, const float* rot, float* out,
+                      int B, int VB, int NV, int kind, float param) {
+    if (!ctx || !vertices || !eye || !rot || !out) return fail("jr_camera_forward: NULL argument");
+    if (B < 1 || NV < 1 || (VB != 1 && VB != B)) return fail("jr_camera_forward: vertices must be [1 or B, NV, 3]");
+    if (kind < 0 || kind > 2) return fail("jr_camera_forward: kind must be 0 (none), 1 (perspective) or 2 (orthogonal)");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_camera_forward(ctx->stream, vertices, eye, rot, out, B, VB, NV, kind, param);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_camera_backward(jr_ctx* ctx, const float* grad_out, const float* vertices, const float* eye,
+                       const float* rot, float* grad_vertices, int B, int VB, int NV, int kind, float param) {
+    if (!ctx || !grad_out || !vertices || !eye || !rot || !grad_vertices) return fail("jr_camera_backward: NULL argument");
+    if (B < 1 || NV < 1 || (VB != 1 && VB != B)) return fail("jr_camera_backward: vertices must be [1 or B, NV, 3]");
+    if (kind < 0 || kind > 2) return fail("jr_camera_backward: kind must be 0 (none), 1 (perspective) or 2 (orthogonal)");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_camera_backward(ctx->stream, grad_out, vertices, eye, rot, grad_vertices, B, VB, NV, kind, param);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_neg_iou_loss(jr_ctx* ctx, const float* predict, const float* target, float* iou, float* grad_predict,
+                    int B, int n, float divisor) {
+    if (!ctx || !predict || !target || !iou) return fail("jr_neg_iou_loss: NULL argument");
+    if (B < 1 || n < 1) return fail("jr_neg_iou_loss: bad sizes");
+    if (grad_predict && !(divisor > 0.f)) return fail("jr_neg_iou_loss: divisor must be > 0");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_neg_iou_loss(ctx->stream, predict, target, iou, grad_predict, B, n, divisor);
     JR_HIP(hipGetLastError());
     return 0;
 }

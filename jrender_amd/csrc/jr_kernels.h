@@ -71,6 +71,12 @@ void launch_face_vertices_backward_shared(hipStream_t st, const float* gfv, cons
                                           float* gv, int B, int NV, int NF);
 void launch_avgpool2x2_forward(hipStream_t st, const float* in, float* out, int planes, int H, int W);
 void launch_avgpool2x2_backward(hipStream_t st, const float* gout, float* gin, int planes, int H, int W);
+void launch_camera_forward(hipStream_t st, const float* v, const float* eye, const float* rot, float* out, int B,
+                           int VB, int NV, int kind, float param);
+void launch_camera_backward(hipStream_t st, const float* gout, const float* v, const float* eye, const float* rot,
+                            float* gv, int B, int VB, int NV, int kind, float param);
+void launch_neg_iou_loss(hipStream_t st, const float* predict, const float* target, float* iou, float* grad, int B,
+                         int n, float divisor);
 void launch_n3mr_image_forward(hipStream_t st, const float* in, float* out, int B, int H, int W, int C, int pool);
 void launch_n3mr_image_backward(hipStream_t st, const float* gout, float* gin, int B, int H, int W, int C, int pool);
 void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textures, float* faces_inv,

@@ -7,12 +7,46 @@ Each ``*_backward`` returns d(loss)/d(input) for an upstream scalar gradient of 
 """
 import numpy as np
 
-__all__ = ["neg_iou_loss", "neg_iou_loss_backward", "LaplacianLoss", "FlattenLoss"]
+from .. import _ffi
+
+__all__ = ["neg_iou_loss", "neg_iou_loss_backward", "neg_iou_loss_and_grad", "LaplacianLoss", "FlattenLoss"]
 
 F32 = np.float32
 
 
+def neg_iou_loss_and_grad(predict, target, total_views=None):
+    """-> (iou per view [B] on the host, d(neg_iou_loss)/d(predict)).  Device ``predict`` (DeviceArray [B,...]): one
+    HIP launch (jr_neg_iou_loss) computes both and the gradient stays on the device; ``total_views`` is the number
+    of views the loss averages over when this call only sees a shard of them (default: its own batch)."""
+    if isinstance(predict, _ffi.DeviceArray):
+        ctx = predict.ctx
+        t = target if isinstance(target, _ffi.DeviceArray) else ctx.array(np.asarray(target, F32))
+        if t.size != predict.size:
+            raise ValueError("target %s does not match predict %s" % (t.shape, predict.shape))
+        B = predict.shape[0]
+        iou = ctx.empty((B,), F32)
+        grad = ctx.empty(predict.shape, F32)
+        _ffi._check(_ffi.load().jr_neg_iou_loss(ctx.handle, predict.ptr, t.ptr, iou.ptr, grad.ptr, B, predict.size // B,
+                                                float(total_views or B)))
+        return iou.numpy(), grad
+    predict, target = np.asarray(predict, F32), np.asarray(target, F32)
+    dims = tuple(range(predict.ndim))[1:]
+    I = (predict * target).sum(dims)
+    U = (predict + target - predict * target).sum(dims) + 1e-6
+    g = neg_iou_loss_backward(predict, target)
+    if total_views:
+        g = g * F32(predict.shape[0] / total_views)
+    return (I / U).astype(F32), g
+
+
 def neg_iou_loss(predict, target):
+    if isinstance(predict, _ffi.DeviceArray):
+        ctx = predict.ctx
+        t = target if isinstance(target, _ffi.DeviceArray) else ctx.array(np.asarray(target, F32))
+        B = predict.shape[0]
+        iou = ctx.empty((B,), F32)
+        _ffi._check(_ffi.load().jr_neg_iou_loss(ctx.handle, predict.ptr, t.ptr, iou.ptr, None, B, predict.size // B, 1.0))
+        return F32(1. - iou.numpy().sum() / B)
     predict, target = np.asarray(predict, F32), np.asarray(target, F32)
     dims = tuple(range(predict.ndim))[1:]
     intersect = (predict * target).sum(dims)
@@ -21,6 +55,8 @@ def neg_iou_loss(predict, target):
 
 
 def neg_iou_loss_backward(predict, target):
+    if isinstance(predict, _ffi.DeviceArray):
+        return neg_iou_loss_and_grad(predict, target)[1]
     predict, target = np.asarray(predict, F32), np.asarray(target, F32)
     dims = tuple(range(predict.ndim))[1:]
     shape = (-1,) + (1,) * (predict.ndim - 1)
@@ -159,6 +195,10 @@ class FlattenLoss:
     def backward(self, vertices, eps=1e-6):
         """d(sum over batch of the loss)/d(vertices) (divided by the batch size when average=True): reverse mode
         through the per-edge expression, scattered to the four vertices of every edge pair."""
+        return self.value_and_grad(vertices, eps)[1]
+
+    def value_and_grad(self, vertices, eps=1e-6):
+        """(__call__(vertices), backward(vertices)) from ONE evaluation of the per-edge expression."""
         vertices = np.asarray(vertices, np.float64)
         B, nv = vertices.shape[:2]
         v0, v1 = vertices[:, self.v0s], vertices[:, self.v1s]
@@ -184,7 +224,9 @@ class FlattenLoss:
             for d in range(3):
                 out[:, d] += np.bincount(flat, weights=contrib[..., d].reshape(-1), minlength=B * nv)
         out = out.reshape(B, nv, 3)
-        return (out / B if self.average else out).astype(F32)
+        loss = ((cos + 1) ** 2).sum(tuple(range(cos.ndim))[1:])
+        return ((loss.sum() / B if self.average else loss).astype(F32),
+                (out / B if self.average else out).astype(F32))
 
     def backward_fd(self, vertices, eps=1e-6, h=1e-4):
         """Gradient by symmetric differences on the (small, smooth) per-edge expression — the loss is

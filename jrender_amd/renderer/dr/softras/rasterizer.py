@@ -21,10 +21,9 @@ def _select_channels(images, c0, c1):
     n = c1 - c0
     out = images.ctx.empty((B, n, H, W) if n > 1 else (B, H, W), np.float32)
     plane = H * W * 4
-    lib = _ffi.load()
-    for b in range(B):
-        _ffi._check(lib.jr_memcpy_d2d(images.ctx.handle, out.ptr + b * n * plane,
-                                      images.ptr + (b * C + c0) * plane, n * plane))
+    # one strided copy: B rows of n planes, C planes apart in the source
+    _ffi._check(_ffi.load().jr_memcpy2d_d2d(images.ctx.handle, out.ptr, n * plane, images.ptr + c0 * plane, C * plane,
+                                            n * plane, B))
     return out
 
 
@@ -41,9 +40,7 @@ def _scatter_channels(ctx, shape, grads):
         n = c1 - c0
         if g.size != B * n * H * W:
             raise ValueError("gradient has %d elements, expected %d" % (g.size, B * n * H * W))
-        for b in range(B):
-            _ffi._check(lib.jr_memcpy_d2d(ctx.handle, out.ptr + (b * C + c0) * plane,
-                                          g.ptr + b * n * plane, n * plane))
+        _ffi._check(lib.jr_memcpy2d_d2d(ctx.handle, out.ptr + c0 * plane, C * plane, g.ptr, n * plane, n * plane, B))
     return out
 
 

@@ -6,6 +6,7 @@ HIP SoftRas kernels, ``dr_type='n3mr'`` the HIP NMR kernels (with NMR's own near
 """
 import numpy as np
 
+from .. import _ffi
 from ..structures import Mesh
 from ..structures.mesh import face_vertices_backward
 from .dr import N3mrRasterizer, SoftRasterizer
@@ -59,7 +60,8 @@ class Renderer:
             mesh = self.lighting(mesh, self.transform.eyes)
         else:
             self.lighting._last = None      # no lighting in this render: grad_textures must not reuse an earlier render's mask
-        self._world_vertices, self._faces = np.array(mesh.vertices, np.float32), mesh.faces
+        v = mesh.vertices       # device vertices are never written in place (the camera step allocates its output)
+        self._world_vertices, self._faces = v if isinstance(v, _ffi.DeviceArray) else np.array(v, np.float32), mesh.faces
         mesh = self.transform(mesh)
         return self.rasterizer(mesh, mode)
 
@@ -89,6 +91,16 @@ class Renderer:
             raise NotImplementedError("grad_vertices: look_at camera only")
         gfv, _ = self._rasterizer_backward(grad_silhouettes, grad_rgb, grad_depth)
         v = self._world_vertices
+        nf = np.asarray(self._faces).shape[-2]
+        if isinstance(v, _ffi.DeviceArray) and gfv.size == gfv.shape[0] * nf * 9:
+            # device-resident chain: scatter kernel -> camera VJP kernel; [VB,nv,3] stays on the device (VB = 1: the
+            # views share the vertex set and the result is their sum)
+            gndc = face_vertices_backward(gfv.reshape(gfv.shape[0], nf, 3, 3), self._faces, v.shape[1])
+            return self.transform.transformer.backward(gndc, v)
+        if isinstance(v, _ffi.DeviceArray):
+            v = v.numpy()
+            if v.shape[0] != gfv.shape[0]:
+                v = np.broadcast_to(v, (gfv.shape[0],) + v.shape[1:])
         gfv = self._fold_back(gfv.numpy().reshape(v.shape[0], -1, 3, 3))
         gndc = face_vertices_backward(gfv, self._faces, v.shape[1])
         return self.transform.transformer.backward(gndc, v)

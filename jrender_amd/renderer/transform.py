@@ -9,12 +9,63 @@ Transform / LookAt / Look / Projection (transform.py:10-135).
 
 ``*_backward`` functions are the hand-written vector-Jacobian products the
 reference obtained from Jittor autograd (needed for mesh-deformation loops).
+
+Device-resident vertices: ``LookAt`` / ``Look`` given a ``DeviceArray`` [VB,nv,3] run the HIP camera kernel
+(``jr_camera_forward`` / ``jr_camera_backward``; only the O(B) rotation matrices are host work) and return a
+``DeviceArray`` [B,nv,3] — VB = 1 broadcasts one vertex set over the B eyes like the reference's own
+``vertices - eye[:, None, :]`` does, and its backward is the sum over the views.
 """
 import math
 
 import numpy as np
 
+from .. import _ffi
+
 F32 = np.float32
+
+
+def _is_device(x):
+    return isinstance(x, _ffi.DeviceArray)
+
+
+class _CameraOnDevice:
+    """eye [B,3] / rotation [B,9] of the views on the device (re-uploaded only when they change) + the two launches."""
+
+    def __init__(self):
+        self._key, self._eye_d, self._rot_d = None, None, None
+
+    def _views(self, ctx, eye, rot):
+        eye = np.ascontiguousarray(eye, F32).reshape(-1, 3)
+        rot = np.ascontiguousarray(rot, F32).reshape(-1, 9)
+        key = (id(ctx), eye.tobytes(), rot.tobytes())
+        if key != self._key:
+            self._eye_d, self._rot_d, self._key = ctx.array(eye), ctx.array(rot), key
+        return eye.shape[0]
+
+    def forward(self, vertices, eye, rot, kind, param):
+        if vertices.ndim != 3 or vertices.shape[2] != 3 or vertices.dtype != F32:
+            raise ValueError('vertices Tensor should have 3 dimensions')
+        ctx = vertices.ctx
+        B = self._views(ctx, eye, rot)
+        VB, NV = vertices.shape[:2]
+        if VB != 1 and VB != B:
+            raise ValueError("vertices batch %d does not match %d eyes" % (VB, B))
+        out = ctx.empty((B, NV, 3), F32)
+        _ffi._check(_ffi.load().jr_camera_forward(ctx.handle, vertices.ptr, self._eye_d.ptr, self._rot_d.ptr, out.ptr,
+                                                  B, VB, NV, int(kind), float(param)))
+        return out
+
+    def backward(self, grad_out, vertices, eye, rot, kind, param):
+        ctx = vertices.ctx
+        B = self._views(ctx, eye, rot)
+        VB, NV = vertices.shape[:2]
+        g = grad_out if _is_device(grad_out) else ctx.array(np.asarray(grad_out, F32))
+        if g.size != B * NV * 3:
+            raise ValueError("grad_out must be [%d, %d, 3], got %s" % (B, NV, g.shape))
+        gv = ctx.empty((VB, NV, 3), F32)
+        _ffi._check(_ffi.load().jr_camera_backward(ctx.handle, g.ptr, vertices.ptr, self._eye_d.ptr, self._rot_d.ptr,
+                                                   gv.ptr, B, VB, NV, int(kind), float(param)))
+        return gv
 
 
 def _normalize(v, eps=1e-5, axis=-1):
@@ -79,13 +130,19 @@ def look(vertices, eye, direction=(0, 1, 0), up=None, coordinate="right"):
     vertices = np.asarray(vertices, F32)
     if vertices.ndim != 3:
         raise ValueError('vertices Tensor should have 3 dimensions')
+    eye, r = _look_rotation(eye, direction, up, coordinate, vertices.shape[0])
+    v = vertices - eye[:, None, :]
+    return np.matmul(v, r.transpose(0, 2, 1)).astype(F32)
+
+
+def _look_rotation(eye, direction, up, coordinate, batch_size):
     direction = np.asarray(direction, F32)
     up = np.asarray([0, 1, 0] if up is None else up, F32)
     z_axis = _normalize(direction, axis=0)
     up = _normalize(up, axis=0)
     if abs(float(np.sum(up * z_axis))) > 1 - 1e-4:
         raise ValueError("camera_direction and camera_up can not be the same")
-    bs = vertices.shape[0]
+    bs = batch_size
     eye, z_axis, up = _as_batch(eye, bs), _as_batch(z_axis, bs), _as_batch(up, bs)
     if coordinate == "right":
         x_axis = _normalize(np.cross(up, z_axis))
@@ -95,9 +152,7 @@ def look(vertices, eye, direction=(0, 1, 0), up=None, coordinate="right"):
         y_axis = _normalize(np.cross(x_axis, z_axis))
     else:
         raise ValueError("coordinate must be 'right' or 'left'")
-    r = np.stack([x_axis, y_axis, z_axis], axis=1)
-    v = vertices - eye[:, None, :]
-    return np.matmul(v, r.transpose(0, 2, 1)).astype(F32)
+    return eye, np.stack([x_axis, y_axis, z_axis], axis=1).astype(F32)
 
 
 def perspective(vertices, angle=30.):
@@ -187,7 +242,24 @@ class LookAt:
         if self._eye is None:
             self._eye = [0, 0, -(1. / math.tan(math.radians(self.viewing_angle)) + 1)]
 
+    def _projection_kind(self):
+        if self.perspective:
+            return 1, float(np.tan(F32(self.viewing_angle / 180 * math.pi)).astype(F32))
+        return 2, float(F32(self.viewing_scale))
+
+    def _device_views(self, vertices):
+        # eyes [B,3] decide the number of views; a single eye follows the vertices' batch (look_at.py:24-30)
+        nviews = np.asarray(self._eye).shape[0] if np.ndim(self._eye) == 2 else vertices.shape[0]
+        key = (nviews, np.asarray(self._eye, F32).tobytes())
+        if getattr(self, "_views_key", None) != key:           # the rotations only change with the eyes
+            self._views_key, self._views = key, _look_at_rotation(self._eye, (0, 0, 0), (0, 1, 0), nviews)
+        return self._views
+
     def __call__(self, vertices):
+        if _is_device(vertices):
+            eye, rot = self._device_views(vertices)
+            self._dev = getattr(self, "_dev", None) or _CameraOnDevice()
+            return self._dev.forward(vertices, eye, rot, *self._projection_kind())
         vertices = look_at(vertices, self._eye)
         if self.perspective:
             return perspective(vertices, angle=self.viewing_angle)
@@ -195,6 +267,10 @@ class LookAt:
 
     def backward(self, grad_out, vertices_in):
         """VJP w.r.t. the world-space vertices given the same input as __call__."""
+        if _is_device(vertices_in):
+            eye, rot = self._device_views(vertices_in)
+            self._dev = getattr(self, "_dev", None) or _CameraOnDevice()
+            return self._dev.backward(grad_out, vertices_in, eye, rot, *self._projection_kind())
         cam = look_at(vertices_in, self._eye)
         if self.perspective:
             g = perspective_backward(grad_out, cam, angle=self.viewing_angle)
@@ -220,6 +296,12 @@ class Look:
             self._eye = [0, 0, -(1. / math.tan(math.radians(self.viewing_angle)) + 1)]
 
     def __call__(self, vertices):
+        if _is_device(vertices):
+            nviews = np.asarray(self._eye).shape[0] if np.ndim(self._eye) == 2 else vertices.shape[0]
+            eye, rot = _look_rotation(self._eye, self.camera_direction, self.up, self.coordinate, nviews)
+            self._dev = getattr(self, "_dev", None) or _CameraOnDevice()
+            kind, param = LookAt._projection_kind(self)
+            return self._dev.forward(vertices, eye, rot, kind, param)
         vertices = look(vertices, self._eye, self.camera_direction, up=self.up,
                         coordinate=self.coordinate)
         if self.perspective:

@@ -11,13 +11,58 @@ from typing import List
 
 import numpy as np
 
+from .. import _ffi
+
 __all__ = ["Mesh", "face_vertices", "join_meshes_as_scene"]
 
 F32 = np.float32
 
+_device_cache = {}          # (context id, kind, shape, content hash) -> DeviceArray: face arrays / default textures
+
+
+def _cached_device(ctx, kind, shape, content, make):
+    key = (id(ctx), kind, tuple(shape), hash(content))
+    hit = _device_cache.get(key)
+    if hit is None or hit.ctx is not ctx or hit.ptr is None:
+        if len(_device_cache) >= 16:
+            _device_cache.pop(next(iter(_device_cache)))
+        hit = _device_cache[key] = make()
+    return hit
+
+
+def _shared_faces(faces):
+    """faces [B,NF,3] -> the [NF,3] all views share, or None when the views have different faces."""
+    if faces.shape[0] == 1 or faces.strides[0] == 0:
+        return faces[0]
+    return faces[0] if all(np.array_equal(faces[0], faces[b]) for b in range(1, faces.shape[0])) else None
+
+
+def device_faces(ctx, faces):
+    """[NF,3] int32 on the device, uploaded once per distinct face array."""
+    f = np.ascontiguousarray(faces, np.int32)
+    return _cached_device(ctx, "faces", f.shape, f.tobytes(), lambda: ctx.array(f))
+
 
 def face_vertices(vertices, faces):
-    """faces_vertices.py:4-19: vertices [B,NV,C] x faces [B,NF,3] -> [B,NF,3,C]."""
+    """faces_vertices.py:4-19: vertices [B,NV,C] x faces [B,NF,3] -> [B,NF,3,C].  Device vertices [B,NV,3]: the HIP gather
+    (jr_face_vertices_forward) when the views share one face array, one launch per view otherwise."""
+    if isinstance(vertices, _ffi.DeviceArray):
+        faces = np.asarray(faces)
+        assert vertices.ndim == 3 and faces.ndim == 3 and vertices.shape[2] == 3
+        assert faces.shape[0] in (1, vertices.shape[0])
+        assert faces.shape[2] == 3
+        ctx, lib = vertices.ctx, _ffi.load()
+        B, NV = vertices.shape[:2]
+        NF = faces.shape[1]
+        out = ctx.empty((B, NF, 3, 3), F32)
+        shared = _shared_faces(faces)
+        if shared is not None:
+            _ffi._check(lib.jr_face_vertices_forward(ctx.handle, vertices.ptr, device_faces(ctx, shared).ptr, out.ptr, B, NV, NF))
+        else:
+            for b in range(B):
+                _ffi._check(lib.jr_face_vertices_forward(ctx.handle, vertices.view(b, b + 1).ptr, device_faces(ctx, faces[b]).ptr,
+                                                         out.view(b, b + 1).ptr, 1, NV, NF))
+        return out
     vertices = np.asarray(vertices)
     faces = np.asarray(faces)
     assert vertices.ndim == 3 and faces.ndim == 3
@@ -28,7 +73,23 @@ def face_vertices(vertices, faces):
 
 
 def face_vertices_backward(grad_fv, faces, num_vertices):
-    """Scatter-add VJP of face_vertices (was Jittor autograd): [B,NF,3,C] -> [B,NV,C]."""
+    """Scatter-add VJP of face_vertices (was Jittor autograd): [B,NF,3,C] -> [B,NV,C].  Device gradients [B,NF,3,3]: the HIP
+    scatter (jr_face_vertices_backward; float atomics, i.e. summation order varies in the last bits)."""
+    if isinstance(grad_fv, _ffi.DeviceArray):
+        faces = np.asarray(faces)
+        ctx, lib = grad_fv.ctx, _ffi.load()
+        B, NF = grad_fv.shape[:2]
+        assert grad_fv.size == B * NF * 9 and faces.shape[-2] == NF
+        out = ctx.empty((B, int(num_vertices), 3), F32)
+        shared = _shared_faces(faces.reshape((-1,) + faces.shape[-2:]))
+        if shared is not None:
+            _ffi._check(lib.jr_face_vertices_backward(ctx.handle, grad_fv.ptr, device_faces(ctx, shared).ptr, out.ptr, B,
+                                                      int(num_vertices), NF))
+        else:
+            for b in range(B):
+                _ffi._check(lib.jr_face_vertices_backward(ctx.handle, grad_fv.view(b, b + 1).ptr, device_faces(ctx, faces[b]).ptr,
+                                                          out.view(b, b + 1).ptr, 1, int(num_vertices), NF))
+        return out
     grad_fv = np.asarray(grad_fv, F32)
     faces = np.asarray(faces).astype(np.int64)
     B, NF = faces.shape[:2]
@@ -48,10 +109,12 @@ class Mesh(object):
     def __init__(self, vertices, faces, textures=None, texture_res=1, texture_type='surface',
                  dr_type='softras', metallic_textures=None, roughness_textures=None,
                  normal_textures=None, TBN=None, with_SSS=False, face_texcoords=None):
-        self._vertices = np.asarray(vertices, F32)
+        # vertices may live on the device (DeviceArray [B,NV,3], float32): the camera transform, the face gather and
+        # the rasteriser then run without a host round trip; normals / lighting still take the host arrays
+        self._vertices = vertices if isinstance(vertices, _ffi.DeviceArray) else np.asarray(vertices, F32)
         self._faces = np.asarray(faces).astype(np.int32)
         if self._vertices.ndim == 2:
-            self._vertices = self._vertices[None]
+            self._vertices = self._vertices.reshape((1,) + tuple(self._vertices.shape))
         if self._faces.ndim == 2:
             self._faces = self._faces[None]
         self.texture_type = texture_type
@@ -86,6 +149,7 @@ class Mesh(object):
         self._metallic_textures = np.zeros(tshape + (1,), F32) if metallic_textures is None else np.asarray(metallic_textures, F32)
         self._roughness_textures = np.ones(tshape + (1,), F32) if roughness_textures is None else np.asarray(roughness_textures, F32)
 
+        self._default_textures = textures is None
         if textures is None:
             self._textures = np.ones(tshape + (3,), F32)
             self.texture_res = texture_res if texture_type == 'surface' else 1
@@ -107,6 +171,7 @@ class Mesh(object):
         self._origin_vertices = self._vertices
         self._origin_faces = self._faces
         self._origin_textures = self._textures
+        self._origin_default_textures = self._default_textures
 
     # ---- properties (MESH:143-211) ----
     @property
@@ -137,7 +202,7 @@ class Mesh(object):
 
     @vertices.setter
     def vertices(self, vertices):
-        self._vertices = np.asarray(vertices, F32)
+        self._vertices = vertices if isinstance(vertices, _ffi.DeviceArray) else np.asarray(vertices, F32)
         self.num_vertices = self._vertices.shape[1]
         self._face_vertices_update = self._surface_normals_update = self._vertex_normals_update = True
 
@@ -148,6 +213,7 @@ class Mesh(object):
     @textures.setter
     def textures(self, textures):
         self._textures = np.asarray(textures, F32)
+        self._default_textures = False
 
     @property
     def metallic_textures(self):
@@ -184,7 +250,7 @@ class Mesh(object):
     def surface_normals(self):
         """MESH:213-229: cross(v2-v1, v0-v1) normalised, evaluated in float64 like the reference."""
         if self._surface_normals_update:
-            fv = self.face_vertices.astype(np.float64)
+            fv = np.asarray(self.face_vertices).astype(np.float64)      # device vertices: normals are host work
             v10 = fv[:, :, 0] - fv[:, :, 1]
             v12 = fv[:, :, 2] - fv[:, :, 1]
             self._surface_normals = _normalize(np.cross(v12, v10), 1e-12, 2).astype(F32)
@@ -195,7 +261,7 @@ class Mesh(object):
     def vertex_normals(self):
         """MESH:231-248: area-weighted sum of the incident corner normals, normalised (eps 1e-6)."""
         if self._vertex_normals_update:
-            fv = self.face_vertices
+            fv = np.asarray(self.face_vertices)
             n1 = np.cross(fv[:, :, 2] - fv[:, :, 1], fv[:, :, 0] - fv[:, :, 1])
             n2 = np.cross(fv[:, :, 0] - fv[:, :, 2], fv[:, :, 1] - fv[:, :, 2])
             n0 = np.cross(fv[:, :, 1] - fv[:, :, 0], fv[:, :, 2] - fv[:, :, 0])
@@ -211,6 +277,18 @@ class Mesh(object):
 
     @property
     def face_textures(self):
+        if isinstance(self._vertices, _ffi.DeviceArray) and self.texture_type == 'surface':
+            # device path: one texture block per VIEW (the camera step may have broadcast one vertex set over B eyes)
+            ctx, B = self._vertices.ctx, self._vertices.shape[0]
+            shape = (B,) + tuple(self._textures.shape[1:])
+            if self._default_textures:
+                return _cached_device(ctx, "ones", shape, 1, lambda: ctx.array(np.ones(shape, F32)))
+            t = self._textures
+            if t.shape[0] != B:
+                if t.shape[0] != 1:
+                    raise ValueError("textures batch %d does not match %d views" % (t.shape[0], B))
+                t = np.broadcast_to(t, shape)
+            return ctx.array(t)
         if self.texture_type in ['surface']:
             return self.textures
         elif self.texture_type in ['vertex']:
@@ -227,6 +305,7 @@ class Mesh(object):
         self.vertices = self._origin_vertices
         self.faces = self._origin_faces
         self.textures = self._origin_textures
+        self._default_textures = self._origin_default_textures
         self._fill_back = False
 
     @classmethod

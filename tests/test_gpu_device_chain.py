@@ -1,0 +1,177 @@
+"""The callers either side of the op, device-resident (BASELINE configs[3]).
+
+The reference runs camera transform, face gather, loss and their backward as Jittor tensor ops on the GPU
+(transform/look_at.py:3-39, look.py:3-54, perspective.py:4-17, orthogonal.py:3-16, structures/utils/faces_vertices.py:4-19,
+loss/iou_loss.py:1-9).  The NumPy mirrors of those files are pinned to the reference's own Python
+(tests/test_host_reference.py); the HIP kernels behind `DeviceArray` vertices are held to the mirrors here:
+element-wise float32 steps to a few ulp, sums to 1e-6 of their scale, and the whole demo2 chain
+(camera -> gather -> SoftRas -> IoU -> SoftRas backward -> scatter -> camera VJP) to the host chain's loss curve.
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import jrender_amd as jr
+from jrender_amd import _ffi
+from jrender_amd.renderer import transform as T
+from jrender_amd.structures.mesh import face_vertices, face_vertices_backward
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return _ffi.Context.default()
+
+
+def close(a, b, rtol, atol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return bool(np.all(np.abs(a - b) <= atol + rtol * np.abs(b)))
+
+
+def ring(n, seed=0):
+    r = np.random.default_rng(seed)
+    return (r.uniform(2.0, 3.5, n).astype(np.float32), r.uniform(-60, 60, n).astype(np.float32),
+            r.uniform(0, 360, n).astype(np.float32))
+
+
+@pytest.mark.parametrize("perspective", [True, False])
+@pytest.mark.parametrize("shared", [True, False])
+def test_look_at_camera_forward_and_vjp(ctx, perspective, shared):
+    B, NV = 7, 1000
+    r = np.random.default_rng(3)
+    v = r.uniform(-0.6, 0.6, (1 if shared else B, NV, 3)).astype(np.float32)
+    cam = T.LookAt(perspective=perspective, viewing_angle=15, viewing_scale=0.8)
+    cam._eye = T.get_points_from_angles(*ring(B))
+    host_in = np.repeat(v, B, 0) if shared else v
+    want = cam(host_in)
+    got = cam(ctx.array(v))
+    assert isinstance(got, _ffi.DeviceArray) and got.shape == (B, NV, 3)
+    assert close(got.numpy(), want, 3e-6, 1e-6)
+    g = r.uniform(-1, 1, (B, NV, 3)).astype(np.float32)
+    want_g = cam.backward(g, host_in)
+    if shared:
+        want_g = want_g.astype(np.float64).sum(0, keepdims=True)
+    got_g = cam.backward(ctx.array(g), ctx.array(v))
+    assert got_g.shape == v.shape
+    assert close(got_g.numpy(), want_g, 1e-5, 1e-5 * np.abs(want_g).max())
+
+
+def test_single_eye_follows_the_vertex_batch(ctx):
+    v = np.random.default_rng(5).uniform(-0.5, 0.5, (3, 50, 3)).astype(np.float32)
+    cam = T.LookAt(viewing_angle=30)                       # default eye: one 3-vector (transform.py:44-45)
+    assert close(cam(ctx.array(v)).numpy(), cam(v), 3e-6, 1e-6)
+    with pytest.raises(ValueError):
+        cam._eye = T.get_points_from_angles(*ring(2))
+        cam(ctx.array(v))                                  # 3 vertex sets, 2 eyes
+
+
+@pytest.mark.parametrize("coordinate", ["right", "left"])
+def test_look_camera_forward(ctx, coordinate):
+    v = np.random.default_rng(6).uniform(-0.5, 0.5, (4, 300, 3)).astype(np.float32)
+    cam = T.Look(camera_direction=(0.2, -0.1, 1.0), viewing_angle=20, eye=[0.1, 0.2, -2.5], coordinate=coordinate)
+    assert close(cam(ctx.array(v)).numpy(), cam(v), 3e-6, 1e-6)
+
+
+def test_face_gather_and_scatter(ctx):
+    v, f = jr.synthetic.uv_sphere(20, 11)
+    B = 5
+    vb = (v[None] * np.linspace(0.5, 1.5, B, dtype=np.float32)[:, None, None]).astype(np.float32)
+    fb = np.repeat(f[None], B, 0)
+    got = face_vertices(ctx.array(vb), fb)
+    assert np.array_equal(got.numpy(), face_vertices(vb, fb))          # a gather: bit for bit
+    # views with DIFFERENT face arrays take one launch per view
+    fb2 = fb.copy()
+    fb2[1] = fb2[1][:, [2, 1, 0]]
+    assert np.array_equal(face_vertices(ctx.array(vb), fb2).numpy(), face_vertices(vb, fb2))
+    g = np.random.default_rng(7).uniform(-1, 1, (B, f.shape[0], 3, 3)).astype(np.float32)
+    for faces in (fb, fb2):
+        want = face_vertices_backward(g, faces, v.shape[0])
+        got = face_vertices_backward(ctx.array(g), faces, v.shape[0]).numpy()
+        assert close(got, want, 1e-5, 1e-6 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 64), (3, 1, 37, 41), (1, 5)])
+def test_neg_iou_loss_and_gradient(ctx, shape):
+    r = np.random.default_rng(9)
+    p = r.uniform(0, 1, shape).astype(np.float32)
+    t = (r.uniform(0, 1, shape) > 0.6).astype(np.float32)
+    iou, g = jr.neg_iou_loss_and_grad(ctx.array(p), ctx.array(t))
+    iou_h, g_h = jr.neg_iou_loss_and_grad(p, t)
+    assert close(iou, iou_h, 2e-6, 0) and g.shape == p.shape
+    assert close(g.numpy(), g_h, 1e-5, 1e-6 * np.abs(g_h).max())
+    assert close(jr.neg_iou_loss(ctx.array(p), t), jr.neg_iou_loss(p, t), 2e-6, 1e-7)
+    assert close(jr.neg_iou_loss_backward(ctx.array(p), t).numpy(), jr.neg_iou_loss_backward(p, t), 1e-5, 1e-6 * np.abs(g_h).max())
+    # a shard of a larger batch: the mean runs over total_views
+    _, g2 = jr.neg_iou_loss_and_grad(ctx.array(p), ctx.array(t), total_views=4 * shape[0])
+    assert close(g2.numpy(), g_h / 4, 1e-5, 1e-6 * np.abs(g_h).max())
+
+
+def test_all_zero_view_does_not_divide_by_zero(ctx):
+    p = np.zeros((2, 16, 16), np.float32)
+    iou, g = jr.neg_iou_loss_and_grad(ctx.array(p), ctx.array(p))
+    assert np.array_equal(iou, np.zeros(2, np.float32)) and np.isfinite(g.numpy()).all()
+
+
+def _renderer(views, size=64):
+    r = jr.Renderer(image_size=size, sigma_val=1e-4, aggr_func_rgb='hard', camera_mode='look_at', viewing_angle=15,
+                    dr_type='softras')
+    r.transform.set_eyes_from_angles(*ring(views, seed=11))
+    return r
+
+
+def test_renderer_chain_device_vs_host(ctx):
+    """render_mesh / grad_vertices with ONE device vertex set against the host chain.  The camera kernel and NumPy's
+    matmul round differently in the last place, and faces seen edge-on at the limb amplify one ulp into a visibly
+    different pixel - so the host chain rasterises the DEVICE camera's output (the camera itself is held to 3e-6
+    above): the images must then agree bit for bit, the gradient up to the order of the float atomics."""
+    v, f = jr.synthetic.uv_sphere(36, 19)
+    v = (v * np.asarray([0.5, 0.35, 0.45], np.float32))[None]
+    B, nv = 6, v.shape[1]
+    target = (np.random.default_rng(1).uniform(0, 1, (B, 64, 64)) > 0.5).astype(np.float32)
+    rh, rd = _renderer(B), _renderer(B)
+    sil_d = rd.render_mesh(jr.Mesh(ctx.array(v), f), mode='silhouettes')
+    assert isinstance(sil_d, _ffi.DeviceArray) and sil_d.shape == (B, 64, 64)
+    cam = rd.transform.transformer(ctx.array(v)).numpy()                       # [B,nv,3]
+    fb = np.repeat(f[None], B, 0)
+    sil_h = rh.rasterizer(jr.Mesh(cam, fb), 'silhouettes').numpy()
+    assert np.array_equal(sil_d.numpy(), sil_h.reshape(B, 64, 64))
+    # the whole host chain (its own camera) differs only where an edge-on face flips: a handful of pixels
+    sil_hh = rh.render_mesh(jr.Mesh(np.repeat(v, B, 0), fb), mode='silhouettes').numpy().reshape(B, 64, 64)
+    assert (np.abs(sil_hh - sil_h.reshape(B, 64, 64)) > 2e-3).mean() <= 2e-3
+    rh.rasterizer(jr.Mesh(cam, fb), 'silhouettes')
+    g_h = jr.neg_iou_loss_backward(sil_h.reshape(B, 64, 64), target)
+    gfv_h, _ = rh.rasterizer.backward(grad_silhouettes=g_h.reshape(B, 1, 64, 64))
+    gndc_h = face_vertices_backward(gfv_h.numpy().reshape(B, -1, 3, 3), fb, nv)
+    gv_h = rh.transform.transformer.backward(gndc_h, np.repeat(v, B, 0)).astype(np.float64).sum(0, keepdims=True)
+    _, g_d = jr.neg_iou_loss_and_grad(sil_d, target)
+    gv_d = rd.grad_vertices(grad_silhouettes=g_d)
+    assert isinstance(gv_d, _ffi.DeviceArray) and gv_d.shape == (1, nv, 3)
+    assert np.abs(gv_d.numpy() - gv_h).max() <= 1e-4 * np.abs(gv_h).max()
+
+
+def test_rgb_mode_with_device_vertices_and_textures(ctx):
+    """Textured surface render from device vertices: one texture block broadcast over the views."""
+    v, f = jr.synthetic.uv_sphere(24, 13)
+    tex = np.random.default_rng(2).uniform(0, 1, (1, f.shape[0], 4, 3)).astype(np.float32)
+    B = 3
+    rh, rd = _renderer(B), _renderer(B)
+    md = rd.transform(jr.Mesh(ctx.array(v[None] * 0.5), f, textures=tex))
+    got = rd.rasterizer(md, 'rgb').numpy()
+    want = rh.rasterizer(jr.Mesh(md.vertices.numpy(), np.repeat(f[None], B, 0), textures=np.repeat(tex, B, 0)), 'rgb').numpy()
+    assert got.shape == want.shape == (B, 3, 64, 64) and np.array_equal(got, want)
+
+
+def test_demo2_front_ends_give_the_same_loss_curve():
+    spec = importlib.util.spec_from_file_location("demo2", os.path.join(os.path.dirname(GOLD), "..", "examples", "demo2_deform.py"))
+    demo2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo2)
+    common = ["-b", "16", "--iters", "12", "--quiet"]
+    dev = demo2.main(common + ["--front-end", "device"])
+    host = demo2.main(common + ["--front-end", "host"])
+    assert dev[-1] < dev[0] - 0.02
+    assert np.abs(np.asarray(dev) - np.asarray(host)).max() <= 2e-3, (dev, host)

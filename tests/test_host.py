@@ -203,6 +203,11 @@ def test_flatten_loss_analytic_backward_matches_central_differences():
         xm[0, i, d] -= h
         num = (total(xp) - total(xm)) / (2 * h)
         assert abs(num - g[0, i, d]) <= 1e-5 * max(1.0, abs(num))
+    # one evaluation for both: the same value and the same gradient, batched input and the mean variant included
+    xb = np.concatenate([x, x * 0.9], 0)
+    for loss in (fl, jr.FlattenLoss(f, average=True)):
+        val, grad = loss.value_and_grad(xb)
+        assert np.array_equal(val, loss(xb)) and np.array_equal(grad, loss.backward(xb))
 
 
 def _cook_torrance_f64(n, pos, eye, ldir, lint, lcol, metallic, roughness):

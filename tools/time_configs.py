@@ -42,7 +42,16 @@ rows = [("C1 spot cow 5 856 faces T=25, 256^2, B=1 (silhouette config)", spot["f
         ("C4-like sphere 3 300 faces, 64^2, B=64, sigma 1e-4, hard rgb", *syn.sphere_views(3300, 64), 64, dict(sigma_val=1e-4, aggr_func_rgb="hard"))]
 for name, fv, tex, IS, kw in rows:
     print("%-66s %8.3f ms fwd+bwd" % (name, timed(fv, tex, IS, **kw)), flush=True)
-t0 = time.time()
+import re
 import subprocess
-out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "demo2_deform.py"), "--iters", "60", "--quiet"], capture_output=True, text=True)
-print("demo2_deform.py, 60 iterations, 64 views at 64^2, 1 rank: %.1f ms per iteration (whole process %.1f s)" % ((time.time() - t0) / 60 * 1e3, time.time() - t0))
+# C4 (BASELINE configs[3]): the optimisation LOOP of demo2 (the script's own clock around its iterations; process start,
+# context creation and the synthetic targets are outside), with the chain around the rasteriser on the device and on the host
+for fe in ("device", "host"):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "demo2_deform.py"), "--iters", "200", "--front-end", fe],
+                         capture_output=True, text=True)
+    m = re.search(r"(\d+) iterations, (\d+) views on (\d+) rank\(s\): ([0-9.]+) s", out.stdout)
+    if not m:
+        print("demo2_deform.py --front-end %s FAILED\n%s" % (fe, (out.stdout + out.stderr)[-1500:]))
+        continue
+    print("demo2_deform.py --front-end %-6s: %s iterations, %s views at 64^2, 1 rank: %.2f ms per iteration"
+          % (fe, m.group(1), m.group(2), float(m.group(4)) / int(m.group(1)) * 1e3), flush=True)
