@@ -91,6 +91,7 @@ def main(argv=None):
     ap.add_argument('--template-vertices', default=None, help=".obj, or .npz with 'vertices' / 'faces' (default: a 1 352-vertex UV sphere)")
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--gpus', type=int, default=1, help="spawn this many ranks (one process per GPU)")
+    ap.add_argument('--history-out', default=None, help="rank 0 writes the loss of every iteration to this .npy")
     ap.add_argument('--front-end', choices=['device', 'host'], default='device',
                     help="where the camera / gather / loss steps around the rasteriser run (see the module docstring)")
     args = ap.parse_args(argv)
@@ -140,10 +141,13 @@ def main(argv=None):
             mesh = jr.Mesh(ctx.array(vertices), model.faces)
             pred = renderer.render_mesh(mesh, mode='silhouettes')             # DeviceArray [nb,IS,IS]
             iou, g_sil = jr.neg_iou_loss_and_grad(pred, target_d, total_views=B)
-            iou_sum = float(iou.sum())
             g_v = renderer.grad_vertices(grad_silhouettes=g_sil)              # DeviceArray [1,nv,3]: summed over the views
             if comm is not None:
                 g_v = comm.all_reduce_sum(g_v)           # RCCL on the device buffer
+            # everything above is enqueued, nothing has waited for the GPU: the regularisers (host, O(nv)) run meanwhile
+            reg = (model.laplacian_loss(vertices), model.laplacian_loss.backward(vertices)) + model.flatten_loss.value_and_grad(vertices)
+            iou_sum = float(iou.numpy().sum())
+            if comm is not None:
                 iou_sum = comm.all_reduce_scalar(iou_sum, "sum")
             g_v = g_v.numpy()
         else:
@@ -158,17 +162,18 @@ def main(argv=None):
             if comm is not None:
                 g_v = comm.all_reduce_sum_host(g_v)          # [1,nv,3]: the mesh is shared by all views
                 iou_sum = comm.all_reduce_scalar(iou_sum, "sum")
-        lap = float(np.mean(model.laplacian_loss(vertices)))
-        flat, g_flat = model.flatten_loss.value_and_grad(vertices)
-        flat = float(np.mean(flat))
+            reg = (model.laplacian_loss(vertices), model.laplacian_loss.backward(vertices)) + model.flatten_loss.value_and_grad(vertices)
+        lap, flat = float(np.mean(reg[0])), float(np.mean(reg[2]))
         loss = (1.0 - iou_sum / B) + 0.03 * lap + 0.0003 * flat
-        g_v = g_v + 0.03 * model.laplacian_loss.backward(vertices) + 0.0003 * g_flat
+        g_v = g_v + 0.03 * reg[1] + 0.0003 * reg[3]
         optimizer.step(model.backward(g_v))
         history.append(loss)
         if rank == 0 and not args.quiet and (it % 20 == 0 or it == args.iters - 1):
             print("iter %4d  loss %.4f  (1-IoU %.4f, laplacian %.4f, flatten %.4f)" % (it, loss, 1.0 - iou_sum / B, lap, flat), flush=True)
     if rank == 0 and not args.quiet:
         print("%d iterations, %d views on %d rank(s): %.2f s" % (args.iters, B, world, time.time() - t0))
+    if rank == 0 and args.history_out:
+        np.save(args.history_out, np.asarray(history, np.float64))
     if rank == 0 and args.output:
         jr.save_obj(args.output, model.forward()[0], model.faces[0])
     if comm is not None:

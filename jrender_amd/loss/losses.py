@@ -15,9 +15,10 @@ F32 = np.float32
 
 
 def neg_iou_loss_and_grad(predict, target, total_views=None):
-    """-> (iou per view [B] on the host, d(neg_iou_loss)/d(predict)).  Device ``predict`` (DeviceArray [B,...]): one
-    HIP launch (jr_neg_iou_loss) computes both and the gradient stays on the device; ``total_views`` is the number
-    of views the loss averages over when this call only sees a shard of them (default: its own batch)."""
+    """-> (iou per view [B], d(neg_iou_loss)/d(predict)); the loss is 1 - mean(iou).  Device ``predict`` (DeviceArray
+    [B,...]): one HIP launch (jr_neg_iou_loss) computes both and BOTH stay on the device (nothing waits for the GPU:
+    read ``iou.numpy()`` when the number is needed); ``total_views`` is the number of views the loss averages over
+    when this call only sees a shard of them (default: its own batch)."""
     if isinstance(predict, _ffi.DeviceArray):
         ctx = predict.ctx
         t = target if isinstance(target, _ffi.DeviceArray) else ctx.array(np.asarray(target, F32))
@@ -28,7 +29,7 @@ def neg_iou_loss_and_grad(predict, target, total_views=None):
         grad = ctx.empty(predict.shape, F32)
         _ffi._check(_ffi.load().jr_neg_iou_loss(ctx.handle, predict.ptr, t.ptr, iou.ptr, grad.ptr, B, predict.size // B,
                                                 float(total_views or B)))
-        return iou.numpy(), grad
+        return iou, grad
     predict, target = np.asarray(predict, F32), np.asarray(target, F32)
     dims = tuple(range(predict.ndim))[1:]
     I = (predict * target).sum(dims)
