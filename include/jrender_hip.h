@@ -149,6 +149,11 @@ int jr_camera_forward(jr_ctx* ctx, const float* vertices, const float* eye, cons
                       int B, int VB, int NV, int kind, float param);
 int jr_camera_backward(jr_ctx* ctx, const float* grad_out, const float* vertices, const float* eye,
                        const float* rot, float* grad_vertices, int B, int VB, int NV, int kind, float param);
+/* jr_face_vertices_backward_shared and jr_camera_backward (VB == 1) in one pass: grad_face_vertices [B,NF,9] in NDC
+ * space -> d/d(the ONE world-space vertex set) [NV,3], summed over faces and views (float atomics per face corner). */
+int jr_face_camera_backward_shared(jr_ctx* ctx, const float* grad_face_vertices, const int32_t* faces,
+                                   const float* vertices, const float* eye, const float* rot, float* grad_vertices,
+                                   int B, int NV, int NF, int kind, float param);
 /* neg_iou_loss (jrender/loss/iou_loss.py:1-9) per view: iou[b] = sum(p*t) / (sum(p + t - p*t) + 1e-6) over the n
  * elements of view b (the loss is 1 - mean(iou)); grad_predict (may be NULL) = d(loss)/d(predict) with the mean
  * taken over `divisor` views (the whole batch when the views are sharded over ranks). */

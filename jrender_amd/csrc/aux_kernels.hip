@@ -187,6 +187,39 @@ __global__ __launch_bounds__(256) void k_camera_bwd(const float* __restrict__ go
         gv[i * 3 + 0] = gw[0]; gv[i * 3 + 1] = gw[1]; gv[i * 3 + 2] = gw[2];
     }
 }
+// Scatter-add of the face-vertex gradients AND the camera VJP in one pass for views that share ONE vertex set
+// (demo2-deform.py:45): the VJP is linear, so it can be applied per (view, face corner) before the sum.  One thread
+// per face corner walks the B views (reads 12 B apart across the threads of a wavefront), applies view b's VJP at the
+// corner's vertex and keeps the sum in registers: three atomics per corner instead of 3 * B, and no [B,NV,3] intermediate.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_face_camera_bwd_shared(const float* __restrict__ gfv,
+                                                                const int32_t* __restrict__ faces,
+                                                                const float* __restrict__ v,
+                                                                const float* __restrict__ eye,
+                                                                const float* __restrict__ rot, float* __restrict__ gv,
+                                                                int B, int NF, float param) {
+    const long fc = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (fc >= (long)NF * 3) return;
+    const int vi = faces[fc];
+    const float* pv = v + (long)vi * 3;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, gw[3];
+    for (int b = 0; b < B; b++) {
+        camera_point_vjp<KIND>(gfv + ((long)b * NF * 3 + fc) * 3, pv, eye + b * 3, rot + b * 9, param, gw);
+        s0 += gw[0]; s1 += gw[1]; s2 += gw[2];
+    }
+    float* dst = gv + (long)vi * 3;
+    atomicAdd(dst + 0, s0); atomicAdd(dst + 1, s1); atomicAdd(dst + 2, s2);
+}
+void launch_face_camera_backward_shared(hipStream_t st, const float* gfv, const int32_t* faces, const float* v,
+                                        const float* eye, const float* rot, float* gv, int B, int NV, int NF,
+                                        int kind, float param) {
+    (void)hipMemsetAsync(gv, 0, sizeof(float) * (size_t)NV * 3, st);
+    if (B < 1) return;
+    const unsigned grid = (unsigned)(((long)NF * 3 + 255) / 256);
+    if (kind == 1) k_face_camera_bwd_shared<1><<<grid, 256, 0, st>>>(gfv, faces, v, eye, rot, gv, B, NF, param);
+    else if (kind == 2) k_face_camera_bwd_shared<2><<<grid, 256, 0, st>>>(gfv, faces, v, eye, rot, gv, B, NF, param);
+    else k_face_camera_bwd_shared<0><<<grid, 256, 0, st>>>(gfv, faces, v, eye, rot, gv, B, NF, param);
+}
 void launch_camera_forward(hipStream_t st, const float* v, const float* eye, const float* rot, float* out, int B,
                            int VB, int NV, int kind, float param) {
     const unsigned grid = (unsigned)(((long)B * NV + 255) / 256);

@@ -572,6 +572,19 @@ int jr_camera_backward(jr_ctx* ctx, const float* grad_out, const float* vertices
     JR_HIP(hipGetLastError());
     return 0;
 }
+int jr_face_camera_backward_shared(jr_ctx* ctx, const float* grad_face_vertices, const int32_t* faces,
+                                   const float* vertices, const float* eye, const float* rot, float* grad_vertices,
+                                   int B, int NV, int NF, int kind, float param) {
+    if (!ctx || !grad_face_vertices || !faces || !vertices || !eye || !rot || !grad_vertices)
+        return fail("jr_face_camera_backward_shared: NULL argument");
+    if (B < 0 || NV < 1 || NF < 1) return fail("jr_face_camera_backward_shared: bad sizes");
+    if (kind < 0 || kind > 2) return fail("jr_face_camera_backward_shared: kind must be 0, 1 or 2");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_face_camera_backward_shared(ctx->stream, grad_face_vertices, faces, vertices, eye, rot, grad_vertices, B,
+                                           NV, NF, kind, param);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
 int jr_neg_iou_loss(jr_ctx* ctx, const float* predict, const float* target, float* iou, float* grad_predict,
                     int B, int n, float divisor) {
     if (!ctx || !predict || !target || !iou) return fail("jr_neg_iou_loss: NULL argument");

@@ -75,6 +75,9 @@ void launch_camera_forward(hipStream_t st, const float* v, const float* eye, con
                            int VB, int NV, int kind, float param);
 void launch_camera_backward(hipStream_t st, const float* gout, const float* v, const float* eye, const float* rot,
                             float* gv, int B, int VB, int NV, int kind, float param);
+void launch_face_camera_backward_shared(hipStream_t st, const float* gfv, const int32_t* faces, const float* v,
+                                        const float* eye, const float* rot, float* gv, int B, int NV, int NF,
+                                        int kind, float param);
 void launch_neg_iou_loss(hipStream_t st, const float* predict, const float* target, float* iou, float* grad, int B,
                          int n, float divisor);
 void launch_n3mr_image_forward(hipStream_t st, const float* in, float* out, int B, int H, int W, int C, int pool);

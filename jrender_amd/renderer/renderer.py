@@ -8,7 +8,7 @@ import numpy as np
 
 from .. import _ffi
 from ..structures import Mesh
-from ..structures.mesh import face_vertices_backward
+from ..structures.mesh import _shared_faces, device_faces, face_vertices_backward
 from .dr import N3mrRasterizer, SoftRasterizer
 from .lighting import Lighting
 from .transform import Transform
@@ -95,6 +95,10 @@ class Renderer:
         if isinstance(v, _ffi.DeviceArray) and gfv.size == gfv.shape[0] * nf * 9:
             # device-resident chain: scatter kernel -> camera VJP kernel; [VB,nv,3] stays on the device (VB = 1: the
             # views share the vertex set and the result is their sum)
+            faces = np.asarray(self._faces).reshape(-1, nf, 3)
+            shared = _shared_faces(faces)
+            if v.shape[0] == 1 and gfv.shape[0] > 1 and shared is not None and hasattr(self.transform.transformer, 'backward_from_faces'):
+                return self.transform.transformer.backward_from_faces(gfv, device_faces(v.ctx, shared), v)
             gndc = face_vertices_backward(gfv.reshape(gfv.shape[0], nf, 3, 3), self._faces, v.shape[1])
             return self.transform.transformer.backward(gndc, v)
         if isinstance(v, _ffi.DeviceArray):

@@ -55,6 +55,19 @@ class _CameraOnDevice:
                                                   B, VB, NV, int(kind), float(param)))
         return out
 
+    def backward_from_faces(self, grad_face_vertices, faces_dev, vertices, eye, rot, kind, param):
+        """[B,NF,3,3] NDC-space face gradients -> [1,nv,3] for ONE shared vertex set: scatter + VJP in one launch."""
+        ctx = vertices.ctx
+        B = self._views(ctx, eye, rot)
+        NV, NF = vertices.shape[1], faces_dev.size // 3
+        if vertices.shape[0] != 1 or grad_face_vertices.size != B * NF * 9:
+            raise ValueError("backward_from_faces: one shared vertex set and [%d, %d, 3, 3] gradients expected" % (B, NF))
+        gv = ctx.empty((1, NV, 3), F32)
+        _ffi._check(_ffi.load().jr_face_camera_backward_shared(ctx.handle, grad_face_vertices.ptr, faces_dev.ptr, vertices.ptr,
+                                                               self._eye_d.ptr, self._rot_d.ptr, gv.ptr, B, NV, NF,
+                                                               int(kind), float(param)))
+        return gv
+
     def backward(self, grad_out, vertices, eye, rot, kind, param):
         ctx = vertices.ctx
         B = self._views(ctx, eye, rot)
@@ -264,6 +277,13 @@ class LookAt:
         if self.perspective:
             return perspective(vertices, angle=self.viewing_angle)
         return orthogonal(vertices, scale=self.viewing_scale)
+
+    def backward_from_faces(self, grad_face_vertices, faces_dev, vertices_in):
+        """Device only, one shared vertex set [1,nv,3]: face-vertex gradients [B,NF,3,3] -> [1,nv,3] (the scatter-add
+        of face_vertices_backward and ``backward`` fused: the VJP is linear, so it commutes with the sums)."""
+        eye, rot = self._device_views(vertices_in)
+        self._dev = getattr(self, "_dev", None) or _CameraOnDevice()
+        return self._dev.backward_from_faces(grad_face_vertices, faces_dev, vertices_in, eye, rot, *self._projection_kind())
 
     def backward(self, grad_out, vertices_in):
         """VJP w.r.t. the world-space vertices given the same input as __call__."""

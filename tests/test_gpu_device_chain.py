@@ -95,6 +95,26 @@ def test_face_gather_and_scatter(ctx):
         assert close(got, want, 1e-5, 1e-6 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("perspective", [True, False])
+def test_fused_scatter_and_camera_vjp_for_a_shared_vertex_set(ctx, perspective):
+    """LookAt.backward_from_faces == face_vertices_backward followed by LookAt.backward (the VJP is linear)."""
+    from jrender_amd.structures.mesh import device_faces
+    v, f = jr.synthetic.uv_sphere(30, 16)
+    B = 9
+    cam = T.LookAt(perspective=perspective, viewing_angle=15, viewing_scale=0.7)
+    cam._eye = T.get_points_from_angles(*ring(B, seed=4))
+    vd = ctx.array((v * 0.5)[None])
+    g = ctx.array(np.random.default_rng(8).uniform(-1, 1, (B, f.shape[0], 3, 3)).astype(np.float32))
+    two_step = cam.backward(face_vertices_backward(g, f[None], v.shape[0]), vd).numpy()
+    fused = cam.backward_from_faces(g, device_faces(ctx, f), vd).numpy()
+    assert fused.shape == (1, v.shape[0], 3)
+    assert close(fused, two_step, 1e-5, 2e-6 * np.abs(two_step).max())
+    # and against the host mirrors end to end
+    want = cam.backward(face_vertices_backward(g.numpy(), np.repeat(f[None], B, 0), v.shape[0]), np.repeat((v * 0.5)[None], B, 0))
+    want = want.astype(np.float64).sum(0, keepdims=True)
+    assert close(fused, want, 1e-5, 1e-5 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("shape", [(6, 64, 64), (3, 1, 37, 41), (1, 5)])
 def test_neg_iou_loss_and_gradient(ctx, shape):
     r = np.random.default_rng(9)
