@@ -277,23 +277,25 @@ class Mesh(object):
 
     @property
     def face_textures(self):
-        if isinstance(self._vertices, _ffi.DeviceArray) and self.texture_type == 'surface':
-            # device path: one texture block per VIEW (the camera step may have broadcast one vertex set over B eyes)
-            ctx, B = self._vertices.ctx, self._vertices.shape[0]
-            shape = (B,) + tuple(self._textures.shape[1:])
-            if self._default_textures:
-                return _cached_device(ctx, "ones", shape, 1, lambda: ctx.array(np.ones(shape, F32)))
-            t = self._textures
-            if t.shape[0] != B:
-                if t.shape[0] != 1:
-                    raise ValueError("textures batch %d does not match %d views" % (t.shape[0], B))
-                t = np.broadcast_to(t, shape)
-            return ctx.array(t)
+        device = isinstance(self._vertices, _ffi.DeviceArray)
+        if device and self.texture_type == 'surface' and self._default_textures:
+            ctx, shape = self._vertices.ctx, (self._vertices.shape[0],) + tuple(self._textures.shape[1:])
+            return _cached_device(ctx, "ones", shape, 1, lambda: ctx.array(np.ones(shape, F32)))
         if self.texture_type in ['surface']:
-            return self.textures
+            t = self.textures
         elif self.texture_type in ['vertex']:
-            return face_vertices(self.textures, self.faces)
-        raise ValueError('texture type not applicable')
+            t = face_vertices(self.textures, self.faces[:self.textures.shape[0]])
+        else:
+            raise ValueError('texture type not applicable')
+        if not device:
+            return t
+        # device path: one texture block per VIEW (the camera step may have broadcast one vertex set over B eyes)
+        B = self._vertices.shape[0]
+        if t.shape[0] != B:
+            if t.shape[0] != 1:
+                raise ValueError("textures batch %d does not match %d views" % (t.shape[0], B))
+            t = np.broadcast_to(t, (B,) + t.shape[1:])
+        return self._vertices.ctx.array(t)
 
     def fill_back_(self):
         if not self._fill_back:

@@ -186,6 +186,34 @@ def test_rgb_mode_with_device_vertices_and_textures(ctx):
     assert got.shape == want.shape == (B, 3, 64, 64) and np.array_equal(got, want)
 
 
+def test_vertex_colours_broadcast_over_the_views(ctx):
+    v, f = jr.synthetic.uv_sphere(24, 13)
+    col = np.random.default_rng(4).uniform(0, 1, (1, v.shape[0], 3)).astype(np.float32)
+    B = 3
+    rh, rd = _renderer(B), _renderer(B)
+    for r in (rh, rd):
+        r.set_texture_mode('vertex')
+    md = rd.transform(jr.Mesh(ctx.array(v[None] * 0.5), f, textures=col, texture_type='vertex'))
+    got = rd.rasterizer(md, 'rgb').numpy()
+    mh = jr.Mesh(md.vertices.numpy(), np.repeat(f[None], B, 0), textures=np.repeat(col, B, 0), texture_type='vertex')
+    assert np.array_equal(got, rh.rasterizer(mh, 'rgb').numpy())
+
+
+def test_lit_rgb_render_from_device_vertices(ctx):
+    """render_mesh(mode='rgb'): lighting runs on the host from a download of the face vertices (normals are O(NF) host
+    work) and rewrites the textures, the rest of the chain stays on the device.  Per-view vertex sets here."""
+    v, f = jr.synthetic.uv_sphere(24, 13)
+    B = 2
+    vb = np.stack([v * 0.5, v * np.asarray([0.4, 0.5, 0.45], np.float32)]).astype(np.float32)
+    tex = np.random.default_rng(5).uniform(0, 1, (B, f.shape[0], 1, 3)).astype(np.float32)
+    rh, rd = _renderer(B), _renderer(B)
+    want = rh.render_mesh(jr.Mesh(vb, np.repeat(f[None], B, 0), textures=tex), mode='rgb').numpy()
+    got = rd.render_mesh(jr.Mesh(ctx.array(vb), np.repeat(f[None], B, 0), textures=tex), mode='rgb').numpy()
+    assert got.shape == want.shape
+    # same lighting (host, same inputs); the cameras differ in the last place: a handful of edge pixels
+    assert (np.abs(got - want) > 2e-3).mean() <= 5e-3 and np.abs(got - want).mean() <= 1e-4
+
+
 def test_demo2_front_ends_give_the_same_loss_curve():
     spec = importlib.util.spec_from_file_location("demo2", os.path.join(os.path.dirname(GOLD), "..", "examples", "demo2_deform.py"))
     demo2 = importlib.util.module_from_spec(spec)
