@@ -15,8 +15,8 @@ the views; the vertex gradient (the mesh is shared by all views) is summed with 
 
 --front-end device (default): the 16 KB vertex set goes to the GPU once per iteration and everything between it and
 the vertex gradient stays there — camera kernel (one vertex set broadcast over the views), face gather, SoftRas
-forward, IoU loss + its gradient, SoftRas backward, scatter to the vertices, camera VJP summed over the views,
-RCCL all-reduce — and 16 KB come back.  --front-end host runs the same chain through the NumPy mirrors (the
+forward, IoU loss + its gradient, SoftRas backward, scatter to the vertices + camera VJP summed over the views,
+RCCL all-reduce, Laplacian and flatten regularisers with their gradients — and three 16 KB gradients come back.  --front-end host runs the same chain through the NumPy mirrors (the
 6 MB face arrays cross PCIe twice per iteration); both produce the same loss curve (tests/test_gpu_named_configs.py).
 """
 import argparse
@@ -138,14 +138,16 @@ def main(argv=None):
         if args.front_end == 'device' and nb:
             # ONE vertex set on the device; the camera step broadcasts it over this rank's eyes (demo2-deform.py:45
             # materialises the copies with repeat())
-            mesh = jr.Mesh(ctx.array(vertices), model.faces)
+            vertices_d = ctx.array(vertices)
+            mesh = jr.Mesh(vertices_d, model.faces)
             pred = renderer.render_mesh(mesh, mode='silhouettes')             # DeviceArray [nb,IS,IS]
             iou, g_sil = jr.neg_iou_loss_and_grad(pred, target_d, total_views=B)
             g_v = renderer.grad_vertices(grad_silhouettes=g_sil)              # DeviceArray [1,nv,3]: summed over the views
             if comm is not None:
                 g_v = comm.all_reduce_sum(g_v)           # RCCL on the device buffer
-            # everything above is enqueued, nothing has waited for the GPU: the regularisers (host, O(nv)) run meanwhile
-            reg = (model.laplacian_loss(vertices), model.laplacian_loss.backward(vertices)) + model.flatten_loss.value_and_grad(vertices)
+            # the regularisers: one launch each on the same device vertices; nothing so far has waited for the GPU
+            reg = model.laplacian_loss.value_and_grad(vertices_d) + model.flatten_loss.value_and_grad(vertices_d)
+            reg = tuple(r.numpy() for r in reg)
             iou_sum = float(iou.numpy().sum())
             if comm is not None:
                 iou_sum = comm.all_reduce_scalar(iou_sum, "sum")

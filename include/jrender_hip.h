@@ -159,6 +159,18 @@ int jr_face_camera_backward_shared(jr_ctx* ctx, const float* grad_face_vertices,
  * taken over `divisor` views (the whole batch when the views are sharded over ranks). */
 int jr_neg_iou_loss(jr_ctx* ctx, const float* predict, const float* target, float* iou, float* grad_predict,
                     int B, int n, float divisor);
+/* The mesh regularisers of the deformation loop, value and gradient in one launch each (Jittor ops + autograd in the
+ * reference).  LaplacianLoss (jrender/loss/laplacian_loss.py:5-37): loss[b] = sum((L x_b)^2), L [NV,NV] given in CSR
+ * (rowptr [NV+1], col, val) and, for the gradient 2 L^T L x_b * grad_scale, its transpose in CSR too; scratch
+ * [B,NV,3] floats.  FlattenLoss (jrender/loss/flatten_loss.py:5-80): loss[b] = sum over the NE edges shared by two
+ * faces of (cos + 1)^2, (v0s, v1s) the edge, (v2s, v3s) the two opposite vertices; gradient * grad_scale (float
+ * atomics).  vertices / grad_vertices [B,NV,3]; grad_vertices may be NULL. */
+int jr_laplacian_loss(jr_ctx* ctx, const int32_t* rowptr, const int32_t* col, const float* val,
+                      const int32_t* rowptr_t, const int32_t* col_t, const float* val_t, const float* vertices,
+                      float* scratch, float* loss, float* grad_vertices, int B, int NV, float grad_scale);
+int jr_flatten_loss(jr_ctx* ctx, const int32_t* v0s, const int32_t* v1s, const int32_t* v2s, const int32_t* v3s,
+                    const float* vertices, float* loss, float* grad_vertices, int B, int NV, int NE, float eps,
+                    float grad_scale);
 int jr_avgpool2x2_forward(jr_ctx* ctx, const float* in, float* out, int planes, int H, int W);
 int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, int planes, int H,
                            int W);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "jr_camera_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float]),
     "jr_camera_backward": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float]),
     "jr_face_camera_backward_shared": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float]),
+    "jr_laplacian_loss": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 2 + [C.c_float]),
+    "jr_flatten_loss": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_float] * 2),
     "jr_neg_iou_loss": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_float]),
     "jr_avgpool2x2_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_avgpool2x2_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),

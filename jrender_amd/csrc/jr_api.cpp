@@ -596,6 +596,29 @@ int jr_neg_iou_loss(jr_ctx* ctx, const float* predict, const float* target, floa
     return 0;
 }
 
+int jr_laplacian_loss(jr_ctx* ctx, const int32_t* rowptr, const int32_t* col, const float* val,
+                      const int32_t* rowptr_t, const int32_t* col_t, const float* val_t, const float* vertices,
+                      float* scratch, float* loss, float* grad_vertices, int B, int NV, float grad_scale) {
+    if (!ctx || !rowptr || !col || !val || !vertices || !scratch || !loss) return fail("jr_laplacian_loss: NULL argument");
+    if (grad_vertices && (!rowptr_t || !col_t || !val_t)) return fail("jr_laplacian_loss: the gradient needs the transposed matrix");
+    if (B < 1 || NV < 1) return fail("jr_laplacian_loss: bad sizes");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_laplacian_loss(ctx->stream, rowptr, col, val, rowptr_t, col_t, val_t, vertices, scratch, loss, grad_vertices,
+                              B, NV, grad_scale);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_flatten_loss(jr_ctx* ctx, const int32_t* v0s, const int32_t* v1s, const int32_t* v2s, const int32_t* v3s,
+                    const float* vertices, float* loss, float* grad_vertices, int B, int NV, int NE, float eps,
+                    float grad_scale) {
+    if (!ctx || !v0s || !v1s || !v2s || !v3s || !vertices || !loss) return fail("jr_flatten_loss: NULL argument");
+    if (B < 1 || NV < 1 || NE < 0) return fail("jr_flatten_loss: bad sizes");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_flatten_loss(ctx->stream, v0s, v1s, v2s, v3s, vertices, loss, grad_vertices, B, NV, NE, eps, grad_scale);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
 int jr_n3mr_forward(jr_ctx* ctx, const float* faces, const float* textures, float* faces_inv,
                     int32_t* face_index_map, float* weight_map, float* depth_map, float* face_inv_map,
                     float* rgb_map, float* alpha_map, int32_t* sampling_index_map,

@@ -80,6 +80,11 @@ void launch_face_camera_backward_shared(hipStream_t st, const float* gfv, const 
                                         int kind, float param);
 void launch_neg_iou_loss(hipStream_t st, const float* predict, const float* target, float* iou, float* grad, int B,
                          int n, float divisor);
+void launch_laplacian_loss(hipStream_t st, const int* rowptr, const int* col, const float* val, const int* rowptr_t,
+                           const int* col_t, const float* val_t, const float* x, float* y, float* loss, float* grad,
+                           int B, int nv, float scale);
+void launch_flatten_loss(hipStream_t st, const int* v0s, const int* v1s, const int* v2s, const int* v3s, const float* x,
+                         float* loss, float* grad, int B, int nv, int ne, float eps, float scale);
 void launch_n3mr_image_forward(hipStream_t st, const float* in, float* out, int B, int H, int W, int C, int pool);
 void launch_n3mr_image_backward(hipStream_t st, const float* gout, float* gin, int B, int H, int W, int C, int pool);
 void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textures, float* faces_inv,

@@ -68,6 +68,25 @@ def neg_iou_loss_backward(predict, target):
     return (-(target * U - I * (1 - target)) / (U * U) / n).astype(F32)
 
 
+class _DeviceLoss:
+    """Per-mesh loss values [B] on the device; ``float(x)`` / ``x.numpy()`` download (and average if the loss was
+    built with average=True) — the only points that wait for the GPU."""
+
+    def __init__(self, values, average):
+        self.values, self.average = values, average
+
+    def numpy(self):
+        v = self.values.numpy()
+        return F32(v.sum() / v.shape[0]) if self.average else v
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self.numpy())
+        return a if dtype is None else a.astype(dtype)
+
+    def __float__(self):
+        return float(np.mean(self.values.numpy()))
+
+
 class LaplacianLoss:
     def __init__(self, vertex, faces, average=False):
         vertex, faces = np.asarray(vertex), np.asarray(faces).astype(np.int64)
@@ -102,6 +121,8 @@ class LaplacianLoss:
         return np.stack([m @ xi for xi in x])
 
     def __call__(self, x):
+        if isinstance(x, _ffi.DeviceArray):
+            return self.value_and_grad(x, want_grad=False)[0]
         x = np.asarray(x, F32)
         y = self._apply(x)
         out = (y * y).sum(tuple(range(y.ndim))[1:])
@@ -109,9 +130,42 @@ class LaplacianLoss:
 
     def backward(self, x):
         """d(sum over batch of the loss)/dx (divided by the batch size when average=True)."""
+        if isinstance(x, _ffi.DeviceArray):
+            return self.value_and_grad(x)[1]
         x = np.asarray(x, F32)
         g = 2 * self._apply(self._apply(x), transpose=True)
         return (g / x.shape[0] if self.average else g).astype(F32)
+
+    def _device_matrices(self, ctx):
+        """(rowptr, col, val) of L and of its transpose on the device, uploaded once per context."""
+        cache = self.__dict__.setdefault("_dev", {})
+        if id(ctx) not in cache:
+            def csr(m):
+                nz = [np.nonzero(row)[0] for row in m]
+                rowptr = np.concatenate([[0], np.cumsum([len(c) for c in nz])]).astype(np.int32)
+                col = np.concatenate(nz).astype(np.int32) if len(nz) else np.zeros(0, np.int32)
+                val = np.concatenate([row[c] for row, c in zip(m, nz)]).astype(F32)
+                return ctx.array(rowptr), ctx.array(col), ctx.array(val)
+            cache[id(ctx)] = (ctx,) + csr(self.laplacian) + csr(np.ascontiguousarray(self.laplacian.T))
+        return cache[id(ctx)][1:]
+
+    def value_and_grad(self, x, want_grad=True):
+        """(__call__(x), backward(x)).  Device ``x`` [B,nv,3]: ONE launch (jr_laplacian_loss), both results stay on the
+        device — the value is a DeviceArray [B] (its mean when ``average``: [1])."""
+        if not isinstance(x, _ffi.DeviceArray):
+            return self(x), (self.backward(x) if want_grad else None)
+        ctx = x.ctx
+        if x.ndim != 3 or x.shape[1] != self.nv or x.shape[2] != 3 or x.dtype != F32:
+            raise ValueError("LaplacianLoss: device vertices must be float32 [B, %d, 3], got %s" % (self.nv, x.shape))
+        B = x.shape[0]
+        m = self._device_matrices(ctx)
+        loss = ctx.empty((B,), F32)
+        grad = ctx.empty(x.shape, F32) if want_grad else None
+        scratch = ctx.empty(x.shape, F32)
+        _ffi._check(_ffi.load().jr_laplacian_loss(ctx.handle, *[a.ptr for a in m], x.ptr, scratch.ptr, loss.ptr,
+                                                  grad.ptr if want_grad else None, B, self.nv,
+                                                  1.0 / B if self.average else 1.0))
+        return _DeviceLoss(loss, self.average), grad
 
 
 class FlattenLoss:
@@ -155,6 +209,8 @@ class FlattenLoss:
         return (cb1 * cb2).sum(-1) / (l1 * l2 + eps)
 
     def __call__(self, vertices, eps=1e-6):
+        if isinstance(vertices, _ffi.DeviceArray):
+            return self.value_and_grad(vertices, eps, want_grad=False)[0]
         vertices = np.asarray(vertices, np.float64)
         cos = self._cos(vertices, eps)
         loss = ((cos + 1) ** 2).sum(tuple(range(cos.ndim))[1:])
@@ -198,8 +254,28 @@ class FlattenLoss:
         through the per-edge expression, scattered to the four vertices of every edge pair."""
         return self.value_and_grad(vertices, eps)[1]
 
-    def value_and_grad(self, vertices, eps=1e-6):
-        """(__call__(vertices), backward(vertices)) from ONE evaluation of the per-edge expression."""
+    def value_and_grad(self, vertices, eps=1e-6, want_grad=True):
+        """(__call__(vertices), backward(vertices)) from ONE evaluation of the per-edge expression.  Device vertices
+        [B,nv,3]: one launch (jr_flatten_loss, double arithmetic like this mirror; the gradient is scattered with float
+        atomics), both results stay on the device."""
+        if isinstance(vertices, _ffi.DeviceArray):
+            ctx = vertices.ctx
+            if vertices.ndim != 3 or vertices.shape[2] != 3 or vertices.dtype != F32:
+                raise ValueError("FlattenLoss: device vertices must be float32 [B, nv, 3], got %s" % (vertices.shape,))
+            cache = self.__dict__.setdefault("_dev", {})
+            if id(ctx) not in cache:
+                pad = lambda a: np.ascontiguousarray(a if len(a) else [0], np.int32)      # noqa: E731  (no zero-byte buffers)
+                cache[id(ctx)] = (ctx,) + tuple(ctx.array(pad(a)) for a in (self.v0s, self.v1s, self.v2s, self.v3s))
+            idx = cache[id(ctx)][1:]
+            B, nv = vertices.shape[:2]
+            if len(self.v0s) and int(max(a.max() for a in (self.v0s, self.v1s, self.v2s, self.v3s))) >= nv:
+                raise ValueError("FlattenLoss: the mesh has %d vertices, the faces index up to %d" % (nv, int(max(a.max() for a in (self.v0s, self.v1s, self.v2s, self.v3s)))))
+            loss = ctx.empty((B,), F32)
+            grad = ctx.empty(vertices.shape, F32) if want_grad else None
+            _ffi._check(_ffi.load().jr_flatten_loss(ctx.handle, *[a.ptr for a in idx], vertices.ptr, loss.ptr,
+                                                    grad.ptr if want_grad else None, B, nv, len(self.v0s), float(eps),
+                                                    1.0 / B if self.average else 1.0))
+            return _DeviceLoss(loss, self.average), grad
         vertices = np.asarray(vertices, np.float64)
         B, nv = vertices.shape[:2]
         v0, v1 = vertices[:, self.v0s], vertices[:, self.v1s]

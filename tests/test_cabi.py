@@ -27,6 +27,44 @@ def test_header_symbols_exported_and_bound():
     assert set(_ffi.SIGNATURES) <= set(names)
 
 
+def _prototypes():
+    """name -> list of parameter kinds ('ptr', 'int', 'float', 'size') parsed from the header's prototypes."""
+    hdr = open(os.path.join(ROOT, "include", "jrender_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(jr_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        name, params = m.group(1), " ".join(m.group(2).split())
+        kinds = []
+        for prm in ([] if params in ("", "void") else params.split(",")):
+            prm = prm.strip()
+            if "*" in prm or "[" in prm:             # arrays decay to pointers
+                kinds.append("ptr")
+            elif re.match(r"(const )?(size_t|uint64_t|unsigned long long)\b", prm):
+                kinds.append("size")
+            elif re.match(r"(const )?float\b", prm):
+                kinds.append("float")
+            elif re.match(r"(const )?(int|int32_t|uint32_t|unsigned)\b", prm):
+                kinds.append("int")
+            else:
+                kinds.append("?" + prm)
+        out[name] = kinds
+    return out
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every bound function passes as many arguments as its prototype takes, pointers where the header has pointers,
+    floats where it has floats (a miscounted pointer list only shows up as a TypeError on the GPU box otherwise)."""
+    C = ctypes
+    kind_of = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_int: "int", C.c_uint: "int", C.c_uint32: "int", C.c_int32: "int",
+               C.c_float: "float", C.c_size_t: "size", C.c_uint64: "size", C.c_ulonglong: "size"}
+    protos = _prototypes()
+    for name, (_, argtypes) in _ffi.SIGNATURES.items():
+        assert name in protos, name
+        got = ["ptr" if (isinstance(t, type) and issubclass(t, (C._Pointer, C.Array))) else kind_of.get(t, "?%r" % (t,))
+               for t in argtypes]
+        assert got == protos[name], (name, got, protos[name])
+
+
 def test_version_and_error_string():
     lib = _ffi.load()
     assert b"gfx950" in lib.jr_version()

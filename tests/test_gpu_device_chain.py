@@ -131,6 +131,24 @@ def test_neg_iou_loss_and_gradient(ctx, shape):
     assert close(g2.numpy(), g_h / 4, 1e-5, 1e-6 * np.abs(g_h).max())
 
 
+@pytest.mark.parametrize("average", [False, True])
+def test_mesh_regularisers_value_and_gradient(ctx, average):
+    """LaplacianLoss / FlattenLoss on device vertices against their NumPy mirrors (which are pinned to the reference's
+    laplacian_loss.py / flatten_loss.py in tests/test_host_reference.py)."""
+    v, f = jr.synthetic.uv_sphere(52, 27)                                     # the demo's 1 352-vertex class template
+    r = np.random.default_rng(12)
+    x = np.stack([v * 0.5 + r.normal(0, 0.01, v.shape), v * 0.4 + r.normal(0, 0.02, v.shape),
+                  v * np.asarray([0.5, 0.2, 0.3])]).astype(np.float32)
+    for loss in (jr.LaplacianLoss(v, f, average=average), jr.FlattenLoss(f, average=average)):
+        val_d, g_d = loss.value_and_grad(ctx.array(x))
+        want_v, want_g = np.asarray(loss(x), np.float64), loss.backward(x)
+        assert close(np.asarray(val_d.numpy(), np.float64), want_v, 2e-5, 0), (type(loss).__name__, val_d.numpy(), want_v)
+        assert g_d.shape == x.shape
+        assert close(g_d.numpy(), want_g, 1e-4, 2e-5 * np.abs(want_g).max()), type(loss).__name__
+        assert close(np.asarray(loss(ctx.array(x)).numpy(), np.float64), want_v, 2e-5, 0)
+        assert close(loss.backward(ctx.array(x)).numpy(), want_g, 1e-4, 2e-5 * np.abs(want_g).max())
+
+
 def test_all_zero_view_does_not_divide_by_zero(ctx):
     p = np.zeros((2, 16, 16), np.float32)
     iou, g = jr.neg_iou_loss_and_grad(ctx.array(p), ctx.array(p))
