@@ -29,7 +29,7 @@ sample — the only place the oracle is touched, never the measured path.  The o
 ALSO the parity check of the line: the GPU renders the same view at the same size with the same upstream gradient and
 `parity` reports the index-buffer match fraction (must be 1.0) and the RGBA / grad_faces / vertex-gradient errors,
 SURVEY.md §8(d)'s element-wise formula next to the max-normalised one.  `latency_ms_b1` is fwd+bwd of ONE 39k-face
-image (BASELINE's "ms @1024^2, 39k faces"); `secondary` carries the NMR workload (configs[4]) and the random-triangle
+image (BASELINE's "ms @1024^2, 39k faces"); `secondary` carries the demo2 loop (configs[3]), the NMR workload (configs[4]) and the random-triangle
 scene, all measured AFTER the timed region.
 """
 import argparse
@@ -356,6 +356,24 @@ def fwd_bwd_ms(ctx, comm, fv_h, tex_h, IS, K, steps=30, warmup=5, seed=3):
     return percentiles(per_step), {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()}
 
 
+def demo2_loop_ms():
+    """examples/demo2_deform.py (the reference's demo2-deform.py on this library) timed by its own clock around the
+    optimisation loop: camera -> gather -> SoftRas -> IoU -> SoftRas backward -> scatter + camera VJP -> regularisers ->
+    Adam per iteration, with the chain around the rasteriser on the device and, for comparison, through the NumPy mirrors."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("demo2_deform", os.path.join(ROOT, "examples", "demo2_deform.py"))
+    demo2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo2)
+    res = {"workload": "demo2 silhouette fitting: 64 views at 64x64, 1 352-vertex sphere template, sigma 1e-4, one rank",
+           "unit": "ms per iteration"}
+    for fe, iters in (("device", 200), ("host", 40)):
+        demo2.main(["--iters", "5", "--quiet", "--front-end", fe])
+        hist = demo2.main(["--iters", str(iters), "--quiet", "--front-end", fe])
+        res[fe] = demo2.main.loop_seconds / iters * 1e3
+        res["loss_%s" % fe] = [float(hist[0]), float(hist[-1])]
+    return res
+
+
 def secondary_lines(args, ctx, comm):
     """What the driver's plain `bench.py` run should also put on the record (measured after the timed region):
     the single-image latency, larger K, the random-triangle scene and the NMR path."""
@@ -380,6 +398,10 @@ def secondary_lines(args, ctx, comm):
     m = measure_n3mr(ctx, comm, NF, IS, 20, 3)
     out["n3mr"] = {"workload": "NMR rgb+alpha+depth fwd+bwd, %d faces (fill_back x2), %dx%d, batch 1 (BASELINE configs[4])" % (m["NF2"], IS, IS),
                    "ms": percentiles(m["per_step"]), "phase_ms": m["phase_ms_per_step"], "roofline": m["roofline"]}
+    try:        # BASELINE configs[3]: the demo2 silhouette-fitting loop end to end (64 views at 64^2, 1 352-vertex template)
+        out["c4_demo2"] = demo2_loop_ms()
+    except Exception as e:
+        out["c4_demo2"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         try:                                        # the reference's NMR kernels on one host thread (their CUDA form is one thread per face), bounded sample
             out["n3mr"]["cpu_baseline"] = n3mr_cpu_baseline(m["faces_h"], m["tex_h"], IS, budget_s=8.0)

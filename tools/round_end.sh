@@ -21,5 +21,8 @@ timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --scene soup --no-secondary > $out/${tag}_bench_soup.json 2>> $out/${tag}_bench.err
 timeout 400 python tools/grad_parity.py > $out/${tag}_grad_parity.txt 2>&1
 timeout 400 python tools/time_configs.py > $out/${tag}_time_configs.txt 2>&1
+# kernel trace of the demo2 loop with the chain around the rasteriser on the device
+(cd /tmp; export TMPDIR=/tmp; cd - > /dev/null; timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/demo2_prof -o demo2 --output-format csv -- python examples/demo2_deform.py --iters 100 --quiet > $out/${tag}_demo2_traced.log 2>&1)
+cp $(find gpurun_out/demo2_prof -name "*kernel_stats.csv" | head -1) $out/${tag}_demo2_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/demo2_prof $out/${tag}_demo2_traced.log
 rm -rf gpurun_out/profiles_$tag gpurun_out/profiles_${tag}_b1 gpurun_out/n3mr_prof
 tail -3 $out/${tag}_pytest_gpu.log; tail -c 400 $out/${tag}_bench.json
