@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void k_camera_bwd(const float* __restrict__ go
 // Scatter-add of the face-vertex gradients AND the camera VJP in one pass for views that share ONE vertex set
 // (demo2-deform.py:45): the VJP is linear, so it can be applied per (view, face corner) before the sum.  One thread
 // per face corner walks the B views (reads 12 B apart across the threads of a wavefront), applies view b's VJP at the
-// corner's vertex and keeps the sum in registers: three atomics per corner instead of 3 * B, and no [B,NV,3] intermediate.
+// corner's vertex and keeps the sum of eight views in registers: 3 * B / 8 atomics per corner instead of 3 * B, and no
+// [B,NV,3] intermediate.
+constexpr int FCB_VIEWS = 8;
 template <int KIND>
 __global__ __launch_bounds__(256) void k_face_camera_bwd_shared(const float* __restrict__ gfv,
                                                                 const int32_t* __restrict__ faces,
@@ -203,7 +205,9 @@ __global__ __launch_bounds__(256) void k_face_camera_bwd_shared(const float* __r
     const int vi = faces[fc];
     const float* pv = v + (long)vi * 3;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, gw[3];
-    for (int b = 0; b < B; b++) {
+    // blockIdx.y = a chunk of FCB_VIEWS views: the walk over the views is a dependent chain of divisions, so it is kept short
+    const int b0 = blockIdx.y * FCB_VIEWS, b1 = min(B, b0 + FCB_VIEWS);
+    for (int b = b0; b < b1; b++) {
         camera_point_vjp<KIND>(gfv + ((long)b * NF * 3 + fc) * 3, pv, eye + b * 3, rot + b * 9, param, gw);
         s0 += gw[0]; s1 += gw[1]; s2 += gw[2];
     }
@@ -215,7 +219,7 @@ void launch_face_camera_backward_shared(hipStream_t st, const float* gfv, const 
                                         int kind, float param) {
     (void)hipMemsetAsync(gv, 0, sizeof(float) * (size_t)NV * 3, st);
     if (B < 1) return;
-    const unsigned grid = (unsigned)(((long)NF * 3 + 255) / 256);
+    const dim3 grid((unsigned)(((long)NF * 3 + 255) / 256), (unsigned)((B + FCB_VIEWS - 1) / FCB_VIEWS));
     if (kind == 1) k_face_camera_bwd_shared<1><<<grid, 256, 0, st>>>(gfv, faces, v, eye, rot, gv, B, NF, param);
     else if (kind == 2) k_face_camera_bwd_shared<2><<<grid, 256, 0, st>>>(gfv, faces, v, eye, rot, gv, B, NF, param);
     else k_face_camera_bwd_shared<0><<<grid, 256, 0, st>>>(gfv, faces, v, eye, rot, gv, B, NF, param);

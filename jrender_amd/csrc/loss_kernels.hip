@@ -8,10 +8,11 @@
 
 namespace jr {
 
-__device__ inline double block_sum(double v, double* s) {          // 256 threads
+constexpr int LOSS_WG = 1024;      // one workgroup per mesh: as many threads as a workgroup can have
+__device__ inline double block_sum(double v, double* s) {          // LOSS_WG threads
     s[threadIdx.x] = v;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = LOSS_WG / 2; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
         __syncthreads();
     }
@@ -22,17 +23,17 @@ __device__ inline double block_sum(double v, double* s) {          // 256 thread
 
 // y = L x (CSR, float like the reference's matmul), loss = sum y^2, grad = 2 L^T y (CSR of the transpose: a gather,
 // no atomics).  y goes through a global scratch row block of the same mesh, written and read by this workgroup only.
-__global__ __launch_bounds__(256) void k_laplacian_loss(const int* __restrict__ rowptr, const int* __restrict__ col,
+__global__ __launch_bounds__(LOSS_WG) void k_laplacian_loss(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                         const float* __restrict__ val, const int* __restrict__ rowptr_t,
                                                         const int* __restrict__ col_t, const float* __restrict__ val_t,
                                                         const float* __restrict__ x, float* __restrict__ y,
                                                         float* __restrict__ loss, float* __restrict__ grad, int nv,
                                                         float scale) {
-    __shared__ double s_red[256];
+    __shared__ double s_red[LOSS_WG];
     const long off = (long)blockIdx.x * nv * 3;
     x += off; y += off;
     double part = 0.0;
-    for (int i = threadIdx.x; i < nv; i += 256) {
+    for (int i = threadIdx.x; i < nv; i += LOSS_WG) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
             const float w = val[k];
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void k_laplacian_loss(const int* __restrict__ 
     if (!grad) return;
     __threadfence_block();
     grad += off;
-    for (int j = threadIdx.x; j < nv; j += 256) {
+    for (int j = threadIdx.x; j < nv; j += LOSS_WG) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; k++) {
             const float w = val_t[k];
@@ -103,17 +104,17 @@ __device__ inline void flatten_half_vjp(D3 a, D3 b, const Half& h, double eps, D
 
 // One workgroup per mesh: value (in-block double sum) and gradient (float atomics onto the four vertices of every edge
 // pair; grad must arrive zeroed).  Arithmetic in double like the host mirror.
-__global__ __launch_bounds__(256) void k_flatten_loss(const int* __restrict__ v0s, const int* __restrict__ v1s,
+__global__ __launch_bounds__(LOSS_WG) void k_flatten_loss(const int* __restrict__ v0s, const int* __restrict__ v1s,
                                                       const int* __restrict__ v2s, const int* __restrict__ v3s,
                                                       const float* __restrict__ x, float* __restrict__ loss,
                                                       float* __restrict__ grad, int nv, int ne, float eps_f,
                                                       float scale) {
-    __shared__ double s_red[256];
+    __shared__ double s_red[LOSS_WG];
     const long off = (long)blockIdx.x * nv * 3;
     x += off;
     const double eps = (double)eps_f;
     double part = 0.0;
-    for (int e = threadIdx.x; e < ne; e += 256) {
+    for (int e = threadIdx.x; e < ne; e += LOSS_WG) {
         const int i0 = v0s[e], i1 = v1s[e], i2 = v2s[e], i3 = v3s[e];
         const D3 p0 = load3(x + (long)i0 * 3);
         const D3 a = load3(x + (long)i1 * 3) - p0, b1 = load3(x + (long)i2 * 3) - p0, b2 = load3(x + (long)i3 * 3) - p0;
@@ -143,12 +144,12 @@ __global__ __launch_bounds__(256) void k_flatten_loss(const int* __restrict__ v0
 void launch_laplacian_loss(hipStream_t st, const int* rowptr, const int* col, const float* val, const int* rowptr_t,
                            const int* col_t, const float* val_t, const float* x, float* y, float* loss, float* grad,
                            int B, int nv, float scale) {
-    k_laplacian_loss<<<(unsigned)B, 256, 0, st>>>(rowptr, col, val, rowptr_t, col_t, val_t, x, y, loss, grad, nv, scale);
+    k_laplacian_loss<<<(unsigned)B, LOSS_WG, 0, st>>>(rowptr, col, val, rowptr_t, col_t, val_t, x, y, loss, grad, nv, scale);
 }
 void launch_flatten_loss(hipStream_t st, const int* v0s, const int* v1s, const int* v2s, const int* v3s, const float* x,
                          float* loss, float* grad, int B, int nv, int ne, float eps, float scale) {
     if (grad) (void)hipMemsetAsync(grad, 0, sizeof(float) * (size_t)B * nv * 3, st);
-    k_flatten_loss<<<(unsigned)B, 256, 0, st>>>(v0s, v1s, v2s, v3s, x, loss, grad, nv, ne, eps, scale);
+    k_flatten_loss<<<(unsigned)B, LOSS_WG, 0, st>>>(v0s, v1s, v2s, v3s, x, loss, grad, nv, ne, eps, scale);
 }
 
 }  // namespace jr
