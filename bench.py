@@ -671,8 +671,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("JRENDER_BENCH_FAIL_RANK") == str(rank):       # tests/test_parallel.py: the launcher must notice a dead rank
-        sys.exit("bench.py: injected failure of rank %d (launcher test)" % rank)
+    if os.environ.get("JRENDER_BENCH_FAIL_RANK") is not None:        # tests/test_parallel.py: the launcher must notice a dead rank
+        if os.environ["JRENDER_BENCH_FAIL_RANK"] == str(rank):
+            sys.exit("bench.py: injected failure of rank %d (launcher test)" % rank)
+        time.sleep(5.0)       # the injected failure must be the FIRST exit the launcher sees (on a box without a GPU the
+                              # healthy ranks die too, at the device query below, and used to win that race now and then)
     from jrender_amd import _ffi, comm as jcomm
     ndev = _ffi.device_count()
     if ndev < 1:
