@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""GPU box: forward (incl. set-up) / backward time of small and medium configurations under the run-time launch policy
+(jr_softras_set_launch_policy: heavy threshold x workgroup size), synchronised per step.  The table of
+profiles/r04_experiments.md call 28 comes from this script."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
