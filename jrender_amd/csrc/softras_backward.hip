@@ -138,12 +138,12 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     Dist dd;
     dd.sign = 0.f; dd.dx = 0.f; dd.dy = 0.f; dd.t0 = 0.f; dd.t1 = 0.f; dd.t2 = 0.f;
     if (DIST == 0) D = 1.f;                                               // SRK:1258-1270
-    else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_fast<tune::bwd_exact>(-dis, p); }
+    else if (DIST == 1) { dis = barycentric_dist(w); D = coverage_backward<tune::bwd_exact>(-dis, p); }
     else {
         // nothing is decided from the projection parameter here (sign and region come from the exact w)
         dd = euclidean_p2f<FAST, tune::bwd_tv_rcp ? TV_RCP : TV_IEEE>(r, meta, w, xp, yp);
         dis = dd.dx * dd.dx + dd.dy * dd.dy;
-        D = coverage_fast<tune::bwd_exact>(-dd.sign * dis, p);
+        D = coverage_backward<tune::bwd_exact>(-dd.sign * dis, p);
     }
     float ca = px.g3;                                                     // SRK:1281-1291
     if (p.alpha == 1) ca /= p.NF;

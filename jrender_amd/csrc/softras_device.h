@@ -422,6 +422,22 @@ __device__ inline float coverage_fast(float neg_num, const RasterParams& p) {
     return __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// The same coverage for the BACKWARD, where D * (1 - D) / sigma scales the whole distance gradient (SRK:1336): the plain
+// form rounds 1.0f + e first, and for e << 1 that quantises 1 - D to the ulp ABOVE 1 - twice the ulp below it, on which
+// the reference's D = (float)(1. / (1. + e)) lives.  With e = 1.58e-7 the reference holds 1 - D = 3 ulp, the plain form
+// 2 ulp: that pair's gradient comes out at 2/3 of the reference's (tests/golden/regress_saturated_coverage.npz: a 17^2
+// image with sigma 1e-6 has no unsaturated pair to hide it behind, 1.1e-3 of the largest gradient).  For e < 2^-10 the
+// quotient is 1 - e (1 - e) + O(e^3) with e^3 < 1e-9, far below the rounding step: ONE rounding of that value is the
+// reference's double quotient rounded to float.  Above 2^-10, 1 - D >= 1e-3 and an ulp of D is 1e-4 of it or less.
+template <int EX = 0>
+__device__ inline float coverage_backward(float neg_num, const RasterParams& p) {
+    if (EX & 1) return (float)(1.0 / (1.0 + (double)expf(neg_num / p.sigma)));
+    const float e = p.consts_safe ? __builtin_amdgcn_exp2f(neg_num * p.rs_log2e) : fast_exp(neg_num / p.sigma);
+    const float far_ = __builtin_amdgcn_rcpf(1.0f + e);
+    const float near_ = __builtin_fmaf(-e, 1.0f - e, 1.0f);
+    return e < 0x1p-10f ? near_ : far_;
+}
+
 // 'surface' sampler texel choice (SRK:159-166, identical in SRK:1138-1145)
 __device__ inline int surface_texel(const Bary& c, int R) {
     const int wx = (int)fminf(c.w0 * R, (float)(R - 1));
