@@ -29,7 +29,7 @@ struct BinWorkspace {
     int heavy_min = tune::fwd_heavy;
     long heavy_bound = -1;
     mutable int heavy_waves_used = 0;          // what the last forward launch really used (8 falls back to 4 when the LDS opt-in is refused)
-    mutable unsigned lds_optin_ok = 0, lds_optin_tried = 0;   // per (dist, rgb, K class) instantiation of the 8-wavefront kernel: > 64 KB of dynamic LDS granted on this device
+    mutable unsigned long long lds_optin_ok = 0, lds_optin_tried = 0;   // per (dist, rgb, K class) instantiation of the 8-wavefront kernel: > 64 KB of dynamic LDS granted on this device
 };
 
 // Launch order of the bins (k_bin_alloc_schedule): ~12 buckets per octave of the list length, heaviest first.  Bins in

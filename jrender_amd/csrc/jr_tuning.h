@@ -96,6 +96,9 @@
 #ifndef JR_TUNE_FWD_EXACT         // forward colour path in the reference's own (slow) arithmetic: bit 0 coverage sigmoid, bit 1 softmax exponential (A/B for tools/grad_parity.py)
 #define JR_TUNE_FWD_EXACT 0
 #endif
+#ifndef JR_TUNE_FWD_HARD_EXACT    // 'hard' alpha: the inside distance with the reference's IEEE quotients (its D > 0.5 decision rides on it); 0 = round 3's behaviour, for the A/B of what the uniform branch costs the other modes
+#define JR_TUNE_FWD_HARD_EXACT 1
+#endif
 #ifndef JR_TUNE_BWD_EXACT         // backward: bit 0 coverage sigmoid, bit 1 softmax exponential, bit 2 IEEE divisions by ssum / D / (1 - D), bit 3 IEEE divisions by sigma / gamma / (near - far)
 #define JR_TUNE_BWD_EXACT 0
 #endif
@@ -158,6 +161,7 @@ constexpr bool n3_line_walks = JR_TUNE_N3_LINE_WALKS != 0;
 constexpr int n3_line_parts = JR_TUNE_N3_LINE_PARTS;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr int fwd_exact = JR_TUNE_FWD_EXACT, bwd_exact = JR_TUNE_BWD_EXACT;
+constexpr bool fwd_hard_exact = JR_TUNE_FWD_HARD_EXACT != 0;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;

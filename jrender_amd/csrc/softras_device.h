@@ -342,17 +342,20 @@ __device__ inline Dist euclidean_p2f(const FaceGeo& r, int meta, const Bary& b, 
 // bit for bit the candidate's own dd = ex*ex + ey*ey; the nearest point and its barycentric offsets (six
 // selects per candidate) are only used by the backward.  An inside pixel is never culled by distance, so
 // its three projections only feed the coverage sigmoid (colour path, 1e-4): the 2nd and 3rd use a
-// reciprocal multiply.
-template <bool FAST>
-__device__ inline void euclidean_sign_dis(const FaceGeo& r, int meta, const Bary& b, float xp, float yp, float& sign,
-                                          float& dis) {
+// reciprocal multiply - UNLESS the alpha aggregation is 'hard' (EXACT_INSIDE: those launches run their own kernel
+// instantiations, DIST = 3; a wave-uniform run-time test in this place cost the other modes 2 % of the forward): D > 0.5
+// is then a decision taken from this very number (alpha_accumulate), and for a pixel centre within float noise of an
+// edge the distance IS noise - the reference's noise has to be reproduced bit for bit (fuzz seed 61 case 141, round 4:
+// true x / sigma = -9e-9, the reference's float arithmetic makes it < -9e-8, a 2-ulp quotient made it something else).
+template <bool FAST, bool EXACT_INSIDE>
+__device__ inline void euclidean_sign_dis(const FaceGeo& r, int meta, const Bary& b, float xp, float yp, float& sign, float& dis) {
     const bool inside = strictly_inside_t<FAST>(b);
     const int v0 = outside_edge(r, face_obtuse(meta), b, xp, yp);
     const EdgeCand c = edge_candidate<FAST>(r, b, inside ? 0 : (v0 < 0 ? 0 : v0), !inside);
     if (inside) {
         float best = 100000000.f;                    // SRK:68: candidates that are not < 1e8 (NaN) leave dis = 0
         if (c.dd < best) best = c.dd;
-        constexpr int TVI = tune::fwd_inside_rcp ? TV_RCP : TV_IEEE;
+        constexpr int TVI = (tune::fwd_inside_rcp && !EXACT_INSIDE) ? TV_RCP : TV_IEEE;
         const float d1 = edge_candidate<FAST, TVI>(r, b, 1, false).dd;
         const float d2 = edge_candidate<FAST, TVI>(r, b, 2, false).dd;
         if (d1 < best) best = d1;
@@ -375,12 +378,12 @@ __device__ inline float euclidean_outside_dis(const FaceGeo& r, int meta, const 
 }
 // ... and an INSIDE pixel's (SRK:68-105; sign = +1): nearest of the three edge projections, strict '<' from 1e8.
 // Only the coverage sigmoid reads it (colour path): the 2nd / 3rd projection use the reciprocal multiply.
-template <bool FAST>
+template <bool FAST, bool EXACT_INSIDE>
 __device__ inline float euclidean_inside_dis(const FaceGeo& r, const Bary& b) {
     float best = 100000000.f;                        // SRK:68: candidates that are not < 1e8 (NaN) leave dis = 0
     const float d0 = edge_candidate<FAST>(r, b, 0, false).dd;
     if (d0 < best) best = d0;
-    constexpr int TVI = tune::fwd_inside_rcp ? TV_RCP : TV_IEEE;
+    constexpr int TVI = (tune::fwd_inside_rcp && !EXACT_INSIDE) ? TV_RCP : TV_IEEE;   // 'hard' alpha decides D > 0.5 from this distance: the reference's bits (see euclidean_sign_dis)
     const float d1 = edge_candidate<FAST, TVI>(r, b, 1, false).dd;
     const float d2 = edge_candidate<FAST, TVI>(r, b, 2, false).dd;
     if (d1 < best) best = d1;

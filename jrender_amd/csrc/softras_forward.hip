@@ -245,7 +245,7 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
         D = coverage_fast<tune::fwd_exact>(neg_num, p);
     } else {                                                                   // SRK:340-344
         float sign, dis;
-        if (tune::fwd_dis_only) euclidean_sign_dis<FAST>(r, meta, w, xp, yp, sign, dis);
+        if (tune::fwd_dis_only) euclidean_sign_dis<FAST, DIST == 3>(r, meta, w, xp, yp, sign, dis);
         else {
             const Dist dd = euclidean_p2f<FAST>(r, meta, w, xp, yp);
             sign = dd.sign;
@@ -545,7 +545,7 @@ __device__ inline unsigned long long pixel_masks(const RasterParams& p, const Fa
     float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool have = lane < fill;
     if (have) box = *reinterpret_cast<const float4*>(&s_rec[lane]);
-    constexpr bool PRE = DIST == 2 && tune::fwd_prepass;
+    constexpr bool PRE = DIST >= 2 && tune::fwd_prepass;
     unsigned long long cx[8], ry[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -746,10 +746,10 @@ __device__ inline float4 evaluate_pair(const RasterParams& p, const FaceRec& r, 
 }
 
 // coverage of a deferred (inside) pair -> (D, aux) of its cell
-template <bool FAST>
+template <bool FAST, bool EXACT_INSIDE>
 __device__ inline float2 evaluate_inside(const RasterParams& p, const FaceRec& r, float xp, float yp, unsigned aux) {
     const Bary w = barycentric(r, xp, yp);
-    const float neg_num = -euclidean_inside_dis<FAST>(r, w);
+    const float neg_num = -euclidean_inside_dis<FAST, EXACT_INSIDE>(r, w);
     const float D = coverage_fast<tune::fwd_exact>(neg_num, p);
     if (p.alpha == 0) {
         const float x = (neg_num == 0.f || in_fast_range(neg_num)) ? div_known<FAST>(neg_num, p.sigma, p.r_sigma) : neg_num / p.sigma;
@@ -921,7 +921,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
                     else cell = evaluate_pair<DIST, RGB, false>(p, r, c.x, c.y, pr & 63u, deferred);
                     s_cell[q] = cell;
                 }
-                if (DIST == 2) {
+                if (DIST >= 2) {
                     const unsigned long long im = ballot(deferred);
                     if (im) {
                         int at = 0;
@@ -934,7 +934,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
             }
             __syncthreads();                                                   // D: cells, inside list
             if (wid == 0) clk.lap(3);
-            if (DIST == 2) {
+            if (DIST >= 2) {
                 const int nin = s_misc[3];
                 for (int i0 = wid * 64; i0 < nin; i0 += 256) {                 // ---- inside pairs: lane = pair ----
                     const int i = i0 + lane;
@@ -945,8 +945,8 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
                         const float2 c = s_pix[pr >> 6];
                         const unsigned aux = __builtin_bit_cast(unsigned, s_cell[q].w);
                         float2 da;
-                        if (face_safe(r.meta) && p.consts_safe) da = evaluate_inside<true>(p, r, c.x, c.y, aux);
-                        else da = evaluate_inside<false>(p, r, c.x, c.y, aux);
+                        if (face_safe(r.meta) && p.consts_safe) da = evaluate_inside<true, DIST == 3>(p, r, c.x, c.y, aux);
+                        else da = evaluate_inside<false, DIST == 3>(p, r, c.x, c.y, aux);
                         *reinterpret_cast<float2*>(&s_cell[q].z) = da;
                     }
                 }
@@ -1187,8 +1187,8 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                         const float2 c = s_pix[pr >> 6];
                         const unsigned aux = __builtin_bit_cast(unsigned, cells[q].w);
                         float2 da;
-                        if (face_safe(r.meta) && p.consts_safe) da = evaluate_inside<true>(p, r, c.x, c.y, aux);
-                        else da = evaluate_inside<false>(p, r, c.x, c.y, aux);
+                        if (face_safe(r.meta) && p.consts_safe) da = evaluate_inside<true, DIST == 3>(p, r, c.x, c.y, aux);
+                        else da = evaluate_inside<false, DIST == 3>(p, r, c.x, c.y, aux);
                         *reinterpret_cast<float2*>(&cells[q].z) = da;
                     }
                 };
@@ -1209,7 +1209,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                         else cell = evaluate_pair<DIST, RGB, false>(p, r, c.x, c.y, pr & 63u, deferred);
                         cells[q] = cell;
                     }
-                    if (DIST == 2) {
+                    if (DIST >= 2) {
                         const unsigned long long im = ballot(deferred);
                         if (im) {
                             const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(im >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)im, 0u));
@@ -1219,7 +1219,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                         }
                     }
                 }
-                if (DIST == 2 && n_in > 0) run_inside(0, n_in);
+                if (DIST >= 2 && n_in > 0) run_inside(0, n_in);
                 if (wid == tune::sections_wave) clk.lap(3);
             }
             a_valid = e_valid; a_batch = e_batch;
@@ -1331,7 +1331,7 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
         if (eight && mixed_lds_bytes(8) > 65536) {
             // more than 64 KB of dynamic LDS per workgroup is an opt-in PER DEVICE and per kernel instantiation: asked once
             // per context (= device) and instantiation; a refusal falls back to four wavefronts instead of a failed launch
-            const unsigned bit = 1u << ((DIST * 3 + RGB) * 3 + (KCAP <= 16 ? 0 : (KCAP <= 32 ? 1 : 2)));
+            const unsigned long long bit = 1ull << ((DIST * 3 + RGB) * 3 + (KCAP <= 16 ? 0 : (KCAP <= 32 ? 1 : 2)));
             if (!(ws.lds_optin_tried & bit)) {
                 ws.lds_optin_tried |= bit;
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softras_forward_mixed<DIST, RGB, KCAP, 8>),
@@ -1368,7 +1368,10 @@ void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* 
                             const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
 #define JR_FWD(D, R) launch_k<D, R>(st, p, textures, ws, aggrs, rgba, ids)
     const int rgb = p.rgb == 0 ? 0 : (p.rgb == 1 ? 1 : 2);
-    switch (p.dist * 3 + rgb) {
+    // DIST = 3: euclidean distance under 'hard' alpha - the inside distance keeps the reference's IEEE quotients because
+    // D > 0.5 is decided from it (softras_device.h: euclidean_sign_dis); its own instantiations, so the other modes pay nothing
+    const int dist = (p.dist == 2 && p.alpha == 0 && tune::fwd_hard_exact) ? 3 : p.dist;
+    switch (dist * 3 + rgb) {
         case 0: JR_FWD(0, 0); break;
         case 1: JR_FWD(0, 1); break;
         case 2: JR_FWD(0, 2); break;
@@ -1377,7 +1380,10 @@ void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* 
         case 5: JR_FWD(1, 2); break;
         case 6: JR_FWD(2, 0); break;
         case 7: JR_FWD(2, 1); break;
-        default: JR_FWD(2, 2); break;
+        case 8: JR_FWD(2, 2); break;
+        case 9: JR_FWD(3, 0); break;
+        case 10: JR_FWD(3, 1); break;
+        default: JR_FWD(3, 2); break;
     }
 #undef JR_FWD
 }

@@ -122,7 +122,9 @@ def test_fuzz_regressions(ctx, port, path):
     'hard' alpha (D > 0.5) used to be decided on the approximate sigmoid.  regress_saturated_coverage (round 4, with the
     upstream gradient of the failing run): a 17^2 image with sigma 1e-6 - every pair saturated, so the 1 - D of a pair
     at x / sigma = 15.7 (three ulp in the reference, two from a sigmoid that rounds 1 + e first) showed as 1.1e-3 of
-    the largest gradient; the backward now rounds 1 / (1 + e) once (softras_device.h: coverage_backward)."""
+    the largest gradient; the backward now rounds 1 / (1 + e) once (softras_device.h: coverage_backward).
+    regress_hard_alpha_inside_noise (round 4): a pixel centre 3e-7 inside an edge - its squared distance (1e-13) is float
+    noise, 'hard' alpha decides D > 0.5 from it, so with 'hard' alpha the inside distance keeps the reference's IEEE quotients."""
     z = np.load(path)
     run_case(ctx, port, z["fv"], z["tex"], g=z["g"] if "g" in z.files else None, **eval(str(z["kw"])))
 
