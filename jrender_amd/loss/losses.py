@@ -68,6 +68,16 @@ def neg_iou_loss_backward(predict, target):
     return (-(target * U - I * (1 - target)) / (U * U) / n).astype(F32)
 
 
+def _csr_arrays(m):
+    """Dense [n,n] float matrix -> (rowptr int32 [n+1], col int32 [nnz], val float32 [nnz]), columns ascending per row
+    (the order jr_laplacian_loss sums a row in)."""
+    m = np.asarray(m)
+    rows, cols = np.nonzero(m)                       # row-major: rows ascending, columns ascending within a row
+    rowptr = np.zeros(m.shape[0] + 1, np.int32)
+    np.cumsum(np.bincount(rows, minlength=m.shape[0]), out=rowptr[1:])
+    return rowptr, cols.astype(np.int32), m[rows, cols].astype(F32)
+
+
 class _DeviceLoss:
     """Per-mesh loss values [B] on the device; ``float(x)`` / ``x.numpy()`` download (and average if the loss was
     built with average=True) — the only points that wait for the GPU."""
@@ -140,13 +150,8 @@ class LaplacianLoss:
         """(rowptr, col, val) of L and of its transpose on the device, uploaded once per context."""
         cache = self.__dict__.setdefault("_dev", {})
         if id(ctx) not in cache:
-            def csr(m):
-                nz = [np.nonzero(row)[0] for row in m]
-                rowptr = np.concatenate([[0], np.cumsum([len(c) for c in nz])]).astype(np.int32)
-                col = np.concatenate(nz).astype(np.int32) if len(nz) else np.zeros(0, np.int32)
-                val = np.concatenate([row[c] for row, c in zip(m, nz)]).astype(F32)
-                return ctx.array(rowptr), ctx.array(col), ctx.array(val)
-            cache[id(ctx)] = (ctx,) + csr(self.laplacian) + csr(np.ascontiguousarray(self.laplacian.T))
+            arrays = _csr_arrays(self.laplacian) + _csr_arrays(np.ascontiguousarray(self.laplacian.T))
+            cache[id(ctx)] = (ctx,) + tuple(ctx.array(a) for a in arrays)
         return cache[id(ctx)][1:]
 
     def value_and_grad(self, x, want_grad=True):

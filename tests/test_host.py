@@ -302,3 +302,49 @@ def test_lighting_derivative_mask_belongs_to_the_last_call():
     L.light_mode = 'vertex'
     L(mesh(np.full((1, v.shape[0], 4, 3), 0.5, np.float32)), eyes=np.array([[0, 0, -2.7]], np.float32))
     assert L._last is None
+
+
+def test_csr_arrays_of_the_laplacian_match_scipy():
+    """The (rowptr, col, val) triple the device Laplacian kernel walks is the matrix: against scipy's CSR and a dense product."""
+    import jrender_amd as jr
+    from jrender_amd.loss.losses import _csr_arrays
+    from scipy.sparse import csr_matrix
+    v, f = jr.synthetic.uv_sphere(10, 7)
+    lap = jr.LaplacianLoss(v, f).laplacian
+    for m in (lap, np.ascontiguousarray(lap.T)):
+        rowptr, col, val = _csr_arrays(m)
+        ref = csr_matrix(m)
+        ref.sort_indices()
+        assert np.array_equal(rowptr, ref.indptr) and np.array_equal(col, ref.indices) and np.array_equal(val, ref.data)
+        x = np.random.default_rng(0).normal(size=(m.shape[0], 3)).astype(np.float32)
+        y = np.stack([(val[rowptr[i]:rowptr[i + 1], None] * x[col[rowptr[i]:rowptr[i + 1]]]).sum(0) for i in range(m.shape[0])])
+        assert np.allclose(y, m @ x, atol=1e-5)
+    rp, c, vl = _csr_arrays(np.zeros((3, 3), np.float32))
+    assert np.array_equal(rp, [0, 0, 0, 0]) and c.size == 0 and vl.size == 0
+
+
+def test_single_rounding_sigmoid_of_the_backward_is_the_references_float():
+    """softras_device.h: coverage_backward.  For e < 2^-10 the backward takes D = fma(-e, 1 - e, 1); the claim is that this ONE
+    rounding of 1 - e + e^2 is the reference's D = (float)(1. / (1. + e)) (SRK:338 / :344 evaluate in double), while the plain
+    float form 1 / (1.0f + e) is not (it quantises 1 - D to the ulp above 1).  Emulated in NumPy: float32 steps, the fma's
+    exact product-sum in float64 (48-bit product + 1: rounding to double first moves the result by < 2^-53)."""
+    r = np.random.default_rng(0)
+    e = np.exp(r.uniform(np.log(1e-12), np.log(2.0 ** -10), 2_000_000)).astype(np.float32)
+    ref = (1.0 / (1.0 + e.astype(np.float64))).astype(np.float32)
+    t = (np.float32(1) - e).astype(np.float32)
+    near = (1.0 - e.astype(np.float64) * t.astype(np.float64)).astype(np.float32)
+    plain = (np.float32(1) / (np.float32(1) + e)).astype(np.float32)
+    assert (near != ref).mean() < 1e-3                      # (2.6e-4: e^3 within reach of a rounding boundary, near e = 1e-3 only)
+    one_minus = lambda d: 1.0 - d.astype(np.float64)        # noqa: E731
+    bad = near != ref
+    assert np.abs(one_minus(near[bad]) / one_minus(ref[bad]) - 1).max() < 0.06          # and then by one ulp of a 1 - D of >= 19 ulp
+    assert (plain != ref).mean() > 0.2
+    m = one_minus(ref) > 0
+    assert np.abs(one_minus(plain[m]) / one_minus(ref[m]) - 1).max() > 0.3              # the plain form: 1 - D off by up to 100 %
+    # the pair of fuzz seed 61 case 94: x / sigma = 15.6576
+    e1 = np.float32(np.exp(-15.6576))
+    d_ref = np.float32(1.0 / (1.0 + float(e1)))
+    d_plain = np.float32(1) / (np.float32(1) + e1)
+    d_near = np.float32(1.0 - float(e1) * float(np.float32(1) - e1))
+    ulp = 2.0 ** -24
+    assert round((1 - float(d_ref)) / ulp) == 3 and round((1 - float(d_plain)) / ulp) == 2 and d_near == d_ref
