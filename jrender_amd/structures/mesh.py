@@ -17,11 +17,11 @@ __all__ = ["Mesh", "face_vertices", "join_meshes_as_scene"]
 
 F32 = np.float32
 
-_device_cache = {}          # (context id, kind, shape, content hash) -> DeviceArray: face arrays / default textures
+_device_cache = {}          # (context id, kind, shape, content) -> DeviceArray: face arrays / default textures
 
 
 def _cached_device(ctx, kind, shape, content, make):
-    key = (id(ctx), kind, tuple(shape), hash(content))
+    key = (id(ctx), kind, tuple(shape), content)     # the content itself (bytes of a face array): equal keys ARE equal arrays
     hit = _device_cache.get(key)
     if hit is None or hit.ctx is not ctx or hit.ptr is None:
         if len(_device_cache) >= 16:

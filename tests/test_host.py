@@ -348,3 +348,30 @@ def test_single_rounding_sigmoid_of_the_backward_is_the_references_float():
     d_near = np.float32(1.0 - float(e1) * float(np.float32(1) - e1))
     ulp = 2.0 ** -24
     assert round((1 - float(d_ref)) / ulp) == 3 and round((1 - float(d_plain)) / ulp) == 2 and d_near == d_ref
+
+
+def test_device_face_cache_is_keyed_on_content():
+    """structures/mesh.py uploads a face array once per distinct array: equal content -> the same device buffer, different
+    content -> another one (the key is the content itself, not a hash of it), and the cache stays bounded.  A stand-in context:
+    no GPU needed."""
+    from jrender_amd.structures import mesh as M
+
+    class Arr:
+        def __init__(self, ctx, a):
+            self.ctx, self.ptr, self.a = ctx, 1, a
+
+    class Ctx:
+        def array(self, a):
+            return Arr(self, np.array(a))
+
+    c, other = Ctx(), Ctx()
+    f1 = np.arange(12, dtype=np.int32).reshape(4, 3)
+    a, b, d = M.device_faces(c, f1), M.device_faces(c, f1.copy()), M.device_faces(c, f1[::-1].copy())
+    assert a is b and d is not a and np.array_equal(d.a, f1[::-1])
+    assert M.device_faces(other, f1) is not a                      # per context
+    for i in range(40):
+        M.device_faces(c, f1 + i)
+    assert len(M._device_cache) <= 16
+    assert M._shared_faces(np.broadcast_to(f1[None], (5, 4, 3))) is not None
+    two = np.stack([f1, f1[:, ::-1]])
+    assert M._shared_faces(two) is None and M._shared_faces(np.stack([f1, f1])) is not None
