@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GPU box: where do the raster kernels spend their (wall-clock, per-wavefront) time?  Needs the instrumented
 build (python tools/ablate/build.py sections): s_memtime laps per section, summed over wavefronts.  The laps
-perturb the kernels (each is an s_memtime + s_waitcnt): read the SHARES, not the totals."""
+perturb the kernels (each is an s_memtime + s_waitcnt): read the SHARES, not the totals.
+    python tools/ablate/sections.py [--heavy] [--shape faces,views,image_size[,sigma[,rgb]]]"""
 import os
 import sys
 
@@ -15,11 +16,18 @@ from jrender_amd import _ffi, synthetic as syn                                  
 from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction   # noqa: E402
 
 ctx = _ffi.Context(0)
-NB = 1 if HEAVY else 8
-fv, tex = syn.sphere_views(39000, NB)
+NB, NF, IS, KW = (1 if HEAVY else 8), 39000, 1024, {}
+if "--shape" in sys.argv:          # --shape faces,views,image_size[,sigma[,rgb]]   e.g. config 4's operator call: --heavy --shape 3300,64,64,1e-4,hard
+    a = sys.argv[sys.argv.index("--shape") + 1].split(",")
+    NF, NB, IS = int(a[0]), int(a[1]), int(a[2])
+    if len(a) > 3:
+        KW["sigma_val"] = float(a[3])
+    if len(a) > 4:
+        KW["aggr_func_rgb"] = a[4]
+fv, tex = syn.sphere_views(NF, NB)
 fv, tex = ctx.array(fv), ctx.array(tex)
-g = ctx.array(np.random.default_rng(7).uniform(-1, 1, (NB, 4, 1024, 1024)).astype(np.float32))
-fn = SoftRasterizeFunction(image_size=1024, ctx=ctx)
+g = ctx.array(np.random.default_rng(7).uniform(-1, 1, (NB, 4, IS, IS)).astype(np.float32))
+fn = SoftRasterizeFunction(image_size=IS, ctx=ctx, **KW)
 for _ in range(2):
     fn.execute(fv, tex); fn.grad(g)
 ctx.section_clocks()
