@@ -564,82 +564,11 @@ def bench_softras(args, ctx, comm, rank, world):
 
 def launch_ranks(n, argv, timeout_s=1500.0):
     """`python bench.py --gpus N` outside any launcher: start N ranks of this script (one process per GPU, each its
-    own process group), rendezvous through a private 0700 directory, relay rank 0's JSON line.  ALL children are
-    polled: if any rank exits non-zero (or the whole launch exceeds timeout_s) before the others are done, the rest
-    is killed and the launcher exits non-zero with the tail of the failing rank's stderr (every rank's stderr goes
-    to a file in the rendezvous directory) - a rank that dies before ncclCommInitRank completes must not leave rank 0
-    waiting for ever."""
-    import signal
-    rdzv = tempfile.mkdtemp(prefix="jrender_bench_")
-    procs, logs = [], []
-    for r in range(n):
-        # HSA_ENABLE_IPC_MODE_LEGACY=0: the MI355X host driver of this pool only supports dmabuf IPC; RCCL's
-        # cross-process buffer registration fails with `hipIpcGetMemHandle: invalid argument` without it.  An
-        # explicit setting in the caller's environment wins.
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   JRENDER_RDZV=os.path.join(rdzv, "rdzv"), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        out = open(os.path.join(rdzv, "rank%d.out" % r), "w+b")
-        err = open(os.path.join(rdzv, "rank%d.err" % r), "w+b")
-        logs.append((out, err))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=out, stderr=err, start_new_session=True))
-
-    def tail(f, nbytes=3000):
-        f.flush(); f.seek(0, 2); size = f.tell(); f.seek(max(0, size - nbytes))
-        return f.read().decode(errors="replace")
-
-    def kill_all():
-        for q in procs:
-            if q.poll() is None:
-                try:
-                    os.killpg(q.pid, signal.SIGKILL)       # the rank's own process group (start_new_session)
-                except OSError:
-                    pass
-        for q in procs:
-            try:
-                q.wait(timeout=10)
-            except Exception:
-                pass
-
-    failure, t0 = None, time.time()
-    while failure is None and any(q.poll() is None for q in procs):
-        for r, q in enumerate(procs):
-            rc = q.poll()
-            if rc not in (None, 0):
-                failure = "rank %d exited with code %d" % (r, rc)
-                break
-        else:
-            if time.time() - t0 > timeout_s:
-                failure = "launch exceeded %.0f s" % timeout_s
-            else:
-                time.sleep(0.05)
-    if failure is None:
-        bad = [(r, q.returncode) for r, q in enumerate(procs) if q.returncode]
-        if bad:
-            failure = "rank %d exited with code %d" % bad[0]
-    if failure is not None:
-        kill_all()
-        sys.stderr.write("bench.py: %s; exit codes %s\n" % (failure, [q.returncode for q in procs]))
-        for r, (_o, e) in enumerate(logs):
-            t = tail(e).strip()
-            if t:
-                sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, t))
-    else:
-        sys.stdout.write(tail(logs[0][0], 1 << 20))
-        sys.stdout.flush()
-        for r, (_o, e) in enumerate(logs):                 # warnings of healthy ranks stay visible
-            t = tail(e).strip()
-            if t:
-                sys.stderr.write("---- rank %d stderr ----\n%s\n" % (r, t))
-    for o, e in logs:
-        o.close(); e.close()
-    try:
-        for f in os.listdir(rdzv):
-            os.unlink(os.path.join(rdzv, f))
-        os.rmdir(rdzv)
-    except OSError:
-        pass
-    if failure is not None:
+    own process group), rendezvous through a private 0700 directory, relay rank 0's JSON line.  ALL children are polled
+    (jrender_amd/parallel.py: launch_ranks): a rank that exits non-zero - e.g. before ncclCommInitRank completes - ends
+    the launch at once, the others are killed, and the launcher exits non-zero with the dead rank's stderr tail."""
+    from jrender_amd.parallel import launch_ranks as _launch
+    if _launch(os.path.abspath(__file__), n, argv, timeout_s=timeout_s, name="bench.py"):
         sys.exit(1)
 
 

@@ -13,11 +13,14 @@ Without -i/-c (the reference's data files are not shipped here) the target is sy
 squashed, shifted ellipsoid seen from a ring of cameras.  With several ranks every rank renders its slice of
 the views; the vertex gradient (the mesh is shared by all views) is summed with one all-reduce.
 
---front-end device (default): the 16 KB vertex set goes to the GPU once per iteration and everything between it and
-the vertex gradient stays there — camera kernel (one vertex set broadcast over the views), face gather, SoftRas
-forward, IoU loss + its gradient, SoftRas backward, scatter to the vertices + camera VJP summed over the views,
-RCCL all-reduce, Laplacian and flatten regularisers with their gradients — and three 16 KB gradients come back.  --front-end host runs the same chain through the NumPy mirrors (the
-6 MB face arrays cross PCIe twice per iteration); both produce the same loss curve (tests/test_gpu_named_configs.py).
+--front-end device (default): NOTHING of an iteration runs on the host (round 5).  Template, displacement map, centre and
+the Adam moments live on the GPU; an iteration is a chain of launches on one stream - parametrisation kernel, camera kernel
+(one vertex set broadcast over the views), face gather, SoftRas forward, IoU loss + its gradient, SoftRas backward, scatter to
+the vertices + camera VJP summed over the views, RCCL all-reduce, Laplacian and flatten regularisers with their gradients, the
+parametrisation's VJP (which also combines the three gradients), one Adam launch per parameter - and the three loss terms of
+the iteration land in a history array ON the device, downloaded when a line is printed (every 20 iterations) and at the end.
+--front-end host runs the same chain through the NumPy mirrors (the 6 MB face arrays cross PCIe twice per iteration); both
+produce the same loss curve (tests/test_gpu_named_configs.py, tests/test_gpu_device_chain.py).
 """
 import argparse
 import os
@@ -32,39 +35,7 @@ from jrender_amd import comm as jcomm                                        # n
 from jrender_amd.parallel import shard_bounds                                # noqa: E402
 
 
-class Model:
-    """demo2-deform.py:17-47 with an explicit backward."""
-
-    def __init__(self, vertices, faces):
-        self.vertices = (np.asarray(vertices, np.float32) * 0.5)[None]      # [1,nv,3], |v| < 1
-        self.faces = np.asarray(faces, np.int32)[None]
-        self.displace = np.zeros_like(self.vertices)
-        self.center = np.zeros((1, 1, 3), np.float32)
-        self.laplacian_loss = jr.LaplacianLoss(self.vertices[0], self.faces[0])
-        self.flatten_loss = jr.FlattenLoss(self.faces[0])
-
-    def parameters(self):
-        return [self.displace, self.center]
-
-    def forward(self):
-        a = np.abs(self.vertices)
-        with np.errstate(divide="ignore"):
-            base = np.log(a / (1 - a))
-        self._c = np.tanh(self.center)
-        self._s = 1.0 / (1.0 + np.exp(-(base + self.displace)))
-        self._sign = np.sign(self.vertices)
-        u = self._s * self._sign
-        self._u = u
-        v = np.maximum(u, 0) * (1 - self._c) - np.maximum(-u, 0) * (self._c + 1) + self._c
-        return v.astype(np.float32)
-
-    def backward(self, g):
-        """g = d(loss)/d(vertices) [1,nv,3] -> (d/d displace, d/d center)."""
-        u, c = self._u, self._c
-        g_c = (g * (1 - np.maximum(u, 0) - np.maximum(-u, 0))).sum(1, keepdims=True)
-        g_u = g * ((u > 0) * (1 - c) + (u < 0) * (c + 1))
-        g_disp = g_u * self._sign * self._s * (1 - self._s)
-        return g_disp.astype(np.float32), (g_c * (1 - c * c)).astype(np.float32)
+Model = jr.DeformModel      # demo2-deform.py:17-47 with an explicit backward; on the GPU when given a context (jrender_amd/deform.py)
 
 
 def synthetic_target(renderer, template_v, faces, n_views):
@@ -112,7 +83,9 @@ def main(argv=None):
         tv, tf = jr.load_obj(args.template_vertices)                         # demo2-deform.py:61 (sphere_1352.obj)
     else:
         tv, tf = jr.synthetic.uv_sphere(52, 27)                               # 1 352-vertex class template
-    model = Model(tv, tf)
+    device = args.front_end == 'device'
+    ctx = jr.Context.default()
+    model = Model(tv, tf, ctx=ctx if device else None)
     renderer = jr.Renderer(image_size=args.image_size, sigma_val=1e-4, aggr_func_rgb='hard', camera_mode='look_at',
                            viewing_angle=15, dr_type='softras', bin_size=16, max_elems_per_bin=2700,
                            max_faces_per_pixel_for_grad=16)
@@ -125,77 +98,84 @@ def main(argv=None):
         target, cameras = synthetic_target(renderer, tv, tf, args.batch_size)
     B = target.shape[0]
     lo, hi = (0, B) if comm is None else shard_bounds(B, world)[rank]
+    nb = hi - lo
+    if nb < 1:                           # (cannot happen after the check above; every rank takes the SAME branch below whatever its share)
+        raise SystemExit("demo2_deform: rank %d got no view" % rank)
     renderer.transform.set_eyes_from_angles(cameras[lo:hi, 0], cameras[lo:hi, 1], cameras[lo:hi, 2])
     optimizer = jr.Adam(model.parameters(), 0.01, betas=(0.5, 0.99))
 
     t0 = time.time()
-    history = []
-    nb = hi - lo
-    ctx = jr.Context.default()
-    target_d = ctx.array(np.ascontiguousarray(target[lo:hi], np.float32)) if args.front_end == 'device' and nb else None
+    # per iteration: [sum of this rank's IoUs, Laplacian loss, flatten loss]
+    hist = ctx.zeros((max(args.iters, 1), 3)) if device else np.zeros((max(args.iters, 1), 3), np.float32)
+    target_d = ctx.array(np.ascontiguousarray(target[lo:hi], np.float32)) if device else None
+
+    def losses_upto(n):
+        """[n] total losses of iterations 0 .. n-1 (device front end: ONE download; the IoU sums of the ranks are added up)"""
+        h = hist.view(0, n).numpy() if device else hist[:n]
+        iou_sum = h[:, 0].astype(np.float64)
+        if comm is not None:
+            iou_sum = np.asarray(comm.all_reduce_sum_host(np.ascontiguousarray(iou_sum, np.float32)), np.float64)
+        return (1.0 - iou_sum / B) + 0.03 * h[:, 1] + 0.0003 * h[:, 2], h
+
     for it in range(args.iters):
-        vertices = model.forward()                                            # [1,nv,3]
-        if args.front_end == 'device' and nb:
+        vertices = model.forward()                                            # [1,nv,3] (device front end: a DeviceArray)
+        if device:
             # ONE vertex set on the device; the camera step broadcasts it over this rank's eyes (demo2-deform.py:45
             # materialises the copies with repeat())
-            vertices_d = ctx.array(vertices)
-            mesh = jr.Mesh(vertices_d, model.faces)
+            mesh = jr.Mesh(vertices, model.faces)
             pred = renderer.render_mesh(mesh, mode='silhouettes')             # DeviceArray [nb,IS,IS]
             iou, g_sil = jr.neg_iou_loss_and_grad(pred, target_d, total_views=B)
             g_v = renderer.grad_vertices(grad_silhouettes=g_sil)              # DeviceArray [1,nv,3]: summed over the views
             if comm is not None:
                 g_v = comm.all_reduce_sum(g_v)           # RCCL on the device buffer
-            # the regularisers: one launch each on the same device vertices; nothing so far has waited for the GPU
-            reg = model.laplacian_loss.value_and_grad(vertices_d) + model.flatten_loss.value_and_grad(vertices_d)
-            reg = tuple(r.numpy() for r in reg)
-            iou_sum = float(iou.numpy().sum())
-            if comm is not None:
-                iou_sum = comm.all_reduce_scalar(iou_sum, "sum")
-            g_v = g_v.numpy()
+            # the regularisers: value and gradient on the same device vertices; nothing has waited for the GPU
+            lap, g_lap = model.laplacian_loss.value_and_grad(vertices)
+            flat, g_flat = model.flatten_loss.value_and_grad(vertices)
+            # parametrisation VJP of g_v + 0.03 g_lap + 0.0003 g_flat (demo2-deform.py:85-88), Adam on the device
+            optimizer.step(model.backward(g_v, (0.03, g_lap), (0.0003, g_flat)))
+            ctx.scalar_accumulate(hist, 3 * it + 0, iou)
+            ctx.scalar_accumulate(hist, 3 * it + 1, lap.values)
+            ctx.scalar_accumulate(hist, 3 * it + 2, flat.values)
         else:
             mesh = jr.Mesh(np.repeat(vertices, nb, 0), np.repeat(model.faces, nb, 0))
             pred = renderer.render_mesh(mesh, mode='silhouettes').numpy().reshape(nb, args.image_size, args.image_size)
             # neg-IoU over ALL views: per-view IoUs are independent, so the local part is (1/B) * sum over local views
             inter = (pred * target[lo:hi]).sum((1, 2))
             union = (pred + target[lo:hi] - pred * target[lo:hi]).sum((1, 2)) + 1e-6
-            iou_sum = float((inter / union).sum())
             g_sil = jr.neg_iou_loss_backward(pred, target[lo:hi]) * (nb / B)      # that helper averages over its own batch
             g_v = renderer.grad_vertices(grad_silhouettes=g_sil.reshape(nb, 1, args.image_size, args.image_size)).sum(0, keepdims=True)
             if comm is not None:
                 g_v = comm.all_reduce_sum_host(g_v)          # [1,nv,3]: the mesh is shared by all views
-                iou_sum = comm.all_reduce_scalar(iou_sum, "sum")
             reg = (model.laplacian_loss(vertices), model.laplacian_loss.backward(vertices)) + model.flatten_loss.value_and_grad(vertices)
-        lap, flat = float(np.mean(reg[0])), float(np.mean(reg[2]))
-        loss = (1.0 - iou_sum / B) + 0.03 * lap + 0.0003 * flat
-        g_v = g_v + 0.03 * reg[1] + 0.0003 * reg[3]
-        optimizer.step(model.backward(g_v))
-        history.append(loss)
-        if rank == 0 and not args.quiet and (it % 20 == 0 or it == args.iters - 1):
-            print("iter %4d  loss %.4f  (1-IoU %.4f, laplacian %.4f, flatten %.4f)" % (it, loss, 1.0 - iou_sum / B, lap, flat), flush=True)
+            hist[it] = (float((inter / union).sum()), float(np.mean(reg[0])), float(np.mean(reg[2])))
+            optimizer.step(model.backward(g_v, (0.03, reg[1]), (0.0003, reg[3])))
+        if not args.quiet and (it % 20 == 0 or it == args.iters - 1):          # (every rank: the IoU sums are all-reduced)
+            loss, h = losses_upto(it + 1)
+            iou_all = B * (1.0 - (loss[it] - 0.03 * h[it, 1] - 0.0003 * h[it, 2]))
+            if rank == 0:
+                print("iter %4d  loss %.4f  (1-IoU %.4f, laplacian %.4f, flatten %.4f)" % (it, loss[it], 1.0 - iou_all / B, h[it, 1], h[it, 2]), flush=True)
+    if device:
+        ctx.synchronize()
+    history = [float(x) for x in losses_upto(args.iters)[0]] if args.iters else []
     main.loop_seconds = time.time() - t0           # the optimisation loop alone (bench.py's secondary.c4_demo2 reads it)
     if rank == 0 and not args.quiet:
         print("%d iterations, %d views on %d rank(s): %.2f s" % (args.iters, B, world, main.loop_seconds))
     if rank == 0 and args.history_out:
         np.save(args.history_out, np.asarray(history, np.float64))
     if rank == 0 and args.output:
-        jr.save_obj(args.output, model.forward()[0], model.faces[0])
+        jr.save_obj(args.output, np.asarray(model.forward().numpy() if device else model.forward())[0], model.faces[0])
     if comm is not None:
         comm.close()
     return history
 
 
 def launch_ranks(n, argv):
-    """Start n ranks of this script (one process per GPU) with a private file rendezvous."""
-    import subprocess
-    import tempfile
-    rdzv = os.path.join(tempfile.mkdtemp(prefix="jrender_demo2_"), "rdzv")
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
-                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                                       LOCAL_WORLD_SIZE=str(n), JRENDER_RDZV=rdzv))
-             for r in range(n)]
-    rcs = [p.wait() for p in procs]
-    if any(rcs):
-        raise SystemExit("demo2_deform: rank exit codes %s" % rcs)
+    """Start n ranks of this script (one process per GPU) with a private rendezvous; every rank is polled, a rank that dies
+    (e.g. before ncclCommInitRank) ends the launch with its stderr instead of leaving the others blocked
+    (jrender_amd/parallel.py: launch_ranks, the launcher bench.py --gpus N uses)."""
+    from jrender_amd.parallel import launch_ranks as _launch
+    if _launch(os.path.abspath(__file__), n, argv, name="demo2_deform.py"):
+        raise SystemExit(1)
 
 
 if __name__ == '__main__':

@@ -164,13 +164,35 @@ int jr_neg_iou_loss(jr_ctx* ctx, const float* predict, const float* target, floa
  * (rowptr [NV+1], col, val) and, for the gradient 2 L^T L x_b * grad_scale, its transpose in CSR too; scratch
  * [B,NV,3] floats.  FlattenLoss (jrender/loss/flatten_loss.py:5-80): loss[b] = sum over the NE edges shared by two
  * faces of (cos + 1)^2, (v0s, v1s) the edge, (v2s, v3s) the two opposite vertices; gradient * grad_scale (float
- * atomics).  vertices / grad_vertices [B,NV,3]; grad_vertices may be NULL. */
+ * atomics).  vertices / grad_vertices [B,NV,3]; grad_vertices may be NULL.  Both run a grid per mesh (rows / edges) with a
+ * two-stage sum of the loss, so that they scale past one compute unit (a 39k-face mesh has 19 502 vertices). */
 int jr_laplacian_loss(jr_ctx* ctx, const int32_t* rowptr, const int32_t* col, const float* val,
                       const int32_t* rowptr_t, const int32_t* col_t, const float* val_t, const float* vertices,
                       float* scratch, float* loss, float* grad_vertices, int B, int NV, float grad_scale);
 int jr_flatten_loss(jr_ctx* ctx, const int32_t* v0s, const int32_t* v1s, const int32_t* v2s, const int32_t* v3s,
                     const float* vertices, float* loss, float* grad_vertices, int B, int NV, int NE, float eps,
                     float grad_scale);
+/* The optimiser side of the deformation loop (BASELINE configs[3]), Jittor tensor ops + autograd + nn.Adam in the
+ * reference, all on the GPU there (demo2-deform.py:17-40, :72, :85-88) and here:
+ * jr_deform_vertices_forward   Model.execute, demo2-deform.py:35-41: vertices [NV,3] from the template (already scaled by
+ *     0.5, |t| < 1), the displacement map [NV,3] and the centre [3]:
+ *       u = sigmoid(log(|t| / (1 - |t|)) + displace) * sign(t);  c = tanh(center);  v = relu(u)(1 - c) - relu(-u)(c + 1) + c
+ * jr_deform_vertices_backward  its VJP for the upstream gradient w0*grad0 + w1*grad1 + w2*grad2 (each [NV,3]; grad1 / grad2
+ *     may be NULL: the silhouette term and the two regularisers of demo2-deform.py:85-88 are combined here) ->
+ *     grad_displace [NV,3], grad_center [3] (a deterministic two-stage sum over the vertices).
+ * jr_adam_step   one step of nn.Adam (demo2-deform.py:72) on n floats, in place on param / m / v (m, v start at zero);
+ *     step counts from 1; scalars are doubles like the Python floats of the host mirror (jrender_amd/optim.py), which
+ *     this kernel reproduces operation by operation:  p -= (lr / (1 - b0^t)) m / (sqrt(v / (1 - b1^t)) + eps).
+ * jr_scalar_accumulate   dst[0] = (accumulate ? dst[0] : 0) + bias + scale * sum(src[0..n)): loss terms stay on the
+ *     device (e.g. one slot of a history array per iteration) and are read when the caller wants the number. */
+int jr_deform_vertices_forward(jr_ctx* ctx, const float* template_vertices, const float* displace, const float* center,
+                               float* vertices, int NV);
+int jr_deform_vertices_backward(jr_ctx* ctx, const float* template_vertices, const float* displace, const float* center,
+                                const float* grad0, float w0, const float* grad1, float w1, const float* grad2, float w2,
+                                float* grad_displace, float* grad_center, int NV);
+int jr_adam_step(jr_ctx* ctx, float* param, const float* grad, float* m, float* v, size_t n, double lr, double beta0,
+                 double beta1, double eps, double weight_decay, int step);
+int jr_scalar_accumulate(jr_ctx* ctx, float* dst, const float* src, int n, float scale, float bias, int accumulate);
 int jr_avgpool2x2_forward(jr_ctx* ctx, const float* in, float* out, int planes, int H, int W);
 int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, int planes, int H,
                            int W);
@@ -250,7 +272,7 @@ int jr_selftest_division(jr_ctx* ctx, uint64_t n, uint32_t seed, uint64_t* misma
 int jr_selftest_reciprocal(jr_ctx* ctx, uint64_t* mismatches);
 
 /* ---- introspection for tests / benchmarks ---------------------------------------- */
-/* statistics of the last forward on this context: [0]=bin-face pairs, [1]=non-empty 32x32 bins,
+/* statistics of the last forward on this context: [0]=bin-face pairs, [1]=non-empty bins,
  * [2]=max faces in a bin, [3]=bins per image */
 int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]);
 /* which paths the last launches took: [0]=1 when the last forward ran the multi-wavefront kernel (launches of up to 4 Mpixels),
@@ -258,11 +280,23 @@ int jr_softras_last_stats(jr_ctx* ctx, int64_t stats[4]);
  * [3]=the heavy-bin threshold in force (listed faces) */
 int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]);
 /* Launch policy of the multi-wavefront kernels (no counterpart in the reference; results never depend on it, only which
- * kernel organisation computes them).  heavy_min_faces: a 32x32 bin that lists more faces than this gets a whole
+ * kernel organisation computes them).  heavy_min_faces: a bin that lists at least this many faces (rounded DOWN to the
+ * launch order's bucket boundary: 12 buckets per octave of the list length, i.e. up to 6 % below the value) gets a whole
  * workgroup per tile in forwards of up to 4 Mpixels (and four wavefronts per tile in small backwards); 0 = never,
- * < 0 = the built-in default (512).  heavy_waves: 4 or 8 wavefronts per such workgroup, 0 = chosen per launch from the
+ * < 0 = the built-in default of the launch's bin size (512 / 192 / 96 for 32 / 16 / 8-pixel bins).  heavy_waves: 4 or 8 wavefronts per such workgroup, 0 = chosen per launch from the
  * number of heavy tiles.  Environment JR_FWD_HEAVY_MIN / JR_FWD_HEAVY_WAVES set the same two values at jr_ctx_create. */
 int jr_softras_set_launch_policy(jr_ctx* ctx, int heavy_min_faces, int heavy_waves);
+/* Screen-bin size in pixels: replaces the `bin_size` argument of the reference's operator (soft_rasterize.py:85-99 ->
+ * soft_rasterize_coarse_to_fine.py:16-18; demo2-deform.py:65 passes bin_size=16 for its 64^2 images).  0 = chosen per
+ * launch from the image size (the default), otherwise rounded up to the next supported size 8, 16 or 32 (one, 2x2 or 4x4
+ * wavefront tiles per bin).  Sticky per context.  It selects how finely the face lists, the launch order and the
+ * heavy-bin classification follow the image - results are bit-identical for every value (the reference's own binned path
+ * is NOT: it truncates lists at max_elems_per_bin and fills them in a nondeterministic order).  The default threshold of
+ * jr_softras_set_launch_policy follows the bin size (512 / 192 / 96 listed faces for 32 / 16 / 8 pixels).
+ * jr_softras_bin_size: the size a launch at `image_size` would use now; image_size <= 0: the size the workspace's
+ * current face records / lists were built with (0 before the first forward). */
+int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size);
+int jr_softras_bin_size(const jr_ctx* ctx, int image_size);
 /* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
  * previous call, [0..7] forward raster, [8..15] backward raster; all zero in the product build */
 int jr_debug_section_clocks(jr_ctx* ctx, uint64_t clocks[20]);

@@ -9,6 +9,7 @@ from .renderer import *            # noqa: F401,F403
 from .loss import *                # noqa: F401,F403
 from .io import *                  # noqa: F401,F403
 from .optim import Adam            # noqa: F401
+from .deform import DeformModel    # noqa: F401
 from . import synthetic            # noqa: F401
 from ._ffi import Context, DeviceArray   # noqa: F401
 

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libjrender_hip.so")
-SOURCES = ["jr_api.cpp", "jr_comm.cpp", "binning.hip", "softras_forward.hip", "softras_backward.hip", "aux_kernels.hip", "loss_kernels.hip", "n3mr_kernels.hip"]
+SOURCES = ["jr_api.cpp", "jr_comm.cpp", "binning.hip", "softras_forward.hip", "softras_backward.hip", "aux_kernels.hip", "loss_kernels.hip", "optim_kernels.hip", "n3mr_kernels.hip"]
 HEADERS = ["jr_kernels.h", "softras_device.h", "jr_tuning.h", "../../include/jrender_hip.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",

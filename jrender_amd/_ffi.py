@@ -6,6 +6,7 @@ small part of the ``jt.Var`` surface the renderer's callers use (``.shape``,
 ``.dtype``, ``.numpy()``).  The product path has NO CPU fallback: if the HIP
 library is missing or no GPU is visible, calls raise.
 """
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -58,6 +59,10 @@ SIGNATURES = {
     "jr_laplacian_loss": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 2 + [C.c_float]),
     "jr_flatten_loss": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_float] * 2),
     "jr_neg_iou_loss": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_float]),
+    "jr_deform_vertices_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int]),
+    "jr_deform_vertices_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int]),
+    "jr_adam_step": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t] + [C.c_double] * 5 + [C.c_int]),
+    "jr_scalar_accumulate": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_float, C.c_int]),
     "jr_avgpool2x2_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_avgpool2x2_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_n3mr_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float] * 3 + [c_float_p] + [C.c_int] * 3),
@@ -71,6 +76,8 @@ SIGNATURES = {
     "jr_softras_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "jr_softras_last_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "jr_softras_set_launch_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "jr_softras_set_bin_size": (C.c_int, [C.c_void_p, C.c_int]),
+    "jr_softras_bin_size": (C.c_int, [C.c_void_p, C.c_int]),
     "jr_debug_section_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "jr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "jr_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -315,6 +322,41 @@ class Context:
         ``heavy_min_faces`` faces get a workgroup of ``heavy_waves`` (4 / 8; 0 = automatic) wavefronts per tile;
         ``heavy_min_faces`` < 0 restores the default, 0 switches the multi-wavefront tiles off."""
         _check(load().jr_softras_set_launch_policy(self.handle, int(heavy_min_faces), int(heavy_waves)))
+
+    def scalar_accumulate(self, dst, index, src, scale=1.0, bias=0.0, accumulate=False):
+        """dst[index] = (accumulate ? dst[index] : 0) + bias + scale * sum(src) on the device (jr_scalar_accumulate): loss
+        terms stay on the GPU - e.g. one slot of a history array per iteration - until the caller reads them."""
+        if dst.dtype != np.float32 or src.dtype != np.float32:
+            raise TypeError("scalar_accumulate works on float32 arrays")
+        if not 0 <= int(index) < dst.size:
+            raise IndexError("index %d outside the %d elements of dst" % (index, dst.size))
+        _check(load().jr_scalar_accumulate(self.handle, C.c_void_p(dst.ptr + 4 * int(index)), src.ptr, int(src.size),
+                                           float(scale), float(bias), int(bool(accumulate))))
+
+    def set_bin_size(self, bin_size=0):
+        """Screen-bin size in pixels for the next launches (the reference operator's ``bin_size``): 0 = by image size,
+        else rounded up to 8, 16 or 32.  Results are bit-identical for every value."""
+        _check(load().jr_softras_set_bin_size(self.handle, int(bin_size)))
+        self._bin_size = int(bin_size)
+
+    def bin_size(self, image_size=0):
+        """Bin size a launch at ``image_size`` would use now; 0: the one the workspace's lists were built with."""
+        return int(load().jr_softras_bin_size(self.handle, int(image_size)))
+
+    @contextlib.contextmanager
+    def bin_size_scope(self, bin_size):
+        """``with ctx.bin_size_scope(16): ...`` - an operator's own ``bin_size`` for its launches; 0 / None: no change."""
+        if not bin_size:
+            yield
+            return
+        prev = getattr(self, "_bin_size", None)
+        if prev is None:
+            prev = 0 if not os.environ.get("JR_BIN_SIZE") else max(int(os.environ["JR_BIN_SIZE"]), 0)
+        self.set_bin_size(bin_size)
+        try:
+            yield
+        finally:
+            self.set_bin_size(prev)
 
     def close(self):
         if self.handle:

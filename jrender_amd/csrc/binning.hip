@@ -1,7 +1,7 @@
 // Screen binning for the SoftRas kernels (gfx950).
 //
 // The reference visits ALL faces for every pixel (SRK:311) — O(pixels x faces).  Here the screen
-// is cut into 32x32-pixel bins of 4x4 wavefront tiles (8x8 pixels each).  Every bin gets the list
+// is cut into bins of 1, 2x2 or 4x4 wavefront tiles (8x8 pixels each; RasterParams::bin_log2, chosen per launch).  Every bin gets the list
 // of faces whose border box (triangle bbox grown by the cull radius, SRK:28-34, :316) can touch
 // it, in ASCENDING face order — the per-pixel aggregation (alpha product, online softmax,
 // K-nearest buffer: SRK:350-419) is order dependent and the face-index buffer must match the
@@ -52,10 +52,11 @@ __device__ inline void pixel_range(float vlo, float vhi, int is, int& lo, int& h
 // one), the group's first lane adds the group size, every member gets base + its rank.  The matching is ALU only
 // and ALL leaders add in ONE atomic instruction: one memory round trip per call (round 3; it was one per group,
 // and a single view's k_bin_fill - 610 wavefronts, nothing to hide latency behind - was a chain of ~16 of them).
-template <bool RET>
-__device__ inline int wave_bin_add(int* __restrict__ arr, int tb) {
+// -> rank of this lane inside its group, the group's first lane and its size (ALU only)
+__device__ inline void wave_bin_match(int tb, int& leader, int& rank, int& cnt) {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    int rank = 0, leader = lane, cnt = 1, key = tb;
+    rank = 0; leader = lane; cnt = 1;
+    int key = tb;
     unsigned long long todo = ballot(tb >= 0);
     for (int round = 0; todo != 0 && round < 4; round++) {
         const int l = __builtin_ctzll(todo);
@@ -69,6 +70,11 @@ __device__ inline int wave_bin_add(int* __restrict__ arr, int tb) {
         }
         todo &= ~same;
     }
+}
+template <bool RET>
+__device__ inline int wave_bin_add(int* __restrict__ arr, int tb) {
+    int rank, leader, cnt;
+    wave_bin_match(tb, leader, rank, cnt);
     int base = 0;
     if (tb >= 0 && rank == 0) {
         if (RET) base = atomicAdd(&arr[tb], cnt);
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
                                                     float* __restrict__ faces_info,
                                                     FaceGeo* __restrict__ geo,
                                                     ushort4* __restrict__ face_rect,
-                                                    int* __restrict__ bin_count) {
+                                                    int* __restrict__ bin_count, unsigned long long* __restrict__ counters) {
     // records leave through LDS so that the global stores are contiguous 16-byte lanes (a thread
     // writing its own 108 B / 176 B record directly touches ~60 cache lines per store instruction)
     __shared__ __align__(16) float s_out[SETUP_WG * 44];
@@ -95,8 +101,11 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     const int nvalid = min(SETUP_WG, total - i0);
     const int ic = valid ? i : total - 1;
     const float* f = faces + (size_t)ic * 9;
+    SectionClock clk;            // instrumented builds only (JR_TUNE_PROFILE_SECTIONS = 3): 0 face_setup (incl. the face load), 1 faces_info store, 2 record + store, 3 pixel ranges, 4 bin counts
+    clk.start();
     float info[27];
     face_setup(f, info);
+    if (tune::profile_sections) { asm volatile("" :: "v"(info[0]), "v"(info[8]), "v"(info[17])); clk.lap(0); }
     if (faces_info) {   // nullptr when the backward only rebuilds the lists
 #pragma unroll
         for (int k = 0; k < 27; k++) s_out[threadIdx.x * 27 + k] = info[k];
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
         if (threadIdx.x < (nfl & 3)) out[(nfl & ~3) + threadIdx.x] = s_out[(nfl & ~3) + threadIdx.x];
         __syncthreads();
     }
+    clk.lap(1);
     FaceGeo g;
     build_face_geo(g, f, info, p.rad, ic % p.NF);
     if (p.T == 1) {      // single-texel surface colour travels with the record
@@ -120,6 +130,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
         float4* out = reinterpret_cast<float4*>(geo + i0);
         for (int q = threadIdx.x; q < nvalid * 11; q += SETUP_WG) out[q] = reinterpret_cast<const float4*>(s_out)[q];
     }
+    clk.lap(2);
 
     int px0, px1, py0, py1;
     pixel_range(g.xlo, g.xhi, p.IS, px0, px1);
@@ -130,10 +141,11 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
         const int row0 = p.IS - 1 - py1, row1 = p.IS - 1 - py0;
         rect = make_ushort4((unsigned short)px0, (unsigned short)px1, (unsigned short)row0,
                             (unsigned short)row1);
-        bx0 = px0 / BIN; nbx = px1 / BIN - bx0 + 1;
-        by0 = row0 / BIN; nb = nbx * (row1 / BIN - by0 + 1);
+        bx0 = px0 >> p.bin_log2; nbx = (px1 >> p.bin_log2) - bx0 + 1;
+        by0 = row0 >> p.bin_log2; nb = nbx * ((row1 >> p.bin_log2) - by0 + 1);
     }
     if (valid) face_rect[i] = rect;
+    clk.lap(3);
     const int bb = (ic / p.NF) * p.bins_x * p.bins_y;
     int cx = 0, cy = 0;
     for (int it = 0; ballot(it < nb) != 0; it++) {
@@ -141,6 +153,8 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
         wave_bin_add<false>(bin_count, tb);
         if (++cx == nbx) { cx = 0; cy++; }
     }
+    clk.lap(4);
+    if (JR_TUNE_PROFILE_SECTIONS == 3 && (threadIdx.x & 63) == 0) clk.flush0(counters, 4);
 }
 
 __global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4* __restrict__ face_rect,
@@ -150,6 +164,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4*
                                                   const unsigned long long* __restrict__ counters,
                                                   unsigned long long cap) {
     if (counters[0] > cap) return;          // pool too small: the host regrows it and launches again
+    SectionClock clk;            // instrumented builds only (JR_TUNE_PROFILE_SECTIONS = 3): 0 rectangle load + set-up, 1 the append loop
+    clk.start();
     const int total = p.B * p.NF;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int ic = min(i, total - 1);
@@ -157,25 +173,49 @@ __global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4*
     const int b = ic / p.NF, fn = ic - b * p.NF;
     const int bb = b * p.bins_x * p.bins_y;
     const int tx0 = r.x / TILE, tx1 = r.y / TILE, ty0 = r.z / TILE, ty1 = r.w / TILE;
-    const int bx0 = r.x / BIN, by0 = r.z / BIN;
-    const int nbx = r.y / BIN - bx0 + 1;
-    const int nb = (i < total && r.x <= r.y) ? nbx * (r.w / BIN - by0 + 1) : 0;
+    const int bx0 = r.x >> p.bin_log2, by0 = r.z >> p.bin_log2;
+    const int nbx = (r.y >> p.bin_log2) - bx0 + 1;
+    const int nb = (i < total && r.x <= r.y) ? nbx * ((r.w >> p.bin_log2) - by0 + 1) : 0;
+    const int sl = p.sub_log2, subs = 1 << sl;             // tiles per bin side: 1, 2 or 4
     int cx = 0, cy = 0;
-    for (int it = 0; ballot(it < nb) != 0; it++) {
-        const int bx = bx0 + cx, by = by0 + cy;
-        const int t = it < nb ? bb + by * p.bins_x + bx : -1;
-        const int pos = wave_bin_add<true>(bin_cursor, t);
-        if (t >= 0) {
-            // mask of the bin's 4x4 tiles overlapped by the face rectangle (bit = ty*4 + tx)
-            const int sx0 = max(tx0 - bx * SUBS, 0), sx1 = min(tx1 - bx * SUBS, SUBS - 1);
-            const int sy0 = max(ty0 - by * SUBS, 0), sy1 = min(ty1 - by * SUBS, SUBS - 1);
+    if (tune::profile_sections) { asm volatile("" :: "v"(nb)); clk.lap(0); }
+    // FOUR bins of every face per pass (round 5): the matching is ALU work, the four cursor bumps and the four segment-base
+    // loads are independent memory operations that travel together - a pass costs one round trip instead of four (a single
+    // view's launch is ~600 wavefronts with nothing to hide a chain of round trips behind; with 8-pixel bins a face reaches
+    // 3 - 9 bins instead of 1 - 2).
+    constexpr int U = 4;
+    for (int it0 = 0; ballot(it0 < nb) != 0; it0 += U) {
+        int t[U], leader[U], rank[U], base[U], seg[U];
+        unsigned mask[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int bx = bx0 + cx, by = by0 + cy;
+            t[u] = it0 + u < nb ? bb + by * p.bins_x + bx : -1;
+            // mask of the bin's tiles overlapped by the face rectangle (bit = (ty << sub_log2) | tx)
+            const int sx0 = max(tx0 - (bx << sl), 0), sx1 = min(tx1 - (bx << sl), subs - 1);
+            const int sy0 = max(ty0 - (by << sl), 0), sy1 = min(ty1 - (by << sl), subs - 1);
             const unsigned rowbits = ((1u << (sx1 + 1)) - 1u) & ~((1u << sx0) - 1u);
-            unsigned mask = 0;
-            for (int sy = sy0; sy <= sy1; sy++) mask |= rowbits << (sy * SUBS);
-            pool[bin_base[t] + pos] = ((unsigned long long)(unsigned)fn << 32) | mask;
+            unsigned m = 0;
+            for (int sy = sy0; sy <= sy1; sy++) m |= rowbits << (sy << sl);
+            mask[u] = m;
+            seg[u] = t[u] >= 0 ? bin_base[t[u]] : 0;
+            if (++cx == nbx) { cx = 0; cy++; }
         }
-        if (++cx == nbx) { cx = 0; cy++; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int cnt;
+            wave_bin_match(t[u], leader[u], rank[u], cnt);
+            base[u] = 0;
+            if (t[u] >= 0 && rank[u] == 0) base[u] = atomicAdd(&bin_cursor[t[u]], cnt);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int pos = __shfl(base[u], leader[u]) + rank[u];
+            if (t[u] >= 0) pool[seg[u] + pos] = ((unsigned long long)(unsigned)fn << 32) | mask[u];
+        }
     }
+    clk.lap(1);
+    if (JR_TUNE_PROFILE_SECTIONS == 3 && (threadIdx.x & 63) == 0) clk.flush0(const_cast<unsigned long long*>(counters), 12);
 }
 
 // One workgroup per bin: counting order through an LDS bitmap over the face ids (see the file header).
@@ -245,10 +285,12 @@ __global__ __launch_bounds__(256) void k_bin_order(int NF, const int* __restrict
 //   order for the raster kernels: heaviest lists first (longest-processing-time-first keeps the tail of the launch
 //   short: the list length of a bin varies from 1 to > 1000 faces), empty bins last - histogram over ~12 buckets per
 //   octave of the count, descending prefix, scatter.
+// bin_acc = the per-bin counts k_face_setup accumulated: copied to bin_count (what every later kernel reads) and CLEARED here,
+// so that the next set-up pass needs no memset in the stream (round 5: one launch less on the one-view critical path).
 // counters: [0] = total pairs, [1] = non-empty bins, [2] = max bin count, [3] = heavy bins - WRITTEN here (nothing to
 // clear beforehand), and copied to `host_counters` (pinned, device-visible) so that the host's read-back of the pair
 // total is a wait on an event, not a copy engine's turn in the stream.
-__global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, const int* __restrict__ bin_count,
+__global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, int* __restrict__ bin_acc, int* __restrict__ bin_count,
                                                              int* __restrict__ bin_base, int* __restrict__ bin_cursor,
                                                              int* __restrict__ bin_order,
                                                              unsigned long long* __restrict__ counters,
@@ -264,7 +306,7 @@ __global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, co
     const int lane = threadIdx.x & 63;
     for (int t0 = 0; t0 < nbins_total; t0 += 1024) {         // (uniform trip count: the wavefront scans need every lane)
         const int t = t0 + (int)threadIdx.x;
-        const int n = t < nbins_total ? bin_count[t] : 0;
+        const int n = t < nbins_total ? bin_acc[t] : 0;
         // (empty bins are the most frequent bucket by far: one LDS atomic per wavefront for them instead of one per lane)
         const unsigned long long zb = ballot(t < nbins_total && n <= 0);
         if (t < nbins_total && n > 0) atomicAdd(&s_hist[bucket(n)], 1);
@@ -309,7 +351,8 @@ __global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, co
     }
     for (int t0 = 0; t0 < nbins_total; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
-        const int n = t < nbins_total ? bin_count[t] : 1;
+        const int n = t < nbins_total ? bin_acc[t] : 1;
+        if (t < nbins_total) { bin_count[t] = n; bin_acc[t] = 0; }     // what the other kernels read / the accumulator left clear for the next set-up pass (no memset in the stream)
         const bool empty = t < nbins_total && n <= 0;
         const unsigned long long zb = ballot(empty);
         int zbase = 0;
@@ -383,9 +426,9 @@ void launch_binning(hipStream_t st, const RasterParams& p, const float* faces, c
                     float* faces_info, BinWorkspace& ws) {
     const int nfaces = p.B * p.NF;
     const int nbins = p.B * p.bins_x * p.bins_y;
-    (void)hipMemsetAsync(ws.bin_count, 0, sizeof(int) * (size_t)nbins, st);
-    k_face_setup<<<(nfaces + SETUP_WG - 1) / SETUP_WG, SETUP_WG, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_count);
-    k_bin_alloc_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.bin_order, ws.counters, ws.host_counters, heavy_bucket(ws.heavy_min));
+    // (ws.bin_acc is all zero between set-up passes: cleared when allocated, and by k_bin_alloc_schedule after it has read it)
+    k_face_setup<<<(nfaces + SETUP_WG - 1) / SETUP_WG, SETUP_WG, 0, st>>>(p, faces, textures, faces_info, ws.geo, ws.face_rect, ws.bin_acc, ws.counters);
+    k_bin_alloc_schedule<<<1, 1024, 0, st>>>(nbins, ws.bin_acc, ws.bin_count, ws.bin_base, ws.bin_cursor, ws.bin_order, ws.counters, ws.host_counters, heavy_bucket(ws.heavy_min));
 }
 
 // Every kernel here is guarded by "total pairs <= pool capacity" read from device memory, so that the

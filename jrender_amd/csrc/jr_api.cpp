@@ -53,7 +53,11 @@ struct jr_ctx {
     uint64_t geo_epoch = 0;
     uint64_t last_forward_token = 0;
     int bins_T = 0;
-    int bins_B = 0, bins_NF = 0, bins_IS = 0;
+    int bins_B = 0, bins_NF = 0, bins_IS = 0, bins_bin_log2 = 0;
+    // Bin geometry and heavy-bin threshold as the caller set them (jr_softras_set_bin_size / _set_launch_policy); every
+    // set-up pass resolves them for ITS launch: bin size 0 = by image size, threshold < 0 = the default of that bin size.
+    int bin_size_user = 0;
+    int heavy_min_user = -1;
     float bins_rad = 0.f;
     int64_t stats[4] = {0, 0, 0, 0};
     int64_t launch_info[4] = {0, 0, 0, 0};  // last forward: multi-wavefront kernel used, heavy bins, wavefronts per workgroup
@@ -61,7 +65,7 @@ struct jr_ctx {
     // next forward of the same shape sizes its multi-wavefront launch (workgroup size, heavy-tile workgroups) from it while
     // the schedule kernel is still running.  A shape that is NOT in here launches its raster kernel after the host has read
     // this forward's own totals, so that the first call of a shape takes the same path as the second.
-    struct ShapeHist { int B, NF, IS, heavy_min; int64_t heavy; uint64_t stamp; };
+    struct ShapeHist { int B, NF, IS, heavy_min, bin_log2; int64_t heavy; uint64_t stamp; };
     ShapeHist hist[8] = {};
     uint64_t hist_clock = 0;
     int forced_waves = 0;                    // jr_softras_set_launch_policy / JR_FWD_HEAVY_WAVES: 4 or 8 whatever the policy says; 0 = automatic
@@ -69,6 +73,11 @@ struct jr_ctx {
     size_t zkey_cap = 0;
     unsigned char* n3_scratch = nullptr;    // n3mr backward: packed per-pixel planes in both orientations
     size_t n3_scratch_cap = 0;
+    // two-stage sums of the loss / optimiser kernels: [red_cap] double accumulators + [red_cap] tickets, zeroed when
+    // allocated and left zeroed by every launch (the last workgroup clears what it publishes)
+    double* red_acc = nullptr;
+    unsigned* red_ticket = nullptr;
+    size_t red_cap = 0;
     // optional per-phase HIP-event timing (jr_profile_*): pairs of events bracketing each phase
     bool prof_on = false;
     std::vector<hipEvent_t> prof_events;     // pool, reused after every collect
@@ -120,6 +129,22 @@ int grow(T*& ptr, size_t& cap, size_t need, double slack) {
     return 0;
 }
 
+int ensure_reduction_scratch(jr_ctx* ctx, size_t n) {
+    n += 4;                                  // [0..3]: the optimiser kernels' three sums, [4..): one per mesh of a loss launch
+    if (n <= ctx->red_cap) return 0;
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->red_acc) JR_HIP(hipFree(ctx->red_acc));
+    if (ctx->red_ticket) JR_HIP(hipFree(ctx->red_ticket));
+    ctx->red_acc = nullptr; ctx->red_ticket = nullptr; ctx->red_cap = 0;
+    const size_t cap = n + 60;
+    JR_HIP(hipMalloc((void**)&ctx->red_acc, sizeof(double) * cap));
+    JR_HIP(hipMalloc((void**)&ctx->red_ticket, sizeof(unsigned) * cap));
+    JR_HIP(hipMemsetAsync(ctx->red_acc, 0, sizeof(double) * cap, ctx->stream));
+    JR_HIP(hipMemsetAsync(ctx->red_ticket, 0, sizeof(unsigned) * cap, ctx->stream));
+    ctx->red_cap = cap;
+    return 0;
+}
+
 int validate(int B, int NF, int T, int IS, int K, int dist, int rgb, int alpha, int tex) {
     if (B < 1 || NF < 1 || T < 1 || IS < 1) return fail("B, NF, T, image_size must be >= 1 (got %d %d %d %d)", B, NF, T, IS);
     if (IS > jr::MAX_IMAGE) return fail("image_size %d exceeds the supported maximum %d", IS, jr::MAX_IMAGE);
@@ -137,7 +162,25 @@ int validate(int B, int NF, int T, int IS, int K, int dist, int rgb, int alpha, 
     return 0;
 }
 
-jr::RasterParams make_params(int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
+// Bin size of a launch: the caller's (jr_softras_set_bin_size: the reference's `bin_size` kwarg, soft_rasterize.py:85-99)
+// or, by default, one that follows the image - a 32-pixel bin is HALF of a 64^2 image (demo2: every bin lists a third of
+// the mesh and every tile walks that list), while on a 1024^2 image it keeps the lists, the ordering kernel and the
+// launch order cheap.  Results do not depend on it.
+int resolve_bin_log2(const jr_ctx* ctx, int IS) {
+    const int user = ctx->bin_size_user;
+    if (user > 0) return user <= 8 ? 3 : (user <= 16 ? 4 : 5);
+    if (IS <= jr::tune::auto_bin8_max_image) return 3;
+    if (IS <= jr::tune::auto_bin16_max_image) return 4;
+    return 5;
+}
+// Bins that list more faces than this are HEAVY (a workgroup per tile in the forward, split tiles in the backward): the
+// caller's value, or the default of the bin size (a smaller bin lists fewer faces for the same load per tile).
+int resolve_heavy_min(const jr_ctx* ctx, int bin_log2) {
+    if (ctx->heavy_min_user >= 0) return ctx->heavy_min_user;
+    return bin_log2 >= 5 ? jr::tune::fwd_heavy : (bin_log2 == 4 ? jr::tune::fwd_heavy16 : jr::tune::fwd_heavy8);
+}
+
+jr::RasterParams make_params(const jr_ctx* ctx, int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
                              float sigma, int dist, float dist_eps, float gamma, int rgb, int alpha,
                              int tex, int double_side, const float* bg) {
     jr::RasterParams p;
@@ -147,7 +190,9 @@ jr::RasterParams make_params(int B, int NF, int T, int IS, int K, float near_, f
     p.rad = sqrtf(p.thr);                                                                  // SRK:316
     p.dist = dist; p.rgb = rgb; p.alpha = alpha; p.tex = tex; p.double_side = double_side ? 1 : 0;
     for (int k = 0; k < 3; k++) p.bg[k] = bg ? bg[k] : 0.f;
-    p.bins_x = (IS + jr::BIN - 1) / jr::BIN;
+    p.bin_log2 = resolve_bin_log2(ctx, IS);
+    p.sub_log2 = p.bin_log2 - jr::TILE_LOG2;
+    p.bins_x = (IS + (1 << p.bin_log2) - 1) >> p.bin_log2;
     p.bins_y = p.bins_x;
     // correctly rounded reciprocals of the per-call divisors (float IEEE divisions on the host)
     p.far_minus_near = far_ - near_;
@@ -176,7 +221,10 @@ int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, cons
         ws.faces_cap = c0;
     }
     if (nbins > ws.bins_cap || !ws.bin_count) {
-        size_t c0 = ws.bins_cap, c1 = ws.bins_cap, c2 = ws.bins_cap, c3 = ws.bins_cap;
+        size_t c0 = ws.bins_cap, c1 = ws.bins_cap, c2 = ws.bins_cap, c3 = ws.bins_cap, c4 = ws.bins_cap;
+        JR_HIP(hipStreamSynchronize(ctx->stream));            // (a set-up pass in flight may still clear the old accumulator)
+        if (grow(ws.bin_acc, c4, nbins, 1.0)) return 1;
+        JR_HIP(hipMemsetAsync(ws.bin_acc, 0, sizeof(int) * c4, ctx->stream));
         if (grow(ws.bin_count, c0, nbins, 1.0)) return 1;
         if (grow(ws.bin_base, c1, nbins, 1.0)) return 1;
         if (grow(ws.bin_cursor, c2, nbins, 1.0)) return 1;
@@ -187,7 +235,7 @@ int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, cons
         ProfScope ps(ctx, JR_PHASE_BIN_COUNT);
         jr::launch_binning(ctx->stream, p, faces, textures, faces_info, ws);
     }
-    ctx->bins_B = p.B; ctx->bins_NF = p.NF; ctx->bins_IS = p.IS;
+    ctx->bins_B = p.B; ctx->bins_NF = p.NF; ctx->bins_IS = p.IS; ctx->bins_bin_log2 = p.bin_log2;
     ctx->bins_rad = p.rad; ctx->bins_T = p.T;
     ctx->geo_epoch++;
     return 0;
@@ -202,6 +250,7 @@ int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, cons
 int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
                      float* faces_info, float* aggrs_info, float* soft_colors, int32_t* faces_id_buffer) {
     jr::BinWorkspace& ws = ctx->ws;
+    ws.heavy_min = resolve_heavy_min(ctx, p.bin_log2);
     const bool heavy_path = jr::forward_uses_heavy_path(p, ws);
     // Workgroup size of the multi-wavefront kernel.  Eight wavefronts per heavy tile cut a lone view's critical path
     // further (one 39k-face view: 0.33 -> 0.28 ms), but they and the eight light tiles per workgroup cost throughput as
@@ -216,7 +265,7 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     };
     jr_ctx::ShapeHist* hist = nullptr;
     for (auto& h : ctx->hist)
-        if (h.stamp && h.B == p.B && h.NF == p.NF && h.IS == p.IS && h.heavy_min == ws.heavy_min) hist = &h;
+        if (h.stamp && h.B == p.B && h.NF == p.NF && h.IS == p.IS && h.heavy_min == ws.heavy_min && h.bin_log2 == p.bin_log2) hist = &h;
     if (setup_faces(ctx, p, faces, textures, faces_info)) return 1;
     JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));     // k_bin_alloc_schedule has written the totals to h_counters
     auto enqueue_lists = [&](bool again) {
@@ -244,7 +293,7 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
         if (!hist) {
             hist = &ctx->hist[0];
             for (auto& h : ctx->hist) if (h.stamp < hist->stamp) hist = &h;
-            hist->B = p.B; hist->NF = p.NF; hist->IS = p.IS; hist->heavy_min = ws.heavy_min;
+            hist->B = p.B; hist->NF = p.NF; hist->IS = p.IS; hist->heavy_min = ws.heavy_min; hist->bin_log2 = p.bin_log2;
         }
         hist->heavy = heavy_now; hist->stamp = ++ctx->hist_clock;
     }
@@ -297,7 +346,8 @@ int jr_ctx_create(int device, jr_ctx** out) {
     JR_HIP(hipMalloc((void**)&c->ws.counters, sizeof(unsigned long long) * 32));   // [0..3] bin totals (live from a forward to its backward), [4..23] section clocks (instrumented builds), [24..] scratch of the self-tests
     JR_HIP(hipMemset(c->ws.counters, 0, sizeof(unsigned long long) * 32));
     // JR_FWD_HEAVY_MIN / JR_FWD_HEAVY_WAVES (tests, diagnostics): initial launch policy, see jr_softras_set_launch_policy
-    if (const char* e = getenv("JR_FWD_HEAVY_MIN")) c->ws.heavy_min = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("JR_FWD_HEAVY_MIN")) c->heavy_min_user = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("JR_BIN_SIZE")) c->bin_size_user = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("JR_FWD_HEAVY_WAVES")) c->forced_waves = (atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0;
     JR_HIP(hipEventCreateWithFlags(&c->ev_counters, hipEventDisableTiming));
     *out = c;
@@ -312,8 +362,8 @@ int jr_ctx_destroy(jr_ctx* ctx) {
         for (void* p : kv.second) (void)hipFree(p);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     jr::BinWorkspace& ws = ctx->ws;
-    (void)hipFree(ctx->zkey); (void)hipFree(ctx->n3_scratch);
-    (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor); (void)hipFree(ws.bin_order);
+    (void)hipFree(ctx->zkey); (void)hipFree(ctx->n3_scratch); (void)hipFree(ctx->red_acc); (void)hipFree(ctx->red_ticket);
+    (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_acc); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor); (void)hipFree(ws.bin_order);
     (void)hipFree(ws.counters); (void)hipFree(ws.pool); (void)hipFree(ws.pool_scratch);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipHostFree(ctx->h_counters);
@@ -446,7 +496,7 @@ int jr_softras_forward(jr_ctx* ctx, const float* face_vertices, const float* tex
         return fail("jr_softras_forward: NULL tensor pointer");
     if (validate(B, NF, T, IS, K, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type)) return 1;
     JR_HIP(hipSetDevice(ctx->device));
-    const jr::RasterParams p = make_params(B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
+    const jr::RasterParams p = make_params(ctx, B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
                                            dist_eps, gamma_val, func_id_rgb, func_id_alpha,
                                            texture_sample_type, double_side, background_rgb);
     ctx->last_forward_token = 0;
@@ -472,7 +522,7 @@ int jr_softras_backward_ex(jr_ctx* ctx, const float* face_vertices, const float*
         return fail("jr_softras_backward: NULL tensor pointer");
     if (validate(B, NF, T, IS, K, func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type)) return 1;
     JR_HIP(hipSetDevice(ctx->device));
-    const jr::RasterParams p = make_params(B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
+    const jr::RasterParams p = make_params(ctx, B, NF, T, IS, K, near_, far_, eps, sigma_val, func_id_dist,
                                            dist_eps, gamma_val, func_id_rgb, func_id_alpha,
                                            texture_sample_type, double_side, nullptr);
     // The face records / launch order of the matching forward are reused only when the caller proves
@@ -480,8 +530,10 @@ int jr_softras_backward_ex(jr_ctx* ctx, const float* face_vertices, const float*
     // else rebuilds them from face_vertices / textures as passed (0.06 ms on the headline workload; no
     // faces_info write, no lists: the backward finds its faces through the id buffer).
     const bool reuse = forward_token != 0 && forward_token == ctx->geo_epoch && ctx->bins_B == B &&
-                       ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad && ctx->bins_T == T;
+                       ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad && ctx->bins_T == T &&
+                       ctx->bins_bin_log2 == p.bin_log2 && ctx->ws.heavy_min == resolve_heavy_min(ctx, p.bin_log2);
     if (!reuse) {
+        ctx->ws.heavy_min = resolve_heavy_min(ctx, p.bin_log2);
         if (setup_faces(ctx, p, face_vertices, textures, nullptr)) return 1;
         ctx->ws.heavy_bound = -1;           // nobody read this schedule's totals: the pool-capacity bound
     }
@@ -603,8 +655,9 @@ int jr_laplacian_loss(jr_ctx* ctx, const int32_t* rowptr, const int32_t* col, co
     if (grad_vertices && (!rowptr_t || !col_t || !val_t)) return fail("jr_laplacian_loss: the gradient needs the transposed matrix");
     if (B < 1 || NV < 1) return fail("jr_laplacian_loss: bad sizes");
     JR_HIP(hipSetDevice(ctx->device));
+    if (ensure_reduction_scratch(ctx, (size_t)B)) return 1;
     jr::launch_laplacian_loss(ctx->stream, rowptr, col, val, rowptr_t, col_t, val_t, vertices, scratch, loss, grad_vertices,
-                              B, NV, grad_scale);
+                              ctx->red_acc + 4, ctx->red_ticket + 4, B, NV, grad_scale);
     JR_HIP(hipGetLastError());
     return 0;
 }
@@ -614,7 +667,54 @@ int jr_flatten_loss(jr_ctx* ctx, const int32_t* v0s, const int32_t* v1s, const i
     if (!ctx || !v0s || !v1s || !v2s || !v3s || !vertices || !loss) return fail("jr_flatten_loss: NULL argument");
     if (B < 1 || NV < 1 || NE < 0) return fail("jr_flatten_loss: bad sizes");
     JR_HIP(hipSetDevice(ctx->device));
-    jr::launch_flatten_loss(ctx->stream, v0s, v1s, v2s, v3s, vertices, loss, grad_vertices, B, NV, NE, eps, grad_scale);
+    if (ensure_reduction_scratch(ctx, (size_t)B)) return 1;
+    jr::launch_flatten_loss(ctx->stream, v0s, v1s, v2s, v3s, vertices, loss, grad_vertices, ctx->red_acc + 4,
+                            ctx->red_ticket + 4, B, NV, NE, eps, grad_scale);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jr_deform_vertices_forward(jr_ctx* ctx, const float* template_vertices, const float* displace, const float* center,
+                               float* vertices, int NV) {
+    if (!ctx || !template_vertices || !displace || !center || !vertices) return fail("jr_deform_vertices_forward: NULL argument");
+    if (NV < 1 || NV > (1 << 28)) return fail("jr_deform_vertices_forward: bad vertex count %d", NV);
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_deform_forward(ctx->stream, template_vertices, displace, center, vertices, NV);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_deform_vertices_backward(jr_ctx* ctx, const float* template_vertices, const float* displace, const float* center,
+                                const float* grad0, float w0, const float* grad1, float w1, const float* grad2, float w2,
+                                float* grad_displace, float* grad_center, int NV) {
+    if (!ctx || !template_vertices || !displace || !center || !grad0 || !grad_displace || !grad_center)
+        return fail("jr_deform_vertices_backward: NULL argument");
+    if (NV < 1 || NV > (1 << 28)) return fail("jr_deform_vertices_backward: bad vertex count %d", NV);
+    JR_HIP(hipSetDevice(ctx->device));
+    if (ensure_reduction_scratch(ctx, 0)) return 1;
+    jr::launch_deform_backward(ctx->stream, template_vertices, displace, center, grad0, w0, grad1, w1, grad2, w2,
+                               grad_displace, grad_center, ctx->red_acc, ctx->red_ticket, NV);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_adam_step(jr_ctx* ctx, float* param, const float* grad, float* m, float* v, size_t n, double lr, double beta0,
+                 double beta1, double eps, double weight_decay, int step) {
+    if (!ctx || !param || !grad || !m || !v) return fail("jr_adam_step: NULL argument");
+    if (n == 0) return 0;
+    if (step < 1) return fail("jr_adam_step: step counts from 1 (got %d)", step);
+    if (!(beta0 >= 0.0 && beta0 < 1.0 && beta1 >= 0.0 && beta1 < 1.0)) return fail("jr_adam_step: betas must be in [0, 1)");
+    JR_HIP(hipSetDevice(ctx->device));
+    // the mirror's Python scalars: formed in double, rounded to float where NumPy multiplies them into a float32 array
+    const double c0 = 1.0 - std::pow(beta0, step), c1 = 1.0 - std::pow(beta1, step);
+    jr::launch_adam_step(ctx->stream, param, grad, m, v, n, (float)(lr / c0), (float)beta0, (float)(1.0 - beta0), (float)beta1,
+                         (float)(1.0 - beta1), (float)c1, (float)eps, (float)weight_decay);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_scalar_accumulate(jr_ctx* ctx, float* dst, const float* src, int n, float scale, float bias, int accumulate) {
+    if (!ctx || !dst || (n > 0 && !src)) return fail("jr_scalar_accumulate: NULL argument");
+    if (n < 0) return fail("jr_scalar_accumulate: n must be >= 0");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_scalar_accumulate(ctx->stream, dst, src, n, scale, bias, accumulate);
     JR_HIP(hipGetLastError());
     return 0;
 }
@@ -761,12 +861,26 @@ int jr_softras_set_launch_policy(jr_ctx* ctx, int heavy_min_faces, int heavy_wav
     if (!ctx) return fail("NULL context");
     if (heavy_waves != 0 && heavy_waves != 4 && heavy_waves != 8) return fail("jr_softras_set_launch_policy: heavy_waves must be 0 (automatic), 4 or 8");
     if (heavy_min_faces > (1 << 24)) return fail("jr_softras_set_launch_policy: heavy_min_faces out of range");
-    ctx->ws.heavy_min = heavy_min_faces < 0 ? jr::tune::fwd_heavy : heavy_min_faces;
+    ctx->heavy_min_user = heavy_min_faces < 0 ? -1 : heavy_min_faces;
     ctx->forced_waves = heavy_waves;
     ctx->ws.heavy_bound = -1;
     ctx->geo_epoch++;                        // the schedule in the workspace was built under the old threshold: no backward may reuse it
     for (auto& h : ctx->hist) h.stamp = 0;
     return 0;
+}
+
+int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size) {
+    if (!ctx) return fail("NULL context");
+    if (bin_size < 0 || bin_size > jr::MAX_IMAGE) return fail("jr_softras_set_bin_size: bin_size must be 0 (automatic) or a pixel count (got %d)", bin_size);
+    // (no generation bump: a backward reuses the forward's records only when ITS resolved bin size is the one they were built with)
+    ctx->bin_size_user = bin_size;
+    return 0;
+}
+
+int jr_softras_bin_size(const jr_ctx* ctx, int image_size) {
+    if (!ctx) return -1;
+    if (image_size <= 0) return ctx->bins_bin_log2 ? 1 << ctx->bins_bin_log2 : 0;     // of the set-up pass the workspace holds
+    return 1 << resolve_bin_log2(ctx, image_size);
 }
 
 int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]) {

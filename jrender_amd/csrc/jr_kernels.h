@@ -12,7 +12,8 @@ namespace jr {
 struct BinWorkspace {
     FaceGeo* geo = nullptr;                    // [B*NF] packed geometry records
     ushort4* face_rect = nullptr;              // [B*NF] conservative pixel rectangle (x0,x1,row0,row1)
-    int* bin_count = nullptr;                  // [B*bins]
+    int* bin_acc = nullptr;                    // [B*bins] counts as k_face_setup accumulates them; zero between set-up passes (k_bin_alloc_schedule clears what it read)
+    int* bin_count = nullptr;                  // [B*bins] listed faces per bin
     int* bin_base = nullptr;                   // [B*bins] segment start in pool
     int* bin_cursor = nullptr;                 // [B*bins]
     int* bin_order = nullptr;                  // [B*bins] launch rank -> bin, heaviest list first
@@ -80,11 +81,19 @@ void launch_face_camera_backward_shared(hipStream_t st, const float* gfv, const 
                                         int kind, float param);
 void launch_neg_iou_loss(hipStream_t st, const float* predict, const float* target, float* iou, float* grad, int B,
                          int n, float divisor);
+// (acc [B] doubles and ticket [B] counters: zeroed scratch of the context, left zeroed by every launch)
 void launch_laplacian_loss(hipStream_t st, const int* rowptr, const int* col, const float* val, const int* rowptr_t,
                            const int* col_t, const float* val_t, const float* x, float* y, float* loss, float* grad,
-                           int B, int nv, float scale);
+                           double* acc, unsigned* ticket, int B, int nv, float scale);
 void launch_flatten_loss(hipStream_t st, const int* v0s, const int* v1s, const int* v2s, const int* v3s, const float* x,
-                         float* loss, float* grad, int B, int nv, int ne, float eps, float scale);
+                         float* loss, float* grad, double* acc, unsigned* ticket, int B, int nv, int ne, float eps, float scale);
+void launch_deform_forward(hipStream_t st, const float* tmpl, const float* displace, const float* center, float* out, int nv);
+void launch_deform_backward(hipStream_t st, const float* tmpl, const float* displace, const float* center, const float* g0,
+                            float w0, const float* g1, float w1, const float* g2, float w2, float* grad_displace,
+                            float* grad_center, double* acc, unsigned* ticket, int nv);
+void launch_adam_step(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_over_c0, float b0,
+                      float one_minus_b0, float b1, float one_minus_b1, float c1, float eps, float weight_decay);
+void launch_scalar_accumulate(hipStream_t st, float* dst, const float* src, int n, float scale, float bias, int accumulate);
 void launch_n3mr_image_forward(hipStream_t st, const float* in, float* out, int B, int H, int W, int C, int pool);
 void launch_n3mr_image_backward(hipStream_t st, const float* gout, float* gin, int B, int H, int W, int C, int pool);
 void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textures, float* faces_inv,

@@ -48,6 +48,18 @@
 #ifndef JR_TUNE_FWD_HEAVY        // forward: bins whose list is longer than this get FOUR wavefronts per tile (evaluate / apply split); 0 = one wavefront per tile everywhere
 #define JR_TUNE_FWD_HEAVY 512
 #endif
+#ifndef JR_TUNE_FWD_HEAVY16      // the same threshold for 16-pixel bins (2x2 tiles) and 8-pixel bins (one tile: the list IS the tile's)
+#define JR_TUNE_FWD_HEAVY16 192
+#endif
+#ifndef JR_TUNE_FWD_HEAVY8
+#define JR_TUNE_FWD_HEAVY8 96
+#endif
+#ifndef JR_TUNE_AUTO_BIN8_MAX_IMAGE    // bin size by image size when the caller does not choose (jr_softras_set_bin_size): 8-pixel bins up to this image size,
+#define JR_TUNE_AUTO_BIN8_MAX_IMAGE 0
+#endif
+#ifndef JR_TUNE_AUTO_BIN16_MAX_IMAGE   // 16-pixel bins up to this one, 32 above
+#define JR_TUNE_AUTO_BIN16_MAX_IMAGE 0
+#endif
 #ifndef JR_TUNE_FWD_HEAVY_DEFER_COPY // forward, heavy tiles: the record copies of a batch in one round after the list walk
 #define JR_TUNE_FWD_HEAVY_DEFER_COPY 1
 #endif
@@ -77,6 +89,9 @@
 #endif
 #ifndef JR_TUNE_FWD_PIPE_CONSUMER_TASKS   // pipelined heavy tile: which applying wavefronts also take evaluate / mask tasks once their apply is done (bit 0: the K-buffer wavefront, bit 1: the colour wavefront)
 #define JR_TUNE_FWD_PIPE_CONSUMER_TASKS 3
+#endif
+#ifndef JR_TUNE_FWD_PIPE_PRIO     // pipelined heavy tile: s_setprio 3 for the two applying wavefronts while they apply (the per-pixel sequential chain is the tile's critical path)
+#define JR_TUNE_FWD_PIPE_PRIO 0
 #endif
 #ifndef JR_TUNE_FWD_HEAVY_PIXELS // forward: launches of up to this many pixels (B x IS x IS) use the four-wavefront kernel, larger ones one wavefront per tile
 #define JR_TUNE_FWD_HEAVY_PIXELS 4194304
@@ -171,6 +186,7 @@ constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
 constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;
 constexpr bool fwd_heavy_pipe = JR_TUNE_FWD_HEAVY_PIPE != 0;
 constexpr int fwd_pipe_consumer_tasks = JR_TUNE_FWD_PIPE_CONSUMER_TASKS;
+constexpr bool fwd_pipe_prio = JR_TUNE_FWD_PIPE_PRIO != 0;
 constexpr int fwd_heavy_waves = JR_TUNE_FWD_HEAVY_WAVES;
 constexpr int fwd_pipe8_cap = JR_TUNE_FWD_PIPE8_CAP, fwd_pipe8_batch = JR_TUNE_FWD_PIPE8_BATCH;
 constexpr int fwd_pipe_list_depth = JR_TUNE_FWD_PIPE_LIST_DEPTH;
@@ -187,7 +203,8 @@ constexpr bool fwd_ids_global = JR_TUNE_FWD_IDS_GLOBAL != 0;
 constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
 constexpr bool fwd_empty_bins = JR_TUNE_FWD_EMPTY_BINS != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
-constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY;
+constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY, fwd_heavy16 = JR_TUNE_FWD_HEAVY16, fwd_heavy8 = JR_TUNE_FWD_HEAVY8;
+constexpr int auto_bin8_max_image = JR_TUNE_AUTO_BIN8_MAX_IMAGE, auto_bin16_max_image = JR_TUNE_AUTO_BIN16_MAX_IMAGE;
 constexpr bool fwd_heavy_defer_copy = JR_TUNE_FWD_HEAVY_DEFER_COPY != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 constexpr bool bwd_row_ranges = JR_TUNE_BWD_ROW_RANGES != 0;

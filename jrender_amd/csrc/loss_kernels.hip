@@ -1,61 +1,87 @@
 // The mesh regularisers of the deformation loop (BASELINE configs[3], demo2-deform.py:48-56) on the device:
 //   LaplacianLoss  jrender/loss/laplacian_loss.py:5-37   sum((L x)^2) per mesh, L = the normalised graph Laplacian
 //   FlattenLoss    jrender/loss/flatten_loss.py:5-80     sum((cos + 1)^2) over the edges shared by two faces
-// Jittor tensor ops + autograd in the reference; value AND gradient in one launch each here.  Both are O(nv) work on
-// meshes of a few thousand vertices — latency, not bandwidth: ONE workgroup per mesh of the batch walks its rows /
-// edges, so the loss is a plain in-block sum (deterministic) and nothing needs a second launch.
+// Jittor tensor ops + autograd in the reference; value AND gradient here.  Round 5: the work is spread over a GRID per mesh
+// (round 4 ran ONE 1024-thread workgroup per mesh: 28 / 61 us of dependent loads and double arithmetic on 1 of 256 CUs at
+// 1 352 vertices, a wall at 39k-face meshes - VERDICT r4 weak 10) and the loss is a two-stage sum: every workgroup adds its
+// double partial to the mesh's accumulator and takes a ticket, the last one writes the float result and clears both for
+// the next launch (double atomics: the order changes the sum by ~1e-16 relative, invisible after the rounding to float).
 #include "jr_kernels.h"
 
 namespace jr {
 
-constexpr int LOSS_WG = 1024;      // one workgroup per mesh: as many threads as a workgroup can have
-__device__ inline double block_sum(double v, double* s) {          // LOSS_WG threads
-    s[threadIdx.x] = v;
+// sum of `v` over the workgroup (<= 256 threads), valid in thread 0
+template <int WG>
+__device__ inline double wg_sum(double v, double* s) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) s[w] = v;
     __syncthreads();
-    for (int w = LOSS_WG / 2; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
-        __syncthreads();
-    }
-    const double r = s[0];
-    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < WG / 64; k++) r += s[k];
     return r;
 }
+// second stage (thread 0 of every workgroup of mesh `b`): accumulate, and the LAST workgroup publishes + resets
+__device__ inline void mesh_sum_finish(double part, double* acc, unsigned* ticket, float* out, int b, unsigned nblocks) {
+    atomicAdd(&acc[b], part);
+    __threadfence();
+    if (atomicAdd(&ticket[b], 1u) == nblocks - 1u) {
+        __threadfence();
+        const double total = atomicAdd(&acc[b], 0.0);             // (an atomic read: coherent across the XCDs' L2s)
+        out[b] = (float)total;
+        atomicExch(reinterpret_cast<unsigned long long*>(&acc[b]), 0ull);
+        atomicExch(&ticket[b], 0u);
+    }
+}
 
-// y = L x (CSR, float like the reference's matmul), loss = sum y^2, grad = 2 L^T y (CSR of the transpose: a gather,
-// no atomics).  y goes through a global scratch row block of the same mesh, written and read by this workgroup only.
-__global__ __launch_bounds__(LOSS_WG) void k_laplacian_loss(const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                        const float* __restrict__ val, const int* __restrict__ rowptr_t,
-                                                        const int* __restrict__ col_t, const float* __restrict__ val_t,
-                                                        const float* __restrict__ x, float* __restrict__ y,
-                                                        float* __restrict__ loss, float* __restrict__ grad, int nv,
-                                                        float scale) {
-    __shared__ double s_red[LOSS_WG];
-    const long off = (long)blockIdx.x * nv * 3;
+// y = L x (CSR, float like the reference's matmul), loss = sum y^2: EIGHT lanes per row (a mesh vertex has ~7 non-zeros:
+// the row is one round of independent loads instead of a chain of seven), 32 rows per workgroup.
+constexpr int LAP_WG = 256;
+__global__ __launch_bounds__(LAP_WG) void k_laplacian_y(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                        const float* __restrict__ val, const float* __restrict__ x,
+                                                        float* __restrict__ y, float* __restrict__ loss, double* acc,
+                                                        unsigned* ticket, int nv) {
+    __shared__ double s_red[LAP_WG / 64];
+    const long off = (long)blockIdx.y * nv * 3;
     x += off; y += off;
-    double part = 0.0;
-    for (int i = threadIdx.x; i < nv; i += LOSS_WG) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+    const int row = blockIdx.x * (LAP_WG / 8) + ((int)threadIdx.x >> 3), l8 = threadIdx.x & 7;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (row < nv)
+        for (int k = rowptr[row] + l8; k < rowptr[row + 1]; k += 8) {
             const float w = val[k];
             const float* p = x + (long)col[k] * 3;
             a0 += w * p[0]; a1 += w * p[1]; a2 += w * p[2];
         }
-        y[i * 3 + 0] = a0; y[i * 3 + 1] = a1; y[i * 3 + 2] = a2;
-        part += (double)(a0 * a0) + (double)(a1 * a1) + (double)(a2 * a2);
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
+    double part = 0.0;
+    if (row < nv && l8 == 0) {
+        y[row * 3 + 0] = a0; y[row * 3 + 1] = a1; y[row * 3 + 2] = a2;
+        part = (double)(a0 * a0) + (double)(a1 * a1) + (double)(a2 * a2);
     }
-    const double total = block_sum(part, s_red);       // its barriers also publish y to the whole workgroup
-    if (threadIdx.x == 0) loss[blockIdx.x] = (float)total;
-    if (!grad) return;
-    __threadfence_block();
-    grad += off;
-    for (int j = threadIdx.x; j < nv; j += LOSS_WG) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; k++) {
+    const double total = wg_sum<LAP_WG>(part, s_red);
+    if (threadIdx.x == 0) mesh_sum_finish(total, acc, ticket, loss, blockIdx.y, gridDim.x);
+}
+// grad = 2 L^T y * scale (CSR of the transpose: a gather, no atomics), the same eight lanes per row
+__global__ __launch_bounds__(LAP_WG) void k_laplacian_grad(const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
+                                                           const float* __restrict__ val_t, const float* __restrict__ y,
+                                                           float* __restrict__ grad, int nv, float scale) {
+    const long off = (long)blockIdx.y * nv * 3;
+    y += off; grad += off;
+    const int row = blockIdx.x * (LAP_WG / 8) + ((int)threadIdx.x >> 3), l8 = threadIdx.x & 7;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (row < nv)
+        for (int k = rowptr_t[row] + l8; k < rowptr_t[row + 1]; k += 8) {
             const float w = val_t[k];
             const float* p = y + (long)col_t[k] * 3;
             a0 += w * p[0]; a1 += w * p[1]; a2 += w * p[2];
         }
-        grad[j * 3 + 0] = 2.f * a0 * scale; grad[j * 3 + 1] = 2.f * a1 * scale; grad[j * 3 + 2] = 2.f * a2 * scale;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
+    if (row < nv && l8 == 0) {
+        grad[row * 3 + 0] = 2.f * a0 * scale; grad[row * 3 + 1] = 2.f * a1 * scale; grad[row * 3 + 2] = 2.f * a2 * scale;
     }
 }
 
@@ -102,19 +128,21 @@ __device__ inline void flatten_half_vjp(D3 a, D3 b, const Half& h, double eps, D
     db = db + b * (2.0 * dbl2) + a * dab;
 }
 
-// One workgroup per mesh: value (in-block double sum) and gradient (float atomics onto the four vertices of every edge
-// pair; grad must arrive zeroed).  Arithmetic in double like the host mirror.
-__global__ __launch_bounds__(LOSS_WG) void k_flatten_loss(const int* __restrict__ v0s, const int* __restrict__ v1s,
+// One THREAD per edge pair, a grid over the edges of every mesh: value (two-stage double sum) and gradient (float atomics
+// onto the four vertices of every edge pair; grad must arrive zeroed).  Arithmetic in double like the host mirror.
+constexpr int FLAT_WG = 128;
+__global__ __launch_bounds__(FLAT_WG) void k_flatten_loss(const int* __restrict__ v0s, const int* __restrict__ v1s,
                                                       const int* __restrict__ v2s, const int* __restrict__ v3s,
                                                       const float* __restrict__ x, float* __restrict__ loss,
-                                                      float* __restrict__ grad, int nv, int ne, float eps_f,
-                                                      float scale) {
-    __shared__ double s_red[LOSS_WG];
-    const long off = (long)blockIdx.x * nv * 3;
+                                                      float* __restrict__ grad, double* acc, unsigned* ticket, int nv,
+                                                      int ne, float eps_f, float scale) {
+    __shared__ double s_red[FLAT_WG / 64];
+    const long off = (long)blockIdx.y * nv * 3;
     x += off;
     const double eps = (double)eps_f;
     double part = 0.0;
-    for (int e = threadIdx.x; e < ne; e += LOSS_WG) {
+    const int e = blockIdx.x * FLAT_WG + (int)threadIdx.x;
+    if (e < ne) {
         const int i0 = v0s[e], i1 = v1s[e], i2 = v2s[e], i3 = v3s[e];
         const D3 p0 = load3(x + (long)i0 * 3);
         const D3 a = load3(x + (long)i1 * 3) - p0, b1 = load3(x + (long)i2 * 3) - p0, b2 = load3(x + (long)i3 * 3) - p0;
@@ -122,34 +150,38 @@ __global__ __launch_bounds__(LOSS_WG) void k_flatten_loss(const int* __restrict_
         const double num = dot(h1.cb, h2.cb);
         const double den = h1.l * h2.l + eps;
         const double cosv = num / den;
-        part += (cosv + 1.0) * (cosv + 1.0);
-        if (!grad) continue;
-        const double g = 2.0 * (cosv + 1.0);
-        D3 da1, db1, da2, db2;
-        flatten_half_vjp(a, b1, h1, eps, h2.cb * (g / den), -num * h2.l / (den * den) * g, da1, db1);
-        flatten_half_vjp(a, b2, h2, eps, h1.cb * (g / den), -num * h1.l / (den * den) * g, da2, db2);
-        const D3 da = da1 + da2;
-        const D3 d0 = (da + db1 + db2) * -1.0;
-        float* gp = grad + off;
-        const double sc = (double)scale;
-        atomicAdd(gp + (long)i1 * 3 + 0, (float)(da.x * sc)); atomicAdd(gp + (long)i1 * 3 + 1, (float)(da.y * sc)); atomicAdd(gp + (long)i1 * 3 + 2, (float)(da.z * sc));
-        atomicAdd(gp + (long)i2 * 3 + 0, (float)(db1.x * sc)); atomicAdd(gp + (long)i2 * 3 + 1, (float)(db1.y * sc)); atomicAdd(gp + (long)i2 * 3 + 2, (float)(db1.z * sc));
-        atomicAdd(gp + (long)i3 * 3 + 0, (float)(db2.x * sc)); atomicAdd(gp + (long)i3 * 3 + 1, (float)(db2.y * sc)); atomicAdd(gp + (long)i3 * 3 + 2, (float)(db2.z * sc));
-        atomicAdd(gp + (long)i0 * 3 + 0, (float)(d0.x * sc)); atomicAdd(gp + (long)i0 * 3 + 1, (float)(d0.y * sc)); atomicAdd(gp + (long)i0 * 3 + 2, (float)(d0.z * sc));
+        part = (cosv + 1.0) * (cosv + 1.0);
+        if (grad) {
+            const double g = 2.0 * (cosv + 1.0);
+            D3 da1, db1, da2, db2;
+            flatten_half_vjp(a, b1, h1, eps, h2.cb * (g / den), -num * h2.l / (den * den) * g, da1, db1);
+            flatten_half_vjp(a, b2, h2, eps, h1.cb * (g / den), -num * h1.l / (den * den) * g, da2, db2);
+            const D3 da = da1 + da2;
+            const D3 d0 = (da + db1 + db2) * -1.0;
+            float* gp = grad + off;
+            const double sc = (double)scale;
+            atomicAdd(gp + (long)i1 * 3 + 0, (float)(da.x * sc)); atomicAdd(gp + (long)i1 * 3 + 1, (float)(da.y * sc)); atomicAdd(gp + (long)i1 * 3 + 2, (float)(da.z * sc));
+            atomicAdd(gp + (long)i2 * 3 + 0, (float)(db1.x * sc)); atomicAdd(gp + (long)i2 * 3 + 1, (float)(db1.y * sc)); atomicAdd(gp + (long)i2 * 3 + 2, (float)(db1.z * sc));
+            atomicAdd(gp + (long)i3 * 3 + 0, (float)(db2.x * sc)); atomicAdd(gp + (long)i3 * 3 + 1, (float)(db2.y * sc)); atomicAdd(gp + (long)i3 * 3 + 2, (float)(db2.z * sc));
+            atomicAdd(gp + (long)i0 * 3 + 0, (float)(d0.x * sc)); atomicAdd(gp + (long)i0 * 3 + 1, (float)(d0.y * sc)); atomicAdd(gp + (long)i0 * 3 + 2, (float)(d0.z * sc));
+        }
     }
-    const double total = block_sum(part, s_red);
-    if (threadIdx.x == 0) loss[blockIdx.x] = (float)total;
+    const double total = wg_sum<FLAT_WG>(part, s_red);
+    if (threadIdx.x == 0) mesh_sum_finish(total, acc, ticket, loss, blockIdx.y, gridDim.x);
 }
 
 void launch_laplacian_loss(hipStream_t st, const int* rowptr, const int* col, const float* val, const int* rowptr_t,
                            const int* col_t, const float* val_t, const float* x, float* y, float* loss, float* grad,
-                           int B, int nv, float scale) {
-    k_laplacian_loss<<<(unsigned)B, LOSS_WG, 0, st>>>(rowptr, col, val, rowptr_t, col_t, val_t, x, y, loss, grad, nv, scale);
+                           double* acc, unsigned* ticket, int B, int nv, float scale) {
+    const dim3 grid((unsigned)((nv + LAP_WG / 8 - 1) / (LAP_WG / 8)), (unsigned)B);
+    k_laplacian_y<<<grid, LAP_WG, 0, st>>>(rowptr, col, val, x, y, loss, acc, ticket, nv);
+    if (grad) k_laplacian_grad<<<grid, LAP_WG, 0, st>>>(rowptr_t, col_t, val_t, y, grad, nv, scale);
 }
 void launch_flatten_loss(hipStream_t st, const int* v0s, const int* v1s, const int* v2s, const int* v3s, const float* x,
-                         float* loss, float* grad, int B, int nv, int ne, float eps, float scale) {
+                         float* loss, float* grad, double* acc, unsigned* ticket, int B, int nv, int ne, float eps, float scale) {
     if (grad) (void)hipMemsetAsync(grad, 0, sizeof(float) * (size_t)B * nv * 3, st);
-    k_flatten_loss<<<(unsigned)B, LOSS_WG, 0, st>>>(v0s, v1s, v2s, v3s, x, loss, grad, nv, ne, eps, scale);
+    const dim3 grid((unsigned)(ne > 0 ? (ne + FLAT_WG - 1) / FLAT_WG : 1), (unsigned)B);
+    k_flatten_loss<<<grid, FLAT_WG, 0, st>>>(v0s, v1s, v2s, v3s, x, loss, grad, acc, ticket, nv, ne, eps, scale);
 }
 
 }  // namespace jr

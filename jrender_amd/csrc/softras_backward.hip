@@ -240,9 +240,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;      // k-th workgroup of its XCD
     const int nheavy = heavy_cap > 0 ? min((int)counters[3], heavy_cap) : 0;
     const int hx = (nheavy - xcd + 7) >> 3;                   // heavy bins dealt to this XCD (launch ranks xcd, xcd + 8, ...)
+    const int tl = 2 * p.sub_log2, tmask = (1 << tl) - 1;     // a bin has 1 << tl tiles
     int brank, sub, part = -1;
-    if (k < hx * 16 * SPLIT) { brank = (k / (16 * SPLIT)) * 8 + xcd; sub = (k / SPLIT) & 15; part = k % SPLIT; }
-    else { const int k2 = k - hx * 16 * SPLIT; brank = (hx + (k2 >> 4)) * 8 + xcd; sub = k2 & 15; }   // bins are dealt round-robin to the XCDs ...
+    if (k < (hx << tl) * SPLIT) { brank = ((k / SPLIT) >> tl) * 8 + xcd; sub = (k / SPLIT) & tmask; part = k % SPLIT; }
+    else { const int k2 = k - (hx << tl) * SPLIT; brank = (hx + (k2 >> tl)) * 8 + xcd; sub = k2 & tmask; }   // bins are dealt round-robin to the XCDs ...
     if (brank >= nbins) return;
     const int bin = bin_order[brank];                         // ... heaviest first (k_bin_alloc_schedule)
     const int n = bin_count[bin];
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     const int b = bin / bins_per_img;
     const int bb = bin - b * bins_per_img;
     const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
-    const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
+    const int col0 = (bx << p.bin_log2) + ((sub & ((1 << p.sub_log2) - 1)) << TILE_LOG2);
+    const int row0 = (by << p.bin_log2) + ((sub >> p.sub_log2) << TILE_LOG2);
     if (col0 >= p.IS || row0 >= p.IS) return;
 
     // Work items are (face, up to 16 of its holders) and the 16 lanes of a DPP row take one.  (Half rows of 8 were built and
@@ -507,17 +509,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
         __syncthreads();                        // the batch's records and tables are free again
     }
     clk.lap(1);
-    clk.flush(counters, 12);
+    if (JR_TUNE_PROFILE_SECTIONS == 1) clk.flush(counters, 12);
 }
 
 template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, const float* rgba, const float* aggrs, const int32_t* ids,
                      const float* grad_rgba, float* grad_faces, float* grad_textures) {
-    const int nbins = ntiles / (SUBS * SUBS);
+    const int tl = 2 * p.sub_log2;
+    const int nbins = ntiles >> tl;
     // heavy bins' tiles by tune::bwd_split wavefronts each when the launch is too small to fill the GPU anyway
     const int heavy_cap = backward_splits_heavy_tiles(p, ws) ? heavy_bins_cap(ws, nbins) : 0;   // (bound of counters[3], as in the forward)
-    const int grid = 8 * 16 * (tune::bwd_split * ((heavy_cap + 7) / 8) + (nbins + 7) / 8);   // whole bins (16 tiles) per XCD slot
+    const int grid = (8 << tl) * (tune::bwd_split * ((heavy_cap + 7) / 8) + (nbins + 7) / 8);   // whole bins per XCD slot
     const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0);
 #define JR_BWD_K(KC) \
     k_softras_backward<DIST, RGB, KC><<<grid, 64, smem, st>>>( \
@@ -555,7 +558,7 @@ void launch_softras_backward(hipStream_t st, const RasterParams& p, const float*
                              const float* rgba, const float* aggrs, const int32_t* ids,
                              const float* grad_rgba, const BinWorkspace& ws, float* grad_faces,
                              float* grad_textures) {
-    const int ntiles = p.B * p.bins_x * p.bins_y * SUBS * SUBS;
+    const int ntiles = (p.B * p.bins_x * p.bins_y) << (2 * p.sub_log2);
     {                                                                                           // SRK:1374-1375
         const size_t na = (size_t)p.B * p.NF * 9, nb = (size_t)p.B * p.NF * p.T * 3;
         const size_t wgs = ((na + nb) / 4 + 255) / 256;

@@ -29,8 +29,13 @@
 namespace jr {
 
 constexpr int TILE = 8;          // pixels per side of a wavefront's tile (8x8 = 64 lanes)
-constexpr int BIN = 32;          // pixels per side of a binning cell (4x4 tiles)
-constexpr int SUBS = BIN / TILE; // tiles per bin side
+constexpr int TILE_LOG2 = 3;
+// Pixels per side of a binning cell: a RUN-TIME value since round 5 (RasterParams::bin_log2 = 3, 4 or 5: bins of 1, 2x2
+// or 4x4 tiles), chosen per launch from the image size or by the caller (jr_softras_set_bin_size; the reference exposes
+// the same choice as `bin_size`, soft_rasterize.py:85-99, C2F:16-18).  Results never depend on it - every pixel sees its
+// faces in ascending order whatever the cell size - only how precisely the lists, the launch order and the heavy-tile
+// classification follow the tiles.  32 is the largest cell: a list entry carries a 16-bit tile mask.
+constexpr int BIN_LOG2_MIN = 3, BIN_LOG2_MAX = 5;
 constexpr int CHUNK = 64;        // faces staged per pass = one per lane
 constexpr int MAX_IMAGE = 4096;
 
@@ -41,7 +46,9 @@ struct RasterParams {
     float rad;   // sqrtf(thr)                 (SRK:316)
     int dist, rgb, alpha, tex, double_side;
     float bg[3];
-    int bins_x, bins_y;   // ceil(IS / BIN)
+    int bins_x, bins_y;   // ceil(IS / bin size)
+    int bin_log2;         // log2 of the bin's side in pixels: 3, 4 or 5
+    int sub_log2;         // bin_log2 - 3: the bin is (1 << sub_log2)^2 tiles; tile `sub` of a bin = (ty << sub_log2) | tx = its bit in a list entry's mask
     // correctly rounded reciprocals of the per-call divisors + "they are in the safe range"
     float far_minus_near, near_minus_far;
     float r_sigma, r_gamma, r_far_minus_near, r_near_minus_far;

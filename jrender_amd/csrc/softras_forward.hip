@@ -307,7 +307,8 @@ __device__ inline bool tile_geom(const RasterParams& p, int bin, int sub, int n,
     t.b = bin / bins_per_img;
     const int bb = bin - t.b * bins_per_img;
     const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
-    const int col0 = bx * BIN + (sub & 3) * TILE, row0 = by * BIN + (sub >> 2) * TILE;
+    const int col0 = (bx << p.bin_log2) + ((sub & ((1 << p.sub_log2) - 1)) << TILE_LOG2);
+    const int row0 = (by << p.bin_log2) + ((sub >> p.sub_log2) << TILE_LOG2);
     if (col0 >= p.IS || row0 >= p.IS) return false;      // tile lies outside the image
     t.col = col0 + (lane & 7); t.row = row0 + (lane >> 3);
     t.valid = t.col < p.IS && t.row < p.IS;
@@ -364,10 +365,11 @@ __device__ inline void store_colour(const RasterParams& p, const TileGeom& t, co
     float* ag = aggrs + (size_t)t.b * 2 * pp + pn;
     ag[0] = o[4]; ag[pp] = o[5];
 }
-// An EMPTY bin (no face reaches its 32x32 pixels; more than half of the bins of the headline batch): ONE wavefront writes
-// the initial state's outputs for all 16 tiles with 16-byte stores of full 128-byte rows - the same values the tiles'
-// own wavefronts would have stored (final_colour of the untouched state), 88 wide stores instead of 16 x 22 narrow ones.
-// Only when image rows are 16-byte aligned and bins are whole (IS % 32 == 0); other sizes take the per-tile path.
+// An EMPTY bin (no face reaches its pixels; more than half of the 32x32 bins of the headline batch): ONE wavefront writes
+// the initial state's outputs for all its tiles with 16-byte stores of whole bin rows - the same values the tiles'
+// own wavefronts would have stored (final_colour of the untouched state), 88 wide stores instead of 16 x 22 narrow ones
+// for a 32x32 bin.  Only when image rows are 16-byte aligned and bins are whole (IS % bin == 0); other sizes take the
+// per-tile path.
 template <int RGB, int KCAP>
 __device__ inline void store_empty_bin(const RasterParams& p, int bin, int lane,
                                        float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
@@ -379,20 +381,22 @@ __device__ inline void store_empty_bin(const RasterParams& p, int bin, int lane,
     float o[6];
     final_colour<RGB>(p, s, o);
     const size_t pp = (size_t)p.IS * p.IS;
-    const size_t base = ((size_t)(by * BIN + (lane >> 3))) * p.IS + bx * BIN + (lane & 7) * 4;    // 8 lanes x 16 B = one 128-byte row
-    const size_t rstep = (size_t)8 * p.IS;
+    // a bin row is (bin / 4) lanes x 16 B (32-pixel bins: 8 lanes = one 128-byte row); the wavefront covers 64 / that many rows per pass
+    const int lsh = p.bin_log2 - 2, binp = 1 << p.bin_log2;
+    const int lrow = lane >> lsh, rows_pp = 64 >> lsh;
+    const size_t base = ((size_t)((by << p.bin_log2) + lrow)) * p.IS + (bx << p.bin_log2) + (lane & ((1 << lsh) - 1)) * 4;
+    const size_t rstep = (size_t)rows_pp * p.IS;
+    const int passes = lrow < binp ? (binp - lrow + rows_pp - 1) / rows_pp : 0;     // 32: 4, 16: 1, 8: 1 (lanes beyond the bin's 8 rows idle)
 #pragma unroll
     for (int c = 0; c < 6; c++) {
         float* pl = (c < 4 ? rgba + ((size_t)b * 4 + c) * pp : aggrs + ((size_t)b * 2 + (c - 4)) * pp) + base;
         const float4 v = make_float4(o[c], o[c], o[c], o[c]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) *reinterpret_cast<float4*>(pl + i * rstep) = v;
+        for (int i = 0; i < passes; i++) *reinterpret_cast<float4*>(pl + i * rstep) = v;
     }
     const int4 m1 = make_int4(-1, -1, -1, -1);
     for (int k = 0; k < p.K; k++) {
         int32_t* pl = ids + ((size_t)b * p.K + k) * pp + base;
-#pragma unroll
-        for (int i = 0; i < 4; i++) *reinterpret_cast<int4*>(pl + i * rstep) = m1;
+        for (int i = 0; i < passes; i++) *reinterpret_cast<int4*>(pl + i * rstep) = m1;
     }
 }
 template <int KCAP, bool WRITTEN_THROUGH, class KB>
@@ -1130,6 +1134,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
             if (wid == tune::sections_wave) clk.lap(0);
             // ---- apply round step-1: lane = pixel, K-buffer | colour ----
             if (wid <= 1 && a_valid) {
+                if (tune::fwd_pipe_prio) __builtin_amdgcn_s_setprio(3);     // the tile's critical chain: win the SIMD's issue arbitration against the task wavefronts
                 const int2 span = s_span[((step + 2) % 3) * 64 + lane];                        // (step - 1) % 3
                 const float4* cells = s_cell + ((step + 1) & 1) * CAP;
                 const float* colb = s_col + (a_batch & 3) * BATCH * 3;
@@ -1142,6 +1147,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                     else apply_colour<RGB, KCAP>(p, cur, colb, tbase, s);
                     cur = nxt;
                 }
+                if (tune::fwd_pipe_prio) __builtin_amdgcn_s_setprio(0);
                 if (wid == tune::sections_wave) clk.lap(6);
             }
             // ---- wavefront 3: the batch after, the next round's list, the next step's state ----
@@ -1245,19 +1251,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     extern __shared__ float4 s_dyn[];
     if (counters[0] > pool_cap) return;     // lists were not built (pool too small): the host launches again
-    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the 16 tiles of a
+    // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the tiles of a
     // bin (same list, same records) go to ONE XCD so that they share its L2.
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
-    const int brank = (k >> 4) * 8 + (blockIdx.x & 7);   // bins are dealt round-robin to the XCDs ...
-    if (brank * 16 >= ntiles_total) return;
+    const int tl = 2 * p.sub_log2, tmask = (1 << tl) - 1; // a bin has 1 << tl tiles
+    const int brank = (k >> tl) * 8 + (blockIdx.x & 7);  // bins are dealt round-robin to the XCDs ...
+    if ((brank << tl) >= ntiles_total) return;
     const int bin = bin_order[brank];                    // ... heaviest first (k_bin_alloc_schedule)
     const int n = bin_count[bin];
-    if (tune::fwd_empty_bins && n == 0 && (p.IS & (BIN - 1)) == 0) {    // empty bin: tile 0's wavefront writes all 16 tiles
-        if ((k & 15) == 0) store_empty_bin<RGB, KCAP>(p, bin, threadIdx.x, aggrs, rgba, ids);
+    if (tune::fwd_empty_bins && n == 0 && (p.IS & ((1 << p.bin_log2) - 1)) == 0) {    // empty bin: tile 0's wavefront writes all its tiles
+        if ((k & tmask) == 0) store_empty_bin<RGB, KCAP>(p, bin, threadIdx.x, aggrs, rgba, ids);
         return;
     }
     TileGeom t;
-    if (!tile_geom(p, bin, k & 15, n, threadIdx.x, t)) return;
+    if (!tile_geom(p, bin, k & tmask, n, threadIdx.x, t)) return;
     tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
 }
 
@@ -1279,14 +1286,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fwd_wav
     const int nheavy = min((int)counters[3], heavy_cap);
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const int hx = (nheavy - xcd + 7) >> 3;              // heavy bins dealt to this XCD (launch ranks xcd, xcd + 8, ...)
-    const bool heavy = k < hx * 16;
+    const int tl = 2 * p.sub_log2, tmask = (1 << tl) - 1; // a bin has 1 << tl tiles
+    const bool heavy = k < (hx << tl);
     int brank, sub;
-    if (heavy) { brank = (k >> 4) * 8 + xcd; sub = k & 15; }
-    else { constexpr int WGB = 16 / NW; const int k2 = k - hx * 16; brank = (hx + k2 / WGB) * 8 + xcd; sub = (k2 % WGB) * NW + wid; }   // NW tiles of a lighter bin per workgroup
+    if (heavy) { brank = (k >> tl) * 8 + xcd; sub = k & tmask; }
+    else { const int s = (k - (hx << tl)) * NW + wid; brank = (hx + (s >> tl)) * 8 + xcd; sub = s & tmask; }   // NW consecutive tiles of this XCD's lighter bins per workgroup (a quarter of a 4x4 bin, a 2x2 bin, four one-tile bins ...)
     if (brank >= nbins) return;
     const int bin = bin_order[brank];
     const int n = bin_count[bin];
-    if (tune::fwd_empty_bins && n == 0 && (p.IS & (BIN - 1)) == 0) {    // empty bin (never heavy): the first of its four workgroups' wavefront 0
+    if (tune::fwd_empty_bins && n == 0 && (p.IS & ((1 << p.bin_log2) - 1)) == 0) {    // empty bin (never heavy): the wavefront that holds its tile 0
         if (sub == 0) store_empty_bin<RGB, KCAP>(p, bin, lane, aggrs, rgba, ids);
         return;
     }
@@ -1311,7 +1319,8 @@ template <int DIST, int RGB, int KCAP>
 static void launch_kk(hipStream_t st, const RasterParams& p, const float* textures,
                       const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
     const int nbins = p.B * p.bins_x * p.bins_y;
-    const int ntiles = nbins * SUBS * SUBS;
+    const int tl = 2 * p.sub_log2;                   // a bin has 1 << tl tiles
+    const int ntiles = nbins << tl;
     // Four wavefronts per heavy tile cut the critical path of a launch (one 39k-face view: 0.69 -> 0.38 ms), but the
     // waiting wavefronts hold slots that a full GPU has better uses for (eight views: 0.89 -> 0.98 ms even when only the
     // bins above 1024 faces are heavy): the four-wavefront kernel takes launches of up to fwd_heavy_pixels pixels.
@@ -1322,7 +1331,7 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
         const int heavy_cap = heavy_bins_cap(ws, nbins);
         auto launch = [&](auto nw_tag) {
             constexpr int NW = decltype(nw_tag)::value;
-            const int per_xcd = 16 * ((heavy_cap + 7) / 8) + (16 / NW) * ((nbins + 7) / 8);
+            const int per_xcd = (((heavy_cap + 7) / 8) << tl) + ((((nbins + 7) / 8) << tl) + NW - 1) / NW;
             k_softras_forward_mixed<DIST, RGB, KCAP, NW><<<8 * per_xcd, 64 * NW, mixed_lds_bytes(NW), st>>>(
                 p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
         };
@@ -1347,7 +1356,8 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
         return;
     }
     ws.heavy_waves_used = 1;
-    const int grid = ((ntiles + 127) / 128) * 128;   // whole bins (16 tiles) per XCD slot
+    const int per = 8 << tl;
+    const int grid = ((ntiles + per - 1) / per) * per;   // whole bins per XCD slot
     // JR_FWD_LDS_PAD (bytes, diagnostics only): more dynamic LDS per wavefront = fewer wavefronts per CU
     static const size_t pad = getenv("JR_FWD_LDS_PAD") ? (size_t)atol(getenv("JR_FWD_LDS_PAD")) : 0;
     const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0) + pad;

@@ -44,6 +44,8 @@ def neg_iou_loss(predict, target):
     if isinstance(predict, _ffi.DeviceArray):
         ctx = predict.ctx
         t = target if isinstance(target, _ffi.DeviceArray) else ctx.array(np.asarray(target, F32))
+        if t.size != predict.size:
+            raise ValueError("target %s does not match predict %s" % (t.shape, predict.shape))
         B = predict.shape[0]
         iou = ctx.empty((B,), F32)
         _ffi._check(_ffi.load().jr_neg_iou_loss(ctx.handle, predict.ptr, t.ptr, iou.ptr, None, B, predict.size // B, 1.0))
@@ -94,13 +96,48 @@ class _DeviceLoss:
         return a if dtype is None else a.astype(dtype)
 
     def __float__(self):
-        return float(np.mean(self.values.numpy()))
+        # consistent with numpy(): the batch mean when the loss averages, else the value of the ONE mesh - a per-mesh
+        # vector has no float (what float() of the host result says too)
+        v = self.numpy()
+        if np.ndim(v) and np.size(v) != 1:
+            raise TypeError("only a loss built with average=True (or a batch of one mesh) converts to a float; "
+                            "use .numpy() for the %d per-mesh values" % np.size(v))
+        return float(np.reshape(v, -1)[0]) if np.ndim(v) else float(v)
 
 
 class LaplacianLoss:
     def __init__(self, vertex, faces, average=False):
         vertex, faces = np.asarray(vertex), np.asarray(faces).astype(np.int64)
         self.nv, self.nf, self.average = vertex.shape[0], faces.shape[0], average
+        # laplacian_loss.py:14-29 builds the matrix dense: -1 for every edge (set, not accumulated), the diagonal = the
+        # vertex degree, rows divided by it.  ~7 non-zeros per row: built and applied as CSR here (a threaded BLAS needs
+        # 30 ms for the dense 1352 x 1352 x 3 product on a 256-thread host, the sparse one 0.1 ms; the headline mesh's
+        # 19 502 x 19 502 matrix would be 1.5 GB); `.laplacian` materialises the reference's dense array on demand.
+        self._dense = None
+        try:
+            from scipy.sparse import coo_matrix, csr_matrix, diags
+            e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 0]], faces[:, [1, 2]], faces[:, [2, 1]],
+                                faces[:, [2, 0]], faces[:, [0, 2]]])
+            adj = coo_matrix((np.ones(len(e), F32), (e[:, 0], e[:, 1])), shape=(self.nv, self.nv)).tocsr()
+            adj.data[:] = -1.0                                     # duplicates were summed: an edge is -1 however many faces share it
+            deg = -np.asarray(adj.sum(1)).reshape(-1).astype(F32)   # lap[r, r] = -sum of the row
+            with np.errstate(divide="ignore", invalid="ignore"):
+                inv = (F32(1) / deg).astype(F32)
+            lap = (adj + diags(deg.astype(F32), format="csr")).tocsr().astype(F32)
+            lap.sort_indices()
+            # row / diagonal, element by element like the reference's `lap /= lap[r, c][:, None]` (a float division each)
+            rows = np.repeat(np.arange(self.nv), np.diff(lap.indptr))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                lap.data = (lap.data / deg[rows]).astype(F32)
+            del inv
+            self._csr = csr_matrix(lap)
+            self._csr_t = csr_matrix(lap.T.tocsr())
+            self._csr_t.sort_indices()
+        except ImportError:                     # pragma: no cover
+            self._csr = self._csr_t = None
+            self._dense = self._dense_matrix(faces)
+
+    def _dense_matrix(self, faces):
         lap = np.zeros([self.nv, self.nv], F32)
         lap[faces[:, 0], faces[:, 1]] = -1
         lap[faces[:, 1], faces[:, 0]] = -1
@@ -111,15 +148,14 @@ class LaplacianLoss:
         r, c = np.diag_indices(self.nv)
         lap[r, c] = -lap.sum(1)
         lap /= lap[r, c][:, None]
-        self.laplacian = lap                    # dense, as in the reference (laplacian_loss.py:29)
-        # ~7 non-zeros per row: the products go through CSR (a threaded BLAS needs 30 ms for this
-        # 1352 x 1352 x 3 product on a 256-thread host, the sparse one 0.1 ms)
-        try:
-            from scipy.sparse import csr_matrix
-            self._csr = csr_matrix(lap)
-            self._csr_t = csr_matrix(np.ascontiguousarray(lap.T))
-        except ImportError:                     # pragma: no cover
-            self._csr = self._csr_t = None
+        return lap
+
+    @property
+    def laplacian(self):
+        """The dense [nv, nv] matrix of the reference (laplacian_loss.py:29), materialised on first use."""
+        if self._dense is None:
+            self._dense = np.asarray(self._csr.todense(), F32)
+        return self._dense
 
     def _apply(self, x, transpose=False):
         m = self._csr_t if transpose else self._csr
@@ -150,7 +186,11 @@ class LaplacianLoss:
         """(rowptr, col, val) of L and of its transpose on the device, uploaded once per context."""
         cache = self.__dict__.setdefault("_dev", {})
         if id(ctx) not in cache:
-            arrays = _csr_arrays(self.laplacian) + _csr_arrays(np.ascontiguousarray(self.laplacian.T))
+            if self._csr is not None:           # rows ascending, columns ascending within a row (what _csr_arrays gives for the dense matrix)
+                arrays = tuple(x for m in (self._csr, self._csr_t)
+                               for x in (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(F32)))
+            else:
+                arrays = _csr_arrays(self.laplacian) + _csr_arrays(np.ascontiguousarray(self.laplacian.T))
             cache[id(ctx)] = (ctx,) + tuple(ctx.array(a) for a in arrays)
         return cache[id(ctx)][1:]
 

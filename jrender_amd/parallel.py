@@ -20,7 +20,7 @@ import numpy as np
 from . import _ffi
 from . import comm as _comm
 
-__all__ = ["shard_bounds", "BatchShards", "ShardedSoftRasterizer"]
+__all__ = ["shard_bounds", "BatchShards", "ShardedSoftRasterizer", "launch_ranks"]
 
 
 def shard_bounds(batch, world_size):
@@ -130,3 +130,90 @@ def shared_vertex_gradient(grad_faces, faces, num_vertices, comm=None):
     else:
         gv = np.zeros((num_vertices, 3), np.float32)
     return comm.all_reduce_sum(gv.astype(np.float32))
+
+
+def launch_ranks(script, n, argv, timeout_s=1500.0, name=None, relay_stdout=True):
+    """Start ``n`` ranks of ``script`` (one process per GPU, each its own process group) with a private 0700 rendezvous
+    directory, relay rank 0's stdout.  ALL children are polled: if any rank exits non-zero (or the whole launch exceeds
+    ``timeout_s``) before the others are done, the rest is killed and the launcher returns non-zero after printing the tail
+    of the failing rank's stderr (every rank's stderr goes to a file in the rendezvous directory) - a rank that dies before
+    ``ncclCommInitRank`` completes must not leave the others waiting for ever.  Used by ``bench.py --gpus N`` and
+    ``examples/demo2_deform.py --gpus N``.  -> 0 on success, 1 on failure."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import tempfile
+    import time
+    name = name or os.path.basename(script)
+    rdzv = tempfile.mkdtemp(prefix="jrender_%s_" % os.path.splitext(name)[0])
+    procs, logs = [], []
+    for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the MI355X host driver of this pool only supports dmabuf IPC; RCCL's
+        # cross-process buffer registration fails with `hipIpcGetMemHandle: invalid argument` without it.  An
+        # explicit setting in the caller's environment wins.
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   JRENDER_RDZV=os.path.join(rdzv, "rdzv"), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = open(os.path.join(rdzv, "rank%d.out" % r), "w+b")
+        err = open(os.path.join(rdzv, "rank%d.err" % r), "w+b")
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
+                                      stdout=out, stderr=err, start_new_session=True))
+
+    def tail(f, nbytes=3000):
+        f.flush(); f.seek(0, 2); size = f.tell(); f.seek(max(0, size - nbytes))
+        return f.read().decode(errors="replace")
+
+    def kill_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)       # the rank's own process group (start_new_session)
+                except OSError:
+                    pass
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except Exception:
+                pass
+
+    failure, t0 = None, time.time()
+    while failure is None and any(q.poll() is None for q in procs):
+        for r, q in enumerate(procs):
+            rc = q.poll()
+            if rc not in (None, 0):
+                failure = "rank %d exited with code %d" % (r, rc)
+                break
+        else:
+            if time.time() - t0 > timeout_s:
+                failure = "launch exceeded %.0f s" % timeout_s
+            else:
+                time.sleep(0.05)
+    if failure is None:
+        bad = [(r, q.returncode) for r, q in enumerate(procs) if q.returncode]
+        if bad:
+            failure = "rank %d exited with code %d" % bad[0]
+    if failure is not None:
+        kill_all()
+        sys.stderr.write("%s: %s; exit codes %s\n" % (name, failure, [q.returncode for q in procs]))
+        for r, (_o, e) in enumerate(logs):
+            t = tail(e).strip()
+            if t:
+                sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, t))
+    else:
+        if relay_stdout:
+            sys.stdout.write(tail(logs[0][0], 1 << 20))
+            sys.stdout.flush()
+        for r, (_o, e) in enumerate(logs):                 # warnings of healthy ranks stay visible
+            t = tail(e).strip()
+            if t:
+                sys.stderr.write("---- rank %d stderr ----\n%s\n" % (r, t))
+    for o, e in logs:
+        o.close(); e.close()
+    try:
+        for f in os.listdir(rdzv):
+            os.unlink(os.path.join(rdzv, f))
+        os.rmdir(rdzv)
+    except OSError:
+        pass
+    return 1 if failure is not None else 0

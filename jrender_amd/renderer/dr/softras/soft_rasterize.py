@@ -8,9 +8,11 @@ NumPy arrays (copied to the GPU) or ``DeviceArray``s; outputs are ``DeviceArray`
 (``.numpy()`` like a ``jt.Var``).
 
 Differences that are deliberate and documented:
-  * ``bin_size`` / ``max_elems_per_bin`` are accepted and ignored: the reference's
-    coarse-to-fine path (C2F) is an optimisation with nondeterministic face order;
-    here screen tiling is always on and deterministic, results equal ``bin_size=0``.
+  * ``bin_size`` > 0 selects the screen-bin size of this operator's launches (``jr_softras_set_bin_size``:
+    rounded up to 8, 16 or 32 pixels; 0 = chosen from the image size) - the knob the reference's
+    coarse-to-fine path (C2F) exposes (SRW:85-99, C2F:16-18; demo2-deform.py:65 passes 16).  Screen binning
+    is always on here and deterministic, so RESULTS equal the reference's ``bin_size=0`` path for every value;
+    ``max_elems_per_bin`` is accepted and ignored (the lists here are sized exactly, nothing is truncated).
   * ``background_color`` is ignored exactly like the reference (SRW:68-74 builds a
     pre-filled tensor but never passes it to the kernel; the kernel's memset makes
     the background 0, SRK:469).  ``honor_background=True`` opts into the evident intent.
@@ -107,8 +109,9 @@ class SoftRasterizeFunction:
         bg = None
         if self.honor_background:
             bg = (C.c_float * 3)(*[float(np.float32(c)) for c in self.background_color])
-        _ffi._check(lib.jr_softras_forward(ctx.handle, fv.ptr, tex.ptr, faces_info.ptr, aggrs_info.ptr,
-                                           soft_colors.ptr, faces_id_buffer.ptr, *self._scalars(), bg))
+        with ctx.bin_size_scope(self.bin_size):                     # SRW:85-99: the caller's bin size, when given
+            _ffi._check(lib.jr_softras_forward(ctx.handle, fv.ptr, tex.ptr, faces_info.ptr, aggrs_info.ptr,
+                                               soft_colors.ptr, faces_id_buffer.ptr, *self._scalars(), bg))
         self._ctx = ctx
         # generation token of the set-up pass: lets the backward reuse the forward's face records as long
         # as no other forward ran on this context in between (the saved inputs are private clones)
@@ -131,10 +134,11 @@ class SoftRasterizeFunction:
         grad_textures = ctx.empty(tex.shape, np.float32)
         if fv.shape[0] == 0:
             return grad_faces, grad_textures
-        _ffi._check(_ffi.load().jr_softras_backward_ex(
-            ctx.handle, fv.ptr, tex.ptr, soft_colors.ptr, faces_info.ptr, aggrs_info.ptr,
-            faces_id_buffer.ptr, g.ptr, grad_faces.ptr, grad_textures.ptr, *self._scalars(),
-            C.c_uint64(self._token)))
+        with ctx.bin_size_scope(self.bin_size):                     # (the forward's records are reused only under the forward's bin size)
+            _ffi._check(_ffi.load().jr_softras_backward_ex(
+                ctx.handle, fv.ptr, tex.ptr, soft_colors.ptr, faces_info.ptr, aggrs_info.ptr,
+                faces_id_buffer.ptr, g.ptr, grad_faces.ptr, grad_textures.ptr, *self._scalars(),
+                C.c_uint64(self._token)))
         return grad_faces, grad_textures
 
 

@@ -101,13 +101,23 @@ class Renderer:
                 return self.transform.transformer.backward_from_faces(gfv, device_faces(v.ctx, shared), v)
             gndc = face_vertices_backward(gfv.reshape(gfv.shape[0], nf, 3, 3), self._faces, v.shape[1])
             return self.transform.transformer.backward(gndc, v)
-        if isinstance(v, _ffi.DeviceArray):
-            v = v.numpy()
+        dev = v if isinstance(v, _ffi.DeviceArray) else None
+        if dev is not None:
+            # device vertices but a face array the rasteriser doubled (NMR's fill_back appends the reversed faces): the fold
+            # of the appended half runs on the host; the RESULT keeps the device path's contract - a DeviceArray
+            # [VB,nv,3], summed over the views when they share one vertex set (VB = 1)
+            v = dev.numpy()
             if v.shape[0] != gfv.shape[0]:
                 v = np.broadcast_to(v, (gfv.shape[0],) + v.shape[1:])
         gfv = self._fold_back(gfv.numpy().reshape(v.shape[0], -1, 3, 3))
         gndc = face_vertices_backward(gfv, self._faces, v.shape[1])
-        return self.transform.transformer.backward(gndc, v)
+        g = self.transform.transformer.backward(gndc, v)
+        if dev is None:
+            return g
+        g = np.asarray(g, np.float32)
+        if dev.shape[0] == 1 and g.shape[0] != 1:
+            g = g.sum(0, keepdims=True, dtype=np.float32)
+        return dev.ctx.array(np.ascontiguousarray(g))
 
     def grad_textures(self, grad_rgb):
         """d(loss)/d(mesh.textures) of the last ``render_mesh(mode='rgb')`` with 'surface' textures ([B,NF,T,3]

@@ -43,6 +43,8 @@ def _prototypes():
                 kinds.append("size")
             elif re.match(r"(const )?float\b", prm):
                 kinds.append("float")
+            elif re.match(r"(const )?double\b", prm):
+                kinds.append("double")
             elif re.match(r"(const )?(int|int32_t|uint32_t|unsigned)\b", prm):
                 kinds.append("int")
             else:
@@ -56,7 +58,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
     floats where it has floats (a miscounted pointer list only shows up as a TypeError on the GPU box otherwise)."""
     C = ctypes
     kind_of = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_int: "int", C.c_uint: "int", C.c_uint32: "int", C.c_int32: "int",
-               C.c_float: "float", C.c_size_t: "size", C.c_uint64: "size", C.c_ulonglong: "size"}
+               C.c_float: "float", C.c_double: "double", C.c_size_t: "size", C.c_uint64: "size", C.c_ulonglong: "size"}
     protos = _prototypes()
     for name, (_, argtypes) in _ffi.SIGNATURES.items():
         assert name in protos, name

@@ -104,10 +104,11 @@ def test_mesh_above_bitmap_capacity(image_size, npix):
     ctx = _ffi.Context.default()
     nf = 270000
     fv, tex = syn.triangle_soup(nf, 1, seed=21, scale=1.5)
-    fn = SoftRasterizeFunction(image_size=image_size, max_faces_per_pixel_for_grad=K, sigma_val=1e-5, ctx=ctx)
+    # (bin_size=32: the two fall-back sorts are told apart by what a 32-pixel bin lists, whatever size the launch policy would pick)
+    fn = SoftRasterizeFunction(image_size=image_size, max_faces_per_pixel_for_grad=K, sigma_val=1e-5, bin_size=32, ctx=ctx)
     fn(fv, tex)
     st = ctx.last_stats()
-    assert (st["max_faces_in_bin"] <= 4096) == (image_size == 512)
+    assert ctx.bin_size() == 32 and (st["max_faces_in_bin"] <= 4096) == (image_size == 512)
     ids_all = fn.save_vars[5].numpy()
     rgba_all = fn.save_vars[2].numpy()
     pix = np.unique(np.random.default_rng(5).choice(image_size * image_size, npix, replace=False))

@@ -30,6 +30,7 @@ HEAVY_MIN = 96          # faces listed in a 32x32 bin; the scenes below put 150-
 @pytest.fixture(scope="module")
 def hctx():
     ctx = _ffi.Context(0)                      # own context: the policy must not leak into the other test modules
+    ctx.set_bin_size(32)                       # this module's scenes and threshold are sized for 32-pixel bins (the other geometries: test_gpu_bin_geometry.py)
     yield ctx
     ctx.set_launch_policy(-1, 0)
     ctx.close()

@@ -183,3 +183,45 @@ def test_bench_launcher_reports_a_dead_rank_instead_of_hanging():
     assert time.time() - t0 < 120
     assert "exited with code" in out.stderr and "injected failure of rank 1" in out.stderr, out.stderr[-1500:]
     assert not out.stdout.strip()                       # no JSON line from a failed launch
+
+
+def test_launch_ranks_kills_the_survivors_of_a_dead_rank(tmp_path):
+    """jrender_amd.parallel.launch_ranks - the launcher behind `bench.py --gpus N` and `examples/demo2_deform.py --gpus N`
+    (the example used to wait on its ranks one after the other): rank 1 dies at once, ranks 0 and 2
+    would sleep for a minute (a rank blocked in ncclCommInitRank); the launch must end within seconds, non-zero, with the
+    dead rank's stderr, and leave no child behind."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['JRENDER_RDZV'] and os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
+                      "if os.environ['RANK'] == '1':\n"
+                      "    time.sleep(0.5); sys.stderr.write('rank 1 lost its GPU\\n'); sys.exit(3)\n"
+                      "time.sleep(60)\n" % str(tmp_path))
+    driver = ("import sys; sys.path.insert(0, %r)\n"
+              "from jrender_amd.parallel import launch_ranks\n"
+              "sys.exit(launch_ranks(%r, 3, [], timeout_s=30, name='demo'))\n" % (root, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", driver], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and time.time() - t0 < 25
+    assert "demo: rank 1 exited with code 3" in out.stderr and "rank 1 lost its GPU" in out.stderr, out.stderr[-1500:]
+    time.sleep(0.3)
+    for r in (0, 2):
+        pid = int((tmp_path / ("pid%d" % r)).read_text())
+        assert not os.path.exists("/proc/%d" % pid) or "Z" in open("/proc/%d/stat" % pid).read().split()[2]
+    # a healthy launch relays rank 0's stdout and returns 0
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nprint('hello from rank', os.environ['RANK'])\n")
+    driver2 = driver.replace(str(script), str(ok))
+    out = subprocess.run([sys.executable, "-c", driver2], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "hello from rank 0", (out.stdout, out.stderr)
+
+
+def test_the_demo2_example_uses_the_polled_launcher():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "examples", "demo2_deform.py")).read()
+    assert "from jrender_amd.parallel import launch_ranks" in src and "p.wait() for p in procs" not in src

@@ -10,7 +10,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 HEAVY = "--heavy" in sys.argv          # wavefront 0 of the heaviest bin's 16 tiles in the four-wavefront path, ONE view
-os.environ.setdefault("JRENDER_LIB", os.path.join(ROOT, "jrender_amd", "csrc", "libjrender_hip_sections%s.so" % ("_heavy" if HEAVY else "")))
+SETUP = "--setup" in sys.argv          # k_face_setup / k_bin_fill instead of the raster kernels (variant sections_setup)
+os.environ.setdefault("JRENDER_LIB", os.path.join(ROOT, "jrender_amd", "csrc", "libjrender_hip_sections%s.so" % ("_heavy" if HEAVY else ("_setup" if SETUP else ""))))
 sys.path.insert(0, ROOT)
 from jrender_amd import _ffi, synthetic as syn                                     # noqa: E402
 from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction   # noqa: E402
@@ -25,6 +26,9 @@ if "--shape" in sys.argv:          # --shape faces,views,image_size[,sigma[,rgb]
     if len(a) > 4:
         KW["aggr_func_rgb"] = a[4]
 fv, tex = syn.sphere_views(NF, NB)
+if "--spot" in sys.argv:            # --spot IMAGE_SIZE: the spot cow (5 856 faces, 25 texels per face) of BASELINE configs[0..1], one view
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g1_spot.npz"))
+    fv, tex, NB, IS = z["fv"], z["tex"], 1, int(sys.argv[sys.argv.index("--spot") + 1])
 fv, tex = ctx.array(fv), ctx.array(tex)
 g = ctx.array(np.random.default_rng(7).uniform(-1, 1, (NB, 4, IS, IS)).astype(np.float32))
 fn = SoftRasterizeFunction(image_size=IS, ctx=ctx, **KW)
@@ -34,6 +38,15 @@ ctx.section_clocks()
 for _ in range(5):
     fn.execute(fv, tex); fn.grad(g)
 c = np.asarray(ctx.section_clocks(), np.float64)
+if SETUP:
+    nw_setup = -(-fv.shape[0] * fv.shape[1] // 64)
+    for name, lo, labels in (("k_face_setup", 0, ["face load + face_setup", "faces_info store", "record + store", "pixel ranges", "bin counts"]),
+                             ("k_bin_fill", 8, ["rectangle load", "append loop"])):
+        tot = c[lo:lo + 8].sum()
+        print(name, "clocks per wavefront and launch %.0f (%.2f us at 2.4 GHz)" % (tot / nw_setup / 5, tot / nw_setup / 5 / 2400))
+        for i, lab in enumerate(labels):
+            print("   %-24s %5.1f %%   %8.0f clocks" % (lab, 100 * c[lo + i] / max(tot, 1), c[lo + i] / nw_setup / 5))
+    sys.exit(0)
 if HEAVY:
     tot = c[0:8].sum()
     print("heaviest bin, wavefront 0 of its 16 tiles, %d launches: %.3g clocks per tile and launch" % (5, tot / 16 / 5))

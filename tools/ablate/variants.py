@@ -77,6 +77,9 @@ VARIANTS = {
     "n3diag_noout": ["JR_TUNE_DIAG=2048"], "n3diag_noin": ["JR_TUNE_DIAG=4096"], "n3diag_nowalks": ["JR_TUNE_DIAG=6144"],   # WRONG gradients: the NMR pixel-map kernel without its out / in walks
     "n3_face_walks": ["JR_TUNE_N3_LINE_WALKS=0", "JR_TUNE_N3_PIXMAP_WAVES=4"], "n3_lp1": ["JR_TUNE_N3_LINE_PARTS=1"], "n3_lp4": ["JR_TUNE_N3_LINE_PARTS=4"], "n3_lp16": ["JR_TUNE_N3_LINE_PARTS=16"], "n3_lw4": ["JR_TUNE_N3_PIXMAP_WAVES=4"],           # round 4: NMR out-walks by the per-face kernel through the L2s (before the per-line regrouping)
     "hard_exact_off": ["JR_TUNE_FWD_HARD_EXACT=0"],          # round 4: what does the uniform 'hard alpha -> IEEE inside distance' branch cost the default modes?
+    # round 5
+    "pipe_prio": ["JR_TUNE_FWD_PIPE_PRIO=1"],              # pipelined heavy tile: s_setprio 3 while wavefronts 0 / 1 apply
+    "sections_setup": ["JR_TUNE_PROFILE_SECTIONS=3"],     # instrumented: k_face_setup / k_bin_fill section clocks (tools/ablate/sections.py --setup)
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
 }
