@@ -335,12 +335,12 @@ def bench_n3mr(args, ctx, comm, rank, world):
     print(json.dumps(out), flush=True)
 
 
-def fwd_bwd_ms(ctx, comm, fv_h, tex_h, IS, K, steps=30, warmup=5, seed=3):
+def fwd_bwd_ms(ctx, comm, fv_h, tex_h, IS, K, steps=30, warmup=5, seed=3, **op_kwargs):
     """fwd+bwd of one device-resident batch: median ms per step and the per-phase brackets."""
     from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
     fv, tex = ctx.array(fv_h), ctx.array(tex_h)
     grad = ctx.array(np.random.default_rng(seed).uniform(-1, 1, (fv_h.shape[0], 4, IS, IS)).astype(np.float32))
-    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx, **op_kwargs)
 
     def step():
         fn.execute(fv, tex)
@@ -382,7 +382,7 @@ def secondary_lines(args, ctx, comm):
     out = {}
     fv1, tex1 = syn.sphere_views(NF, 1)
     st, ph = fwd_bwd_ms(ctx, comm, fv1, tex1, IS, K)
-    out["b1"] = {"workload": "ONE %d-face sphere view %dx%d fwd+bwd, K=%d" % (NF, IS, IS, K), "ms": st, "phase_ms": ph}
+    out["b1"] = {"workload": "ONE %d-face sphere view %dx%d fwd+bwd, K=%d" % (NF, IS, IS, K), "ms": st, "phase_ms": ph, "bin_size": ctx.bin_size()}
     fv8, tex8 = syn.sphere_views(NF, args.batch)
     for k2 in (32, 64):
         st, ph = fwd_bwd_ms(ctx, comm, fv8, tex8, IS, k2, steps=10, warmup=2)
@@ -398,6 +398,22 @@ def secondary_lines(args, ctx, comm):
     m = measure_n3mr(ctx, comm, NF, IS, 20, 3)
     out["n3mr"] = {"workload": "NMR rgb+alpha+depth fwd+bwd, %d faces (fill_back x2), %dx%d, batch 1 (BASELINE configs[4])" % (m["NF2"], IS, IS),
                    "ms": percentiles(m["per_step"]), "phase_ms": m["phase_ms_per_step"], "roofline": m["roofline"]}
+    # the other NAMED BASELINE configurations as operator calls (fwd + bwd, device-resident inputs): the spot
+    # cow of configs[0..1] on its own data (tests/golden/g1_spot.npz: 5 856 faces, texture_res 5), config 4's operator shape
+    try:
+        spot = np.load(os.path.join(ROOT, "tests", "golden", "g1_spot.npz"))
+        for name, size in (("c1_spot_256", 256), ("c2_spot_1024", 1024)):
+            st, ph = fwd_bwd_ms(ctx, comm, spot["fv"], spot["tex"], size, K)
+            ab = algorithmic_bytes(1, spot["fv"].shape[1], spot["tex"].shape[2], size, K)
+            out[name] = {"workload": "spot cow %d faces, T=%d, %dx%d, one view, fwd+bwd (BASELINE configs[%d])" % (
+                spot["fv"].shape[1], spot["tex"].shape[2], size, size, 0 if size == 256 else 1),
+                "ms": st, "phase_ms": ph, "bin_size": ctx.bin_size(), "step_frac": ab["step"] / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        fv4, tex4 = syn.sphere_views(3300, 64)
+        st, ph = fwd_bwd_ms(ctx, comm, fv4, tex4, 64, K, sigma_val=1e-4, aggr_func_rgb="hard")
+        out["c4_operator"] = {"workload": "config 4's operator call: 3 300-face sphere, 64 views at 64x64, sigma 1e-4, hard rgb, fwd+bwd",
+                              "ms": st, "phase_ms": ph, "bin_size": ctx.bin_size()}
+    except Exception as e:
+        out["named_configs_error"] = repr(e)
     try:        # BASELINE configs[3]: the demo2 silhouette-fitting loop end to end (64 views at 64^2, 1 352-vertex template)
         out["c4_demo2"] = demo2_loop_ms()
     except Exception as e:
@@ -494,6 +510,16 @@ def bench_softras(args, ctx, comm, rank, world):
         valu["busy_raw"] = raw
         valu["busy"] = min(1.0, raw)
         valu["useful_lane_frac"] = valu["busy"] * valu["lane_util"]
+        # how close is the forward to what ITS arithmetic costs with every lane busy?  tools/sim/min_valu.py
+        # prices the shipped kernel's ISA, region by region, with the trip / lane counts of an instrumented GPU run
+        # (profiles/r05_path_counts.json) - it reproduces the PMC's VALU count - and the same at 64 lanes per trip:
+        mv = load_json("min_valu_latest.json") if dom == "fwd_raster" else None
+        if mv:
+            valu["attainable_ms"] = mv["attainable_ms"]
+            valu["frac_of_attainable"] = mv["attainable_ms"] / per_launch[dom]
+            valu["model_over_measured_valu"] = mv["model_over_measured"]
+            valu["split_ms_of_the_profiled_launch"] = mv["split_ms"]
+            valu["gap_owner"] = mv["gap_owner"]
     out = {
         "metric": "SoftRas fwd+bwd images/s @1024x1024, 39k faces",
         "value": world * B / (elapsed / args.steps),

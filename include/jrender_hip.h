@@ -296,6 +296,13 @@ int jr_softras_set_launch_policy(jr_ctx* ctx, int heavy_min_faces, int heavy_wav
  * jr_softras_bin_size: the size a launch at `image_size` would use now; image_size <= 0: the size the workspace's
  * current face records / lists were built with (0 before the first forward). */
 int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size);
+/* Colour-path arithmetic of the forward (sticky per context; default 0).  0: the coverage sigmoid and the softmax weights
+ * use the hardware's exp2 / reciprocal (cuda/soft_rasterize.py:338-344, :401-411 evaluate them with expf and a
+ * double-precision quotient): RGBA within 5e-5 of the reference, gradients within 1e-4 of the largest component, but
+ * 1 - 2e-4 ELEMENT-WISE (|a - b| / (|b| + 1e-3 max|b|)) - the last ulp of D amplified by (k - o) / D / gamma.  1: the
+ * reference's own arithmetic for both quantities (a second set of forward kernels): RGBA 8e-6, gradients under 1e-4
+ * element-wise; forward +15 % on the headline batch.  The face-index buffer and faces_info are bit-exact in both modes. */
+int jr_softras_set_precise_colour(jr_ctx* ctx, int on);
 int jr_softras_bin_size(const jr_ctx* ctx, int image_size);
 /* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
  * previous call, [0..7] forward raster, [8..15] backward raster; all zero in the product build */

@@ -12,8 +12,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libjrender_hip.so")
-SOURCES = ["jr_api.cpp", "jr_comm.cpp", "binning.hip", "softras_forward.hip", "softras_backward.hip", "aux_kernels.hip", "loss_kernels.hip", "optim_kernels.hip", "n3mr_kernels.hip"]
+SOURCES = ["jr_api.cpp", "jr_comm.cpp", "binning.hip", "softras_forward.hip", "softras_forward_precise.hip", "softras_backward.hip", "aux_kernels.hip", "loss_kernels.hip", "optim_kernels.hip", "n3mr_kernels.hip"]
 HEADERS = ["jr_kernels.h", "softras_device.h", "jr_tuning.h", "../../include/jrender_hip.h"]
+INCLUDES = {"softras_forward_precise.hip": ["softras_forward.hip"]}     # sources that #include other sources
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -37,7 +38,8 @@ def build(force=False, verbose=False, variant=None, defines=()):
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + suffix + ".o")
         objs.append(obj)
-        if force or variant or _stale(obj, [src] + hdrs):
+        also = [os.path.join(CSRC, d) for d in INCLUDES.get(s, [])]
+        if force or variant or _stale(obj, [src] + also + hdrs):
             jobs.append([HIPCC, *FLAGS, *["-D" + d for d in defines], "-x", "hip", "-c", src, "-o", obj])
     if jobs:
         def run(cmd):

@@ -58,6 +58,7 @@ struct jr_ctx {
     // set-up pass resolves them for ITS launch: bin size 0 = by image size, threshold < 0 = the default of that bin size.
     int bin_size_user = 0;
     int heavy_min_user = -1;
+    int precise_colour = 0;                  // jr_softras_set_precise_colour: the forward's colour path in the reference's own arithmetic
     float bins_rad = 0.f;
     int64_t stats[4] = {0, 0, 0, 0};
     int64_t launch_info[4] = {0, 0, 0, 0};  // last forward: multi-wavefront kernel used, heavy bins, wavefronts per workgroup
@@ -276,7 +277,8 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
         ws.heavy_waves = waves_for(heavy_bins);
         ws.heavy_bound = exact ? (long)heavy_bins : (long)(heavy_bins + heavy_bins / 4 + 16);
         ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
-        jr::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
+        if (ctx->precise_colour) jr_precise::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
+        else jr::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
     };
     const bool spec_lists = ws.pool != nullptr && ws.pool_cap > 0;
     const bool spec_raster = spec_lists && (!heavy_path || hist != nullptr);
@@ -874,6 +876,12 @@ int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size) {
     if (bin_size < 0 || bin_size > jr::MAX_IMAGE) return fail("jr_softras_set_bin_size: bin_size must be 0 (automatic) or a pixel count (got %d)", bin_size);
     // (no generation bump: a backward reuses the forward's records only when ITS resolved bin size is the one they were built with)
     ctx->bin_size_user = bin_size;
+    return 0;
+}
+
+int jr_softras_set_precise_colour(jr_ctx* ctx, int on) {
+    if (!ctx) return fail("NULL context");
+    ctx->precise_colour = on ? 1 : 0;
     return 0;
 }
 

@@ -30,7 +30,7 @@ struct BinWorkspace {
     int heavy_min = tune::fwd_heavy;
     long heavy_bound = -1;
     mutable int heavy_waves_used = 0;          // what the last forward launch really used (8 falls back to 4 when the LDS opt-in is refused)
-    mutable unsigned long long lds_optin_ok = 0, lds_optin_tried = 0;   // per (dist, rgb, K class) instantiation of the 8-wavefront kernel: > 64 KB of dynamic LDS granted on this device
+    mutable unsigned long long lds_optin_ok[2] = {0, 0}, lds_optin_tried[2] = {0, 0};   // per (dist, rgb, K class) instantiation of the 8-wavefront kernel ([1]: the precise-colour set): > 64 KB of dynamic LDS granted on this device
 };
 
 // Launch order of the bins (k_bin_alloc_schedule): ~12 buckets per octave of the list length, heaviest first.  Bins in
@@ -57,6 +57,13 @@ void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& w
 void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* textures,
                             const BinWorkspace& ws, float* aggrs_info, float* soft_colors,
                             int32_t* faces_id_buffer);
+}  // namespace jr
+namespace jr_precise {   // the same kernels with the colour path in the reference's own arithmetic (softras_forward_precise.hip)
+void launch_softras_forward(hipStream_t st, const jr::RasterParams& p, const float* textures,
+                            const jr::BinWorkspace& ws, float* aggrs_info, float* soft_colors,
+                            int32_t* faces_id_buffer);
+}
+namespace jr {
 bool forward_uses_heavy_path(const RasterParams& p, const BinWorkspace& ws);   // launches of up to tune::fwd_heavy_pixels pixels: four wavefronts per tile of a heavy bin
 bool backward_splits_heavy_tiles(const RasterParams& p, const BinWorkspace& ws);   // launches of up to tune::bwd_split_pixels pixels: tune::bwd_split wavefronts per tile of a heavy bin, each with the face ids of one residue class
 void launch_softras_backward(hipStream_t st, const RasterParams& p, const float* textures,

@@ -90,6 +90,18 @@
 #ifndef JR_TUNE_FWD_PIPE_CONSUMER_TASKS   // pipelined heavy tile: which applying wavefronts also take evaluate / mask tasks once their apply is done (bit 0: the K-buffer wavefront, bit 1: the colour wavefront)
 #define JR_TUNE_FWD_PIPE_CONSUMER_TASKS 3
 #endif
+#ifndef JR_TUNE_FWD_MIXED8_LDS_PAD  // diagnostics: bytes of dynamic LDS added to the eight-wavefront workgroup (16384: one workgroup per CU instead of two)
+#define JR_TUNE_FWD_MIXED8_LDS_PAD 0
+#endif
+#ifndef JR_TUNE_FWD_PIPE_K4        // eight-wavefront pipeline: the K-buffer of a pixel spread over the four lanes of a quad, four wavefronts own 16 pixels each (0: one wavefront, 64 pixels, KCAP registers per lane)
+#define JR_TUNE_FWD_PIPE_K4 0
+#endif
+#ifndef JR_TUNE_FWD_PIPE_COLOUR_SW   // pipelined heavy tile: the colour wavefront's loop software-pipelined (front of cell k + 1 - running maximum, exponential - before the sums of cell k)
+#define JR_TUNE_FWD_PIPE_COLOUR_SW 0
+#endif
+#ifndef JR_TUNE_FWD_PIPE_IDLE_MASK   // pipelined heavy tile: wavefronts (bit = index, >= 2) that take NO evaluate / mask tasks: e.g. 0x30 leaves the K-buffer and the colour wavefront's SIMDs to them (wavefront i runs on SIMD i % 4)
+#define JR_TUNE_FWD_PIPE_IDLE_MASK 0
+#endif
 #ifndef JR_TUNE_FWD_PIPE_PRIO     // pipelined heavy tile: s_setprio 3 for the two applying wavefronts while they apply (the per-pixel sequential chain is the tile's critical path)
 #define JR_TUNE_FWD_PIPE_PRIO 0
 #endif
@@ -98,7 +110,7 @@
 #endif
 #ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert;
                                  // backward: bit 2 no three-projection path, bit 3 no n-th-holder search, bit 4 no row reduction, bit 5 no atomics, bit 7 atomics as plain stores, bit 8 no gathers;
-                                 // multi-wavefront forward: bit 9 heavy tiles only, bit 10 light tiles only
+                                 // multi-wavefront forward: bit 9 heavy tiles only, bit 10 light tiles only, bit 13 cells without the evaluate arithmetic
 #define JR_TUNE_DIAG 0
 #endif
 #ifndef JR_TUNE_BWD_ROW_RANGES   // backward: a row takes a contiguous quarter of the work items and adds up consecutive items of one face before its atomic
@@ -132,6 +144,12 @@
 #ifndef JR_TUNE_BWD_SPLIT_PIXELS
 #define JR_TUNE_BWD_SPLIT_PIXELS 1572864
 #endif
+#ifndef JR_TUNE_BWD_TEX_LDS_MAX   // backward, 'surface' textures: faces of up to this many texels get their texture block staged in LDS with the record (0: never)
+#define JR_TUNE_BWD_TEX_LDS_MAX 36
+#endif
+#ifndef JR_TUNE_BWD_TEX_LDS_PIXELS // ... in launches of up to this many pixels (the staging costs LDS: 40 x T x 12 B per wavefront)
+#define JR_TUNE_BWD_TEX_LDS_PIXELS 4194304
+#endif
 #ifndef JR_TUNE_BWD_WAVES         // backward: wavefronts per SIMD asked of the register allocator at K <= 16 (5 -> 96 VGPRs, still 32 B of scratch;
                                   // 6 and 7 spill 64-112 B and are 1.5-2.2x slower: profiles/r02_ablation_sweep.log)
 #define JR_TUNE_BWD_WAVES 5
@@ -161,6 +179,9 @@
 #define JR_TUNE_PROFILE_SECTIONS 0
 #endif
 
+#ifndef JR_TUNE_COUNT_PATHS       // instrumented build: trips and lanes per region of the forward's raster loop (tools/sim/min_valu.py --measure)
+#define JR_TUNE_COUNT_PATHS 0
+#endif
 #ifndef JR_TUNE_SECTIONS_WAVE     // instrumented build 2: which wavefront of the pipelined heavy tile's workgroup keeps the section clocks (0 K-buffer, 1 colour, 2 tasks, 3 stager)
 #define JR_TUNE_SECTIONS_WAVE 0
 #endif
@@ -169,6 +190,7 @@ namespace jr {
 namespace tune {
 constexpr int sections_wave = JR_TUNE_SECTIONS_WAVE;
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
+constexpr bool count_paths = JR_TUNE_COUNT_PATHS != 0;
 constexpr bool n3_pixmap_all = JR_TUNE_N3_PIXMAP_ALL != 0;
 constexpr int n3_xcd_group = JR_TUNE_N3_XCD_GROUP;
 constexpr int n3_walks = JR_TUNE_N3_WALKS;
@@ -187,6 +209,10 @@ constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;
 constexpr bool fwd_heavy_pipe = JR_TUNE_FWD_HEAVY_PIPE != 0;
 constexpr int fwd_pipe_consumer_tasks = JR_TUNE_FWD_PIPE_CONSUMER_TASKS;
 constexpr bool fwd_pipe_prio = JR_TUNE_FWD_PIPE_PRIO != 0;
+constexpr bool fwd_pipe_colour_sw = JR_TUNE_FWD_PIPE_COLOUR_SW != 0;
+constexpr bool fwd_pipe_k4 = JR_TUNE_FWD_PIPE_K4 != 0;
+constexpr int fwd_mixed8_lds_pad = JR_TUNE_FWD_MIXED8_LDS_PAD;
+constexpr int fwd_pipe_idle_mask = JR_TUNE_FWD_PIPE_IDLE_MASK;
 constexpr int fwd_heavy_waves = JR_TUNE_FWD_HEAVY_WAVES;
 constexpr int fwd_pipe8_cap = JR_TUNE_FWD_PIPE8_CAP, fwd_pipe8_batch = JR_TUNE_FWD_PIPE8_BATCH;
 constexpr int fwd_pipe_list_depth = JR_TUNE_FWD_PIPE_LIST_DEPTH;
@@ -194,6 +220,8 @@ constexpr int fwd_list_depth = JR_TUNE_FWD_LIST_DEPTH;
 constexpr long fwd_heavy_waves8_budget = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET;
 static_assert(fwd_heavy_waves == 4 || fwd_heavy_waves == 8, "JR_TUNE_FWD_HEAVY_WAVES");
 constexpr int bwd_split = JR_TUNE_BWD_SPLIT;
+constexpr int bwd_tex_lds_max = JR_TUNE_BWD_TEX_LDS_MAX;
+constexpr long bwd_tex_lds_pixels = JR_TUNE_BWD_TEX_LDS_PIXELS;
 constexpr bool bwd_one_atomic = JR_TUNE_BWD_ONE_ATOMIC != 0;
 constexpr long bwd_split_pixels = JR_TUNE_BWD_SPLIT_PIXELS;
 constexpr int fwd_waves32 = JR_TUNE_FWD_WAVES32;

@@ -880,10 +880,21 @@ void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textur
 }
 
 // scan lines per launch of the line-walk kernel (two orientations per image); the LDS copy of a line is 20 B per pixel
-static bool n3_use_line_walks(int IS) { return tune::n3_line_walks && (size_t)IS * 20 <= 65536 && IS < (1 << 13); }
+// The crossing lists are sized for the worst case - 1 024 records of 36 B per scan line and orientation: 72 KB per image row,
+// i.e. 19 MB for one 256^2 image, 75 MB for one at 1024^2, 600 MB for a batch of eight of those - and stay in the context's
+// scratch until jr_ctx_trim (the per-face walks needed 44 B per pixel).  Above N3_LINE_LIST_BUDGET the backward keeps the
+// per-face walks instead of growing the arena silently: the regrouping is a latency / L2 optimisation of launches
+// that size, a batch of 64 images has enough faces in flight without it.
+constexpr size_t N3_LINE_LIST_BUDGET = (size_t)1 << 30;
+static size_t n3_line_list_bytes(int B, int IS) {
+    return (size_t)B * 2 * IS * N3_LINE_PARTS * (sizeof(int) + sizeof(N3Crossing) * N3_LINE_CAP) + 64;
+}
+static bool n3_use_line_walks(int B, int IS) {
+    return tune::n3_line_walks && (size_t)IS * 20 <= 65536 && IS < (1 << 13) && n3_line_list_bytes(B, IS) <= N3_LINE_LIST_BUDGET;
+}
 size_t n3mr_backward_scratch_bytes(int B, int IS) {
     size_t bytes = (size_t)B * IS * IS * (2 * 16 + 2 * 4 + 2 * 4);
-    if (n3_use_line_walks(IS)) bytes += (size_t)B * 2 * IS * N3_LINE_PARTS * (sizeof(int) + sizeof(N3Crossing) * N3_LINE_CAP) + 64;
+    if (n3_use_line_walks(B, IS)) bytes += n3_line_list_bytes(B, IS);
     return bytes;
 }
 
@@ -906,7 +917,7 @@ void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* fac
         int32_t* fidx_r = reinterpret_cast<int32_t*>(gb_t + P);
         int32_t* fidx_t = fidx_r + P;
         const int ptiles = (IS + N3_PACK_TILE - 1) / N3_PACK_TILE;
-        const bool line_walks = tune::n3_pixmap_all && n3_use_line_walks(IS);
+        const bool line_walks = tune::n3_pixmap_all && n3_use_line_walks(B, IS);
         const int nlines = B * 2 * IS * N3_LINE_PARTS;            // sub-lists of the scan lines
         int* line_count = reinterpret_cast<int*>(fidx_t + P);
         N3Crossing* line_rec = reinterpret_cast<N3Crossing*>(line_count + ((nlines + 15) & ~15));     // (N3Crossing is 4-byte aligned)

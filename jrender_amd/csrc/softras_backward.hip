@@ -127,7 +127,7 @@ __device__ inline float gdiv(float x, float c, float rc, const RasterParams& p) 
 // (the softmax weight exp((zn - smax)/gamma) is extremely sensitive to zn).  Everything that only
 // feeds gradients uses reciprocal multiplies: float atomics already make the sums order dependent.
 template <int DIST, int RGB, bool FAST>
-__device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
+__device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, const float* vc, const float* tex_block,
                                     const PixelGrad& px, float xp, float yp,
                                     const float* __restrict__ tbase, float (&gv)[9], float (&wcw)[3],
                                     float& tgs, bool& tex_on, unsigned long long* __restrict__ counters) {
@@ -166,7 +166,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
         if (p.tex == 0) {
             if (p.T == 1) { k0 = r.col[0]; k1 = r.col[1]; k2 = r.col[2]; }
             else {
-                const float* tx_ = tbase + ((size_t)fn * p.T + texel) * 3;
+                const float* tx_ = (tex_block ? tex_block : tbase + (size_t)fn * p.T * 3) + texel * 3;      // (the staged LDS copy of the face's texels, or global)
                 k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
             }
         } else {                                                           // SRK:1147-1149 (affine)
@@ -216,8 +216,8 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     return texel;
 }
 
-template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ? JR_TUNE_BWD_WAVES : (KCAP <= 32 ? 4 : JR_TUNE_BWD_WAVES64)))) void k_softras_backward(
+template <int DIST, int RGB, int KCAP, bool TEXLDS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TEXLDS ? (KCAP <= 32 ? 4 : 3) : (KCAP <= 16 ? JR_TUNE_BWD_WAVES : (KCAP <= 32 ? 4 : JR_TUNE_BWD_WAVES64))))) void k_softras_backward(
     RasterParams p, int nbins, int heavy_cap, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
@@ -228,6 +228,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
     constexpr int BATCH = tune::bwd_batch;
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
     float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
+    // TEXLDS (round 5; its own instantiations: as a run-time flag it cost the default kernels 32 B of scratch and + 50 % time; 'surface' textures with 1 < T <= BWD_TEX_LDS_MAX texels, small launches): the batch's texture blocks
+    // are staged next to the records.  A pair of a T > 1 face reads its texel colour - k0..k2 of SRK:1315 - from global
+    // memory IN THE MIDDLE of its arithmetic, and on gfx950 that load's s_waitcnt also waits for every atomic issued
+    // before it (one VMEM counter, in order): each trip paid the round trip of the previous trip's texel atomics.  BASELINE
+    // configs[1] (spot cow, 25 texels per face, 1024^2, one view): backward 0.28 ms, 4 x the 3 300-face sphere's at T = 1.
+    float* s_tex = s_vcol;                                                     // [BATCH][T*3] iff TEXLDS (never together with vertex colours)
     __shared__ unsigned long long s_has[BATCH];     // slot -> pixels (lanes) that hold the face
     __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
 
@@ -351,6 +357,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 for (int k = 0; k < 9; k++) s_vcol[lane * 9 + k] = tx_[k];
             }
         }
+        if (TEXLDS) {            // 16 lanes per slot, four slots per pass: contiguous T*3 floats per face
+            const int t3 = p.T * 3, sub = lane >> 4, l16 = lane & 15;
+            for (int s0 = 0; s0 < fill; s0 += 4) {
+                const int slot = s0 + sub;
+                const int id = __builtin_amdgcn_ds_bpermute((slot < fill ? slot : 0) << 2, myid);    // slot's face id lives in lane `slot`
+                if (slot < fill) {
+                    const float* src = tbase + (size_t)id * t3;
+                    float* dst = s_tex + slot * t3;
+                    for (int k = l16; k < t3; k += 16) dst[k] = src[k];
+                }
+            }
+        }
 
         // ---- work items: (face slot, group of <= 16 of the pixels that hold it) ----
         const int items = (__builtin_popcountll(has) + G - 1) >> GSH;
@@ -443,9 +461,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KCAP <= 16 ?
                 float tgs;
                 bool tex_on;
                 const float* vc = s_vcol + jc * 9;
+                const float* tb = TEXLDS ? s_tex + jc * (p.T * 3) : nullptr;
                 const int texel = (face_safe(fr.meta) && p.consts_safe)
-                    ? backward_pair<DIST, RGB, true>(p, fr, vc, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters)
-                    : backward_pair<DIST, RGB, false>(p, fr, vc, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters);
+                    ? backward_pair<DIST, RGB, true>(p, fr, vc, tb, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters)
+                    : backward_pair<DIST, RGB, false>(p, fr, vc, tb, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters);
                 if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: straight to global
                     float* gtf = gtbase + (size_t)face_id(fr.meta) * p.T * 3;
                     const float c0 = tgs * q.g0, c1 = tgs * q.g1, c2 = tgs * q.g2;
@@ -521,14 +540,22 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
     // heavy bins' tiles by tune::bwd_split wavefronts each when the launch is too small to fill the GPU anyway
     const int heavy_cap = backward_splits_heavy_tiles(p, ws) ? heavy_bins_cap(ws, nbins) : 0;   // (bound of counters[3], as in the forward)
     const int grid = (8 << tl) * (tune::bwd_split * ((heavy_cap + 7) / 8) + (nbins + 7) / 8);   // whole bins per XCD slot
-    const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0);
-#define JR_BWD_K(KC) \
-    k_softras_backward<DIST, RGB, KC><<<grid, 64, smem, st>>>( \
+    // texture blocks in LDS: 'surface' textures of a few texels in launches that are latency-, not occupancy-bound
+    const int tex_lds = (p.tex == 0 && p.T > 1 && p.T <= tune::bwd_tex_lds_max && RGB == 1 &&
+                         (long)p.B * p.IS * p.IS <= (long)tune::bwd_tex_lds_pixels) ? 1 : 0;
+    const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0) +
+                        (tex_lds ? sizeof(float) * 3 * p.T * tune::bwd_batch : 0);
+#define JR_BWD_K(KC, TL) \
+    k_softras_backward<DIST, RGB, KC, TL><<<grid, 64, smem, st>>>( \
         p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba, \
         grad_faces, grad_textures, ws.counters)
-    if (p.K <= 16) JR_BWD_K(16);
-    else if (p.K <= 32) JR_BWD_K(32);
-    else JR_BWD_K(64);
+    if (RGB == 1 && tex_lds) {           // (the staged-texture instantiations exist for the softmax colour path only: nothing else reads texels)
+        if (p.K <= 16) JR_BWD_K(16, (RGB == 1));
+        else if (p.K <= 32) JR_BWD_K(32, (RGB == 1));
+        else JR_BWD_K(64, (RGB == 1));
+    } else if (p.K <= 16) JR_BWD_K(16, false);
+    else if (p.K <= 32) JR_BWD_K(32, false);
+    else JR_BWD_K(64, false);
 #undef JR_BWD_K
 }
 

@@ -32,7 +32,17 @@
 #include <type_traits>
 #include "jr_kernels.h"
 
-namespace jr {
+// This file is compiled TWICE (round 5): as it is -> namespace jr, the product's forward; and through
+// softras_forward_precise.hip with JR_TUNE_FWD_EXACT = 3 -> namespace jr_precise, the same kernels with the colour path in
+// the reference's own arithmetic (libm expf, IEEE quotients, the double-precision sigmoid: SRK:344, :401-411) for callers
+// that need the saved colours - and through them the gradients - within 1e-4 ELEMENT-WISE of the reference
+// (jr_softras_set_precise_colour; +15 % forward time).  Every name of this file lives in that namespace, so
+// the two sets of kernels are distinct symbols.
+#ifndef JR_FWD_NAMESPACE
+#define JR_FWD_NAMESPACE jr
+#endif
+namespace JR_FWD_NAMESPACE {
+using namespace jr;
 
 // The K-buffer's face indices never feed a decision, so they do not live in registers: every insert stores the face
 // index straight into its slot plane of faces_id_buffer (the output), the slots that were never filled get their -1
@@ -141,6 +151,78 @@ struct KBuffer {
     }
 };
 
+// ---- the K-buffer of ONE pixel spread over the FOUR lanes of a quad (eight-wavefront pipeline of a heavy tile; built in round 4,
+// in the product since round 5 together with the lighter colour chain) ----
+// In tile_heavy_pipe the K-buffer wavefront walks the cells of its 64 pixels in lockstep, and a trip in which ANY pixel replaces
+// costs the whole replace + rescan (~100 VALU instructions; 305 of the heaviest tile's 421 trips).  Here a wavefront owns 16
+// pixels, lane = (pixel, quarter), and each lane keeps KCAP / 4 depth slots (slot s lives in lane quarter s / R, register
+// s % R): the write touches R registers instead of KCAP, the rescan is a local maximum plus two quad_perm exchanges of
+// (depth, slot) - first maximum wins, i.e. the larger depth, on a tie the lower slot, exactly the reference's strict '>' scan
+// from -1 (SRK:379-385) - and four such wavefronts share the tile's pixels.  The four lanes of a quad read the same cell and
+// hold the same size / max_z / max_slot: they never diverge from each other.
+template <int KCAP>
+struct KBuffer4 {
+    static constexpr int R = KCAP / 4;
+    float z[R];
+    int32_t* gplane;
+    unsigned goff, gstride;
+    int size, max_slot, quarter;
+    float max_z;
+    __device__ inline void init(int32_t* plane0, unsigned pixel, unsigned stride, int quarter_) {
+        gplane = plane0; goff = pixel; gstride = stride; quarter = quarter_;
+#pragma unroll
+        for (int i = 0; i < R; i++) z[i] = -__builtin_inff();      // never the maximum, never equal to one
+        size = 0; max_z = -1.f; max_slot = -1;
+    }
+    template <int CTRL>
+    __device__ static inline float xf(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false)); }
+    template <int CTRL>
+    __device__ static inline int xi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+    __device__ inline void rescan() {
+        float m = z[0];
+#pragma unroll
+        for (int i = 1; i < R; i++) m = fmaxf(m, z[i]);                     // (NaN depths are skipped, like the reference's compare)
+        int li = 0;
+#pragma unroll
+        for (int i = R - 1; i >= 0; i--) li = z[i] == m ? i : li;           // first register that holds it
+        int sl = quarter * R + li;
+        if (!(m > -1.f)) { m = -1.f; sl = 0x7fffffff; }                     // nothing above the scan's start value here
+        {   const float m2 = xf<0xB1>(m); const int s2 = xi<0xB1>(sl);      // quad_perm [1,0,3,2]
+            const bool take = m2 > m || (m2 == m && s2 < sl);
+            m = take ? m2 : m; sl = take ? s2 : sl; }
+        {   const float m2 = xf<0x4E>(m); const int s2 = xi<0x4E>(sl);      // quad_perm [2,3,0,1]
+            const bool take = m2 > m || (m2 == m && s2 < sl);
+            m = take ? m2 : m; sl = take ? s2 : sl; }
+        max_z = m;
+        if (m > -1.f) max_slot = sl;                                        // else: the slot variable stays where it was (SRK:379-385)
+    }
+    __device__ inline void insert(int fn, float zp, int K) {
+        const bool filling = size < K;
+        if (!filling && !(zp < max_z)) return;
+        const int slot = filling ? size : max_slot;
+        if (slot < 0) return;                                               // (the reference indexes slot -1 here: undefined behaviour)
+        if (quarter == (int)((unsigned)slot / (unsigned)R)) {
+            const int r = (int)((unsigned)slot % (unsigned)R);
+#pragma unroll
+            for (int i = 0; i < R; i++) z[i] = i == r ? zp : z[i];
+            gplane[(unsigned)slot * gstride + goff] = fn;
+        }
+        if (filling) {
+            if (zp > max_z) { max_z = zp; max_slot = size; }
+            size++;
+        } else rescan();
+    }
+    // the slots that were never filled get their -1 (the filled ones were stored when they were filled)
+    __device__ inline void store_rest(int K, bool valid) const {
+        if (!valid) return;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int slot = quarter * R + i;
+            if (slot < K && slot >= size) gplane[(unsigned)slot * gstride + goff] = -1;
+        }
+    }
+};
+
 template <int KCAP>
 struct PixelState {                 // SRK:291-309
     float c0, c1, c2, alpha, ssum, smax, depth_min;
@@ -226,16 +308,57 @@ __device__ inline void alpha_accumulate(const RasterParams& p, float neg_num, fl
     }
 }
 
+// Instrumented build JR_TUNE_COUNT_PATHS (tools/sim/min_valu.py --measure): how many TRIPS of the raster loop execute each
+// region of forward_pair and how many LANES need it, per launch - the dynamic half of the VALU model.  Regions: 0 every pair,
+// 1 inside (two extra edge projections), 2 live (passed the distance cull), 3 K-buffer insert, 4 append, 5 replace + rescan,
+// 6 softmax update, 7 the SLOW (non-FAST face) copy of the loop.  Dead code in every other build.
+struct PathCount {
+    unsigned t[8], l[8], batches, chunks;
+    __device__ inline void clear() {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { t[i] = 0; l[i] = 0; }
+        batches = 0; chunks = 0;
+    }
+    __device__ inline void hit(int i) {          // called by every lane that executes region i in this trip
+        if (!tune::count_paths) return;
+        const unsigned long long m = ballot(true);
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        l[i] += 1;
+        if (lane == (int)__builtin_ctzll(m)) t[i] += 1;
+    }
+    __device__ inline void flush(unsigned long long* counters, int lane) {     // all lanes
+        if (!tune::count_paths) return;
+        auto wsum = [](unsigned v) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+            return v;
+        };
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const unsigned a = wsum(t[i]), b = wsum(l[i]);
+            if (lane == 0) { atomicAdd(counters + 4 + 2 * i, (unsigned long long)a); atomicAdd(counters + 5 + 2 * i, (unsigned long long)b); }
+        }
+        const unsigned a = wsum(t[7]), b = wsum(l[7]);
+        if (lane == 0) {
+            atomicAdd(counters + 18, (unsigned long long)batches); atomicAdd(counters + 19, (unsigned long long)chunks);
+            atomicAdd(counters + 20, 1ull); atomicAdd(counters + 21, (unsigned long long)a); atomicAdd(counters + 22, (unsigned long long)b);
+        }
+    }
+};
+
 // One (pixel, face) pair of the raster loop (SRK:316-419).  (Handling the pairs whose pixel lies strictly inside the face -
 // three edge projections instead of one, 8 % of the pairs but present in nearly every trip - in a second loop per batch
 // was built and measured: VALU instructions -6.7 %, time +2.6 %; tools/ablate/patches/dead_switches_r04.patch.)
 template <int DIST, int RGB, bool FAST, int KCAP>
 __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, const float* vc,
                                     const float* __restrict__ tbase, float xp, float yp,
-                                    PixelState<KCAP>& s) {
+                                    PixelState<KCAP>& s, PathCount& pc) {
     const Bary w = barycentric(r, xp, yp);
     const int meta = r.meta;
     float D = 1.f, neg_num = -1.f;
+    pc.hit(0);
+    if (tune::count_paths && !FAST) pc.hit(7);
+    if (tune::count_paths && DIST >= 2 && strictly_inside_t<FAST>(w)) pc.hit(1);
     if (DIST == 0) {                                                           // SRK:331-333
         if (!pixel_inside(w)) return;
     } else if (DIST == 1) {                                                    // SRK:335-338
@@ -256,13 +379,17 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
         D = coverage_fast<tune::fwd_exact>(neg_num, p);
     }
     // alpha aggregation happens before the depth cull (SRK:350-358)
+    pc.hit(2);
     alpha_accumulate<DIST, FAST>(p, neg_num, D, s);
 
     const Bary wc = barycentric_clip<FAST>(w);
     const float zp = depth_of<FAST>(r, wc);
     if (zp < p.near_ || zp > p.far_) return;                                  // SRK:365
     const int fn = face_id(meta);
-    s.q.insert(fn, zp, p.K);
+    if (tune::count_paths) {
+        const bool was_filling = s.q.size < p.K;
+        if (s.q.insert(fn, zp, p.K) >= 0) { pc.hit(3); if (was_filling) pc.hit(4); else pc.hit(5); }
+    } else s.q.insert(fn, zp, p.K);
 
     if (RGB == 0) {                                                            // SRK:390-397
         if (zp < s.depth_min && pixel_inside(w) && (p.double_side || face_front(meta))) {
@@ -270,7 +397,7 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
             sample_colour<FAST>(p, r, vc, tbase, wc, zp, s.c0, s.c1, s.c2);
         }
     } else if (RGB == 1) {                                                     // SRK:399-419
-        if (face_front(meta) || p.double_side) softmax_accumulate<FAST>(p, r, vc, tbase, wc, zp, D, s);
+        if (face_front(meta) || p.double_side) { pc.hit(6); softmax_accumulate<FAST>(p, r, vc, tbase, wc, zp, D, s); }
     }
 }
 
@@ -370,9 +497,9 @@ __device__ inline void store_colour(const RasterParams& p, const TileGeom& t, co
 // own wavefronts would have stored (final_colour of the untouched state), 88 wide stores instead of 16 x 22 narrow ones
 // for a 32x32 bin.  Only when image rows are 16-byte aligned and bins are whole (IS % bin == 0); other sizes take the
 // per-tile path.
-template <int RGB, int KCAP>
-__device__ inline void store_empty_bin(const RasterParams& p, int bin, int lane,
-                                       float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+template <int RGB, int KCAP, int BL>          // BL = log2 of the bin size: compile-time trip counts (as run-time loops the headline forward - 60 % empty bins - lost 5 %)
+__device__ inline void store_empty_bin_t(const RasterParams& p, int bin, int lane,
+                                         float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
     const int bins_per_img = p.bins_x * p.bins_y;
     const int b = bin / bins_per_img, bb = bin - b * bins_per_img;
     const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
@@ -382,22 +509,31 @@ __device__ inline void store_empty_bin(const RasterParams& p, int bin, int lane,
     final_colour<RGB>(p, s, o);
     const size_t pp = (size_t)p.IS * p.IS;
     // a bin row is (bin / 4) lanes x 16 B (32-pixel bins: 8 lanes = one 128-byte row); the wavefront covers 64 / that many rows per pass
-    const int lsh = p.bin_log2 - 2, binp = 1 << p.bin_log2;
-    const int lrow = lane >> lsh, rows_pp = 64 >> lsh;
-    const size_t base = ((size_t)((by << p.bin_log2) + lrow)) * p.IS + (bx << p.bin_log2) + (lane & ((1 << lsh) - 1)) * 4;
-    const size_t rstep = (size_t)rows_pp * p.IS;
-    const int passes = lrow < binp ? (binp - lrow + rows_pp - 1) / rows_pp : 0;     // 32: 4, 16: 1, 8: 1 (lanes beyond the bin's 8 rows idle)
+    constexpr int LSH = BL - 2, BINP = 1 << BL, ROWS_PP = 64 >> LSH, PASSES = BINP >= ROWS_PP ? BINP / ROWS_PP : 1;   // 32: 4 passes, 16: 1, 8: 1 (lanes beyond the bin's 8 rows idle)
+    const int lrow = lane >> LSH;
+    if (lrow >= BINP) return;
+    const size_t base = ((size_t)((by << BL) + lrow)) * p.IS + (bx << BL) + (lane & ((1 << LSH) - 1)) * 4;
+    const size_t rstep = (size_t)ROWS_PP * p.IS;
 #pragma unroll
     for (int c = 0; c < 6; c++) {
         float* pl = (c < 4 ? rgba + ((size_t)b * 4 + c) * pp : aggrs + ((size_t)b * 2 + (c - 4)) * pp) + base;
         const float4 v = make_float4(o[c], o[c], o[c], o[c]);
-        for (int i = 0; i < passes; i++) *reinterpret_cast<float4*>(pl + i * rstep) = v;
+#pragma unroll
+        for (int i = 0; i < PASSES; i++) *reinterpret_cast<float4*>(pl + i * rstep) = v;
     }
     const int4 m1 = make_int4(-1, -1, -1, -1);
     for (int k = 0; k < p.K; k++) {
         int32_t* pl = ids + ((size_t)b * p.K + k) * pp + base;
-        for (int i = 0; i < passes; i++) *reinterpret_cast<int4*>(pl + i * rstep) = m1;
+#pragma unroll
+        for (int i = 0; i < PASSES; i++) *reinterpret_cast<int4*>(pl + i * rstep) = m1;
     }
+}
+template <int RGB, int KCAP>
+__device__ inline void store_empty_bin(const RasterParams& p, int bin, int lane,
+                                       float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
+    if (p.bin_log2 == 5) store_empty_bin_t<RGB, KCAP, 5>(p, bin, lane, aggrs, rgba, ids);
+    else if (p.bin_log2 == 4) store_empty_bin_t<RGB, KCAP, 4>(p, bin, lane, aggrs, rgba, ids);
+    else store_empty_bin_t<RGB, KCAP, 3>(p, bin, lane, aggrs, rgba, ids);
 }
 template <int KCAP, bool WRITTEN_THROUGH, class KB>
 __device__ inline void store_ids(const RasterParams& p, const TileGeom& t, const KB& q, int32_t* __restrict__ ids) {
@@ -645,10 +781,13 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
     const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
     ListWalker lw;
     lw.start(seg, geo + (size_t)t.b * p.NF, tbase, t.n, t.sub, lane);
+    PathCount pc;
+    pc.clear();
     clk.lap(0);
     for (;;) {
         const int fill = lw.stage<BATCH>(p, s_rec, s_vcol, lane);
         if (fill == 0) break;
+        if (tune::count_paths) pc.batches++;
         wave_sync<WAVE_IS_WG>();
         clk.lap(1);
         // ---- raster: lane = slot for the ballots, then lane = pixel ----
@@ -660,8 +799,8 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
             M &= M - 1;
             const FaceRec& r = s_rec[j];
             const float* vc = s_vcol + j * 9;
-            if (face_safe(r.meta) && p.consts_safe) forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s);
-            else forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s);
+            if (face_safe(r.meta) && p.consts_safe) forward_pair<DIST, RGB, true, KCAP>(p, r, vc, tbase, xp, yp, s, pc);
+            else forward_pair<DIST, RGB, false, KCAP>(p, r, vc, tbase, xp, yp, s, pc);
         }
         wave_sync<WAVE_IS_WG>();                // readers are done with s_rec before it is refilled
         clk.lap(3);
@@ -670,6 +809,7 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
     store_pixel<RGB>(p, t, s, aggrs, rgba, ids);
     clk.lap(4);
     if (JR_TUNE_PROFILE_SECTIONS == 1) clk.flush(counters, 4);
+    if (tune::count_paths) { pc.chunks = (unsigned)((t.n + CHUNK - 1) / CHUNK); pc.flush(counters, lane); }   // (the walk visits every chunk of the bin's list)
 }
 
 // =====================================================================================================================
@@ -697,20 +837,24 @@ __device__ inline void tile_single(const RasterParams& p, const TileGeom& t, int
 // dependent steps in the same order; only the commutative alpha / softmax sums of inside pairs are unaffected here
 // (they stay in face order).
 // =====================================================================================================================
-constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHARD = 256u, CELL_INCLOSED = 512u;
+constexpr unsigned CELL_SLOT = 63u, CELL_LIVE = 64u, CELL_DEPTH = 128u, CELL_AHARD = 256u, CELL_INCLOSED = 512u, CELL_FRONT = 1024u;
 constexpr int CELL_TEXEL_SHIFT = 12;
 constexpr int HEAVY_BATCH = tune::fwd_batch_mixed;                                              // record slots of a heavy tile = of each of the four tiles of a lighter workgroup
 constexpr int HEAVY_LDS_BYTES = 4 * (int)sizeof(FaceRec) * HEAVY_BATCH;                         // = what four single-wavefront tiles use
-constexpr int HEAVY_FIXED_BYTES = (int)sizeof(FaceRec) * HEAVY_BATCH + 64 * 8 + 64 * 8 + 64 + 2 * 64 * 8 + 2 * HEAVY_BATCH * 12;   // records, pixel centres, masks, scalars, per-pixel (first cell, cells) of two rounds, colours of two batches
+constexpr int HEAVY_FIXED_BYTES = (int)sizeof(FaceRec) * HEAVY_BATCH + 64 * 8 + 64 * 8 + 64 + 2 * 64 * 8 + 2 * HEAVY_BATCH * 16;   // records, pixel centres, masks, scalars, per-pixel (first cell, cells) of two rounds, colours + meta words of two batches
 constexpr int HEAVY_CAP = ((HEAVY_LDS_BYTES - HEAVY_FIXED_BYTES) / 20) & ~63;                   // 16 B cell + 2 B pair + 2 B inside entry per pair
 static_assert(HEAVY_CAP >= 256 && HEAVY_CAP <= 4096, "cell buffer of the heavy-tile path");
 
-// stateless arithmetic of one pair -> cell (zp, meta, D, aux); `deferred`: coverage still to come (inside pair)
+// stateless arithmetic of one pair -> cell (zp, zn, D, aux); `deferred`: coverage still to come (inside pair).
+// Round 5: the cell carries what the COLOUR wavefront's chain used to derive per cell - the normalised depth zn (five
+// dependent FMAs + the face's FAST test) and the facing test - computed here by lanes that run dense (64 pairs per trip); the
+// face's meta word left the cell (the K-buffer wavefront reads the id from the batch's meta table, off its critical path:
+// it only feeds the id store).
 template <int DIST, int RGB, bool FAST>
 __device__ inline float4 evaluate_pair(const RasterParams& p, const FaceRec& r, float xp, float yp, unsigned slot, bool& deferred) {
     const Bary w = barycentric(r, xp, yp);
     const int meta = r.meta;
-    float D = 1.f, neg_num = -1.f, zp = 0.f;
+    float D = 1.f, neg_num = -1.f, zp = 0.f, zn = 0.f;
     bool live;
     deferred = false;
     if (DIST == 0) live = pixel_inside(w);                                     // SRK:331-333
@@ -744,9 +888,12 @@ __device__ inline float4 evaluate_pair(const RasterParams& p, const FaceRec& r, 
             aux |= CELL_DEPTH;
             if (RGB == 0 && pixel_inside(w)) aux |= CELL_INCLOSED;
             if (RGB != 2 && p.T != 1) aux |= (unsigned)surface_texel(wc, p.R) << CELL_TEXEL_SHIFT;
+            if (face_front(meta) || p.double_side) aux |= CELL_FRONT;
+            // zn must carry the reference's exact bits (see softmax_accumulate): the softmax divides differences of it by gamma
+            if (RGB == 1) zn = div_known<FAST>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
         }
     } else deferred = false;
-    return make_float4(zp, __builtin_bit_cast(float, meta), D, __builtin_bit_cast(float, aux));
+    return make_float4(zp, zn, D, __builtin_bit_cast(float, aux));
 }
 
 // coverage of a deferred (inside) pair -> (D, aux) of its cell
@@ -764,39 +911,35 @@ __device__ inline float2 evaluate_inside(const RasterParams& p, const FaceRec& r
 
 // the K-buffer half of the state machine of one cell (lane = pixel, wavefront 0)
 template <class KB>
-__device__ inline void apply_kbuf(const RasterParams& p, const float4 cell, KB& q) {
+__device__ inline void apply_kbuf(const RasterParams& p, const float4 cell, const int* s_meta, KB& q) {
     const unsigned aux = __builtin_bit_cast(unsigned, cell.w);
     if ((aux & (CELL_LIVE | CELL_DEPTH)) != (CELL_LIVE | CELL_DEPTH)) return;
-    q.insert(face_id(__builtin_bit_cast(int, cell.y)), cell.x, p.K);
+    q.insert(face_id(s_meta[aux & CELL_SLOT]), cell.x, p.K);
 }
 
 // the colour half (lane = pixel, wavefront 1): alpha (SRK:350-358), hard rgb (SRK:390-397) or online softmax (SRK:399-419)
 template <int RGB, int KCAP>
-__device__ inline void apply_colour(const RasterParams& p, const float4 cell, const float* s_col,
+__device__ inline void apply_colour(const RasterParams& p, const float4 cell, const float* s_col, const int* s_meta,
                                     const float* __restrict__ tbase, PixelState<KCAP>& s) {
     const unsigned aux = __builtin_bit_cast(unsigned, cell.w);
     if (!(aux & CELL_LIVE)) return;
     const float zp = cell.x, D = cell.z;
-    const int meta = __builtin_bit_cast(int, cell.y);
     if (p.alpha == 0) { if (aux & CELL_AHARD) s.alpha = 1.f; }
     else if (p.alpha == 1) s.alpha += D;
     else s.alpha = __builtin_fmaf(-s.alpha, D, s.alpha);
-    if (RGB == 2 || !(aux & CELL_DEPTH)) return;
-    const bool facing = face_front(meta) || p.double_side;
-    if (RGB == 0) { if (!(zp < s.depth_min && (aux & CELL_INCLOSED) && facing)) return; }
-    else if (!facing) return;
-    const int fn = face_id(meta);
+    if (RGB == 2 || (aux & (CELL_DEPTH | CELL_FRONT)) != (CELL_DEPTH | CELL_FRONT)) return;    // (FRONT is only set together with DEPTH)
+    if (RGB == 0) { if (!(zp < s.depth_min && (aux & CELL_INCLOSED))) return; }
     float k0, k1, k2;
+    int fn = 0;
     if (p.T == 1) { const float* col = s_col + (aux & CELL_SLOT) * 3; k0 = col[0]; k1 = col[1]; k2 = col[2]; }
     else {
+        fn = face_id(s_meta[aux & CELL_SLOT]);
         const float* tx_ = tbase + ((size_t)fn * p.T + (aux >> CELL_TEXEL_SHIFT)) * 3;
         k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
     }
-    if (RGB == 0) { s.depth_min = zp; s.face_min = fn; s.c0 = k0; s.c1 = k1; s.c2 = k2; }
+    if (RGB == 0) { s.depth_min = zp; s.face_min = p.T == 1 ? face_id(s_meta[aux & CELL_SLOT]) : fn; s.c0 = k0; s.c1 = k1; s.c2 = k2; }
     else {
-        // zn must carry the reference's exact bits (see softmax_accumulate); FAST as in the evaluate pass
-        const float zn = (face_safe(meta) && p.consts_safe) ? div_known<true>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near)
-                                                            : div_known<false>(p.far_ - zp, p.far_minus_near, p.r_far_minus_near);
+        const float zn = cell.y;                 // evaluate_pair: the reference's exact bits
         const float x = zn - s.smax;
         const bool up = x > 0.f;
         const float e = exp_over_gamma<tune::fwd_exact>(-fabsf(x), p);
@@ -807,6 +950,57 @@ __device__ inline void apply_colour(const RasterParams& p, const float4 cell, co
         s.c0 = __builtin_fmaf(ed, s.c0, t * k0);
         s.c1 = __builtin_fmaf(ed, s.c1, t * k1);
         s.c2 = __builtin_fmaf(ed, s.c2, t * k2);
+    }
+}
+
+// The same colour half cut in two for a software-pipelined loop (tune::fwd_pipe_colour_sw, round 5).  The chain of a cell was
+// cell -> colour read -> x = zn - smax -> v_exp -> selects -> FMAs, every link waiting for the one before in a wavefront that
+// shares its SIMD with three others.  But the exponential only needs the RUNNING MAXIMUM before the cell - one v_max per cell -
+// not the sums: colour_front (flags, colour read, running maximum, exponential, the two selects) of cell k + 1 is issued
+// before colour_back (alpha, the five FMAs of the sums) of cell k, two independent instruction streams for the issue logic
+// to interleave.  Operation by operation the same arithmetic in the same per-pixel order as apply_colour: the same bits.
+struct ColourFront { float D, zp, ed, ez, k0, k1, k2; unsigned aux; int fn; bool use; };
+template <int RGB>
+__device__ inline ColourFront colour_front(const RasterParams& p, const float4 cell, const float* s_col, const int* s_meta,
+                                           const float* __restrict__ tbase, float& smax) {
+    ColourFront c;
+    c.aux = __builtin_bit_cast(unsigned, cell.w);
+    c.D = cell.z; c.zp = cell.x; c.ed = 1.f; c.ez = 1.f; c.k0 = 0.f; c.k1 = 0.f; c.k2 = 0.f; c.fn = 0;
+    c.use = RGB != 2 && (c.aux & (CELL_LIVE | CELL_DEPTH | CELL_FRONT)) == (CELL_LIVE | CELL_DEPTH | CELL_FRONT) &&
+            (RGB != 0 || (c.aux & CELL_INCLOSED));
+    if (c.use) {
+        if (p.T == 1) { const float* col = s_col + (c.aux & CELL_SLOT) * 3; c.k0 = col[0]; c.k1 = col[1]; c.k2 = col[2]; }
+        if (p.T != 1 || RGB == 0) c.fn = face_id(s_meta[c.aux & CELL_SLOT]);
+        if (p.T != 1) {
+            const float* tx_ = tbase + ((size_t)c.fn * p.T + (c.aux >> CELL_TEXEL_SHIFT)) * 3;
+            c.k0 = tx_[0]; c.k1 = tx_[1]; c.k2 = tx_[2];
+        }
+        if (RGB == 1) {
+            const float zn = cell.y;
+            const float x = zn - smax;
+            const bool up = x > 0.f;
+            const float e = exp_over_gamma<tune::fwd_exact>(-fabsf(x), p);
+            c.ed = up ? e : 1.f; c.ez = up ? 1.f : e;
+            smax = fmaxf(smax, zn);
+        }
+    }
+    return c;
+}
+template <int RGB, int KCAP>
+__device__ inline void colour_back(const RasterParams& p, const ColourFront& c, PixelState<KCAP>& s) {
+    if (!(c.aux & CELL_LIVE)) return;
+    if (p.alpha == 0) { if (c.aux & CELL_AHARD) s.alpha = 1.f; }
+    else if (p.alpha == 1) s.alpha += c.D;
+    else s.alpha = __builtin_fmaf(-s.alpha, c.D, s.alpha);
+    if (!c.use) return;
+    if (RGB == 0) {
+        if (c.zp < s.depth_min) { s.depth_min = c.zp; s.face_min = c.fn; s.c0 = c.k0; s.c1 = c.k1; s.c2 = c.k2; }
+    } else if (RGB == 1) {
+        const float t = c.ez * c.D;
+        s.ssum = __builtin_fmaf(c.ed, s.ssum, t);
+        s.c0 = __builtin_fmaf(c.ed, s.c0, t * c.k0);
+        s.c1 = __builtin_fmaf(c.ed, s.c1, t * c.k1);
+        s.c2 = __builtin_fmaf(c.ed, s.c2, t * c.k2);
     }
 }
 
@@ -829,7 +1023,8 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
     int* s_misc = reinterpret_cast<int*>(s_M + 64);                                            // [16] fill, total, j1, inside count
     int2* s_span = reinterpret_cast<int2*>(s_misc + 16);                                       // [2][64] a pixel's first cell, number of cells (by round parity)
     float* s_col = reinterpret_cast<float*>(s_span + 128);                                     // [2][BATCH][3] single-texel colours of the batch (by batch parity)
-    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_col + 2 * BATCH * 3);          // [CAP] slot | pixel << 6
+    int* s_meta = reinterpret_cast<int*>(s_col + 2 * BATCH * 3);                               // [2][BATCH] the faces' meta words (id, facing), by batch parity
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_meta + 2 * BATCH);             // [CAP] slot | pixel << 6
     unsigned short* s_in = s_pair + CAP;                                                       // [CAP] cells of inside pairs
     const float xp = t.xp, yp = t.yp;
     const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
@@ -850,6 +1045,7 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
         if (lane < f) {
             float* c = s_col + ((nb & 1) * BATCH + lane) * 3;
             c[0] = s_rec[lane].col[0]; c[1] = s_rec[lane].col[1]; c[2] = s_rec[lane].col[2];
+            s_meta[(nb & 1) * BATCH + lane] = s_rec[lane].meta;
         }
         if (lane == 0) s_misc[0] = f;
     };
@@ -960,14 +1156,15 @@ __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int 
             if (wid <= 1) {                                                    // ---- apply: lane = pixel, K-buffer | colour ----
                 const int2 span = s_span[(round & 1) * 64 + lane];
                 const float* colb = s_col + (nb & 1) * BATCH * 3;
+                const int* metab = s_meta + (nb & 1) * BATCH;
                 // (cells are read one ahead of their use; beyond the pixel's last cell: cell 0 with aux = 0, "not live")
                 float4 cur = s_cell[span.y > 0 ? span.x : 0];
                 if (!(span.y > 0)) cur.w = 0.f;
                 for (int k = 0; ballot(k < span.y) != 0ull; k++) {
                     float4 nxt = s_cell[k + 1 < span.y ? span.x + k + 1 : 0];
                     if (!(k + 1 < span.y)) nxt.w = 0.f;
-                    if (wid == 0) apply_kbuf(p, cur, s.q);
-                    else apply_colour<RGB, KCAP>(p, cur, colb, tbase, s);
+                    if (wid == 0) apply_kbuf(p, cur, metab, s.q);
+                    else apply_colour<RGB, KCAP>(p, cur, colb, metab, tbase, s);
                     cur = nxt;
                 }
                 if (wid == 0) clk.lap(6);
@@ -1011,10 +1208,14 @@ constexpr int pipe_batch(int nw) { return nw >= 8 ? tune::fwd_pipe8_batch : 40; 
 constexpr int pipe_cap(int nw) { return nw >= 8 ? tune::fwd_pipe8_cap : 512; }
 constexpr int pipe_lds_bytes(int nw) {
     return 2 * pipe_batch(nw) * (int)sizeof(FaceRec) + 2 * pipe_cap(nw) * 16 + 64 * 8 + 2 * 64 * 8 + 3 * 64 * 8
-           + 4 * pipe_batch(nw) * 12 + 64 * 4 + pipe_batch(nw) * 4 + 2 * pipe_cap(nw) * 2 + nw * PIPE_IN * 2;
+           + 4 * pipe_batch(nw) * 16 + 64 * 4 + pipe_batch(nw) * 4 + 2 * pipe_cap(nw) * 2 + nw * PIPE_IN * 2;
 }
-constexpr int mixed_lds_bytes(int nw) { return nw * (int)sizeof(FaceRec) * HEAVY_BATCH; }     // = what nw single-wavefront tiles use
-static_assert(pipe_lds_bytes(4) <= mixed_lds_bytes(4) && pipe_lds_bytes(8) <= mixed_lds_bytes(8), "the pipelined heavy tile must fit the workgroup's LDS");
+// dynamic LDS of a workgroup: what nw single-wavefront tiles use, or the pipelined heavy tile if that is (a few hundred bytes) more
+constexpr int mixed_lds_bytes(int nw) {
+    return (nw * (int)sizeof(FaceRec) * HEAVY_BATCH > pipe_lds_bytes(nw) ? nw * (int)sizeof(FaceRec) * HEAVY_BATCH : pipe_lds_bytes(nw))
+           + (nw >= 8 ? tune::fwd_mixed8_lds_pad : 0);       // (diagnostics: more LDS = ONE eight-wavefront workgroup per CU)
+}
+static_assert(4 * mixed_lds_bytes(4) <= 160 * 1024 && (tune::fwd_mixed8_lds_pad > 0 || 2 * mixed_lds_bytes(8) <= 160 * 1024), "four / two workgroups per CU");
 enum { PS_VALID = 0, PS_BATCH, PS_J0, PS_J1, PS_TOTAL, PS_LAST, PS_MASKS, PS_MBATCH, PS_MFILL, PS_CLAIM, PS_DONE, PS_WORDS = 16 };
 
 template <int DIST, int RGB, int KCAP, int NW>
@@ -1029,21 +1230,33 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
     unsigned long long* s_M = reinterpret_cast<unsigned long long*>(s_pix + 64);               // [2][64] face masks, by batch parity
     int2* s_span = reinterpret_cast<int2*>(s_M + 2 * 64);                                      // [3][64] first cell, cells of a pixel, by step % 3
     float* s_col = reinterpret_cast<float*>(s_span + 3 * 64);                                  // [4][BATCH][3] colours, by batch & 3
-    int* s_state = reinterpret_cast<int*>(s_col + 4 * BATCH * 3);                              // [2][PS_WORDS] by step parity
+    int* s_meta = reinterpret_cast<int*>(s_col + 4 * BATCH * 3);                               // [4][BATCH] meta words (id, facing), by batch & 3
+    int* s_state = s_meta + 4 * BATCH;                                                         // [2][PS_WORDS] by step parity
     int* s_slot = s_state + 64;                                                                // [BATCH] staging scratch
     unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_slot + BATCH);                 // [2][CAP] slot | pixel << 6, by step parity
     unsigned short* s_in = s_pair + 2 * CAP + wid * PIPE_IN;                                   // [PIPE_IN] this wavefront's inside pairs
     const float xp = t.xp, yp = t.yp;
     const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
     PixelState<KCAP> s;                                  // the K-buffer lives in wavefront 0, the colour state in wavefront 1
+    // tune::fwd_pipe_k4 (eight wavefronts): the K-buffer is spread over quads (KBuffer4) and FOUR wavefronts own 16 pixels each:
+    // wavefronts 0, 4, 5, 6 = pixel quarters 0 .. 3 (wavefront 1 colour, 3 stages / lists, 2 and 7 only take tasks)
+    constexpr bool K4 = NW == 8 && tune::fwd_pipe_k4;
+    const int kw = !K4 ? (wid == 0 ? 0 : -1) : (wid == 0 ? 0 : (wid >= 4 && wid <= 6 ? wid - 3 : -1));   // K-buffer owner index, -1: none
+    const int kpix = K4 ? 16 * max(kw, 0) + (lane >> 2) : lane;          // the pixel of the tile whose K-buffer this lane works on
+    KBuffer4<KCAP> q4;
+    bool kvalid = false;
     ListWalkerT<tune::fwd_pipe_list_depth> lw;   // wavefront 3 walks alone: several list chunks in flight
     SectionClock clk;            // instrumented builds only (wavefront tune::sections_wave): 0 barrier wait, 3 claimed tasks (wavefront 3: + staging / lists), 6 apply, 7 stores
     clk.start();
     if (wid == 1) init_colour_state<RGB>(p, s);
-    if (wid == 0) {
-        init_kbuffer(p, t, ids, s.q);
-        s_pix[lane] = make_float2(xp, yp);
-    }
+    if (wid == 0) s_pix[lane] = make_float2(xp, yp);
+    if (K4) {
+        if (kw >= 0) {
+            const int col = t.col - (lane & 7) + (kpix & 7), row = t.row - (lane >> 3) + (kpix >> 3);
+            kvalid = col < p.IS && row < p.IS;
+            q4.init(ids + (size_t)t.b * p.K * p.IS * p.IS, kvalid ? (unsigned)(row * p.IS + col) : 0u, (unsigned)(p.IS * p.IS), lane & 3);
+        }
+    } else if (wid == 0) init_kbuffer(p, t, ids, s.q);
     // ---- wavefront 3: staging and pair lists ----
     auto stage_batch = [&](int nb) -> int {
         FaceRec* rec = s_rec + (nb & 1) * BATCH;
@@ -1052,6 +1265,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
         if (lane < f) {
             float* c = s_col + ((nb & 3) * BATCH + lane) * 3;
             c[0] = rec[lane].col[0]; c[1] = rec[lane].col[1]; c[2] = rec[lane].col[2];
+            s_meta[(nb & 3) * BATCH + lane] = rec[lane].meta;
         }
         return f;
     };
@@ -1133,18 +1347,46 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
             if (st[PS_DONE] && !a_valid) break;
             if (wid == tune::sections_wave) clk.lap(0);
             // ---- apply round step-1: lane = pixel, K-buffer | colour ----
-            if (wid <= 1 && a_valid) {
-                if (tune::fwd_pipe_prio) __builtin_amdgcn_s_setprio(3);     // the tile's critical chain: win the SIMD's issue arbitration against the task wavefronts
+            if (wid == 1 && a_valid && tune::fwd_pipe_colour_sw) {
+                // colour wavefront, software-pipelined: the cell two ahead is in flight, the front of the cell one ahead is
+                // issued while the current one updates the sums
                 const int2 span = s_span[((step + 2) % 3) * 64 + lane];                        // (step - 1) % 3
                 const float4* cells = s_cell + ((step + 1) & 1) * CAP;
                 const float* colb = s_col + (a_batch & 3) * BATCH * 3;
+                const int* metab = s_meta + (a_batch & 3) * BATCH;
+                auto cell_at = [&](int k) {
+                    float4 c = cells[k < span.y ? span.x + k : 0];
+                    if (!(k < span.y)) c.w = 0.f;                                              // beyond the pixel's last cell: "not live"
+                    return c;
+                };
+                float smax = s.smax;
+                ColourFront cur = colour_front<RGB>(p, cell_at(0), colb, metab, tbase, smax);
+                float4 nxt = cell_at(1);
+                for (int k = 0; ballot(k < span.y) != 0ull; k++) {
+                    const float4 nn = cell_at(k + 2);
+                    const ColourFront nf = colour_front<RGB>(p, nxt, colb, metab, tbase, smax);
+                    colour_back<RGB, KCAP>(p, cur, s);
+                    cur = nf; nxt = nn;
+                }
+                s.smax = smax;
+                if (wid == tune::sections_wave) clk.lap(6);
+            } else if ((wid == 1 || kw >= 0) && a_valid) {
+                if (tune::fwd_pipe_prio) __builtin_amdgcn_s_setprio(3);     // the tile's critical chain: win the SIMD's issue arbitration against the task wavefronts
+                const int2 span = s_span[((step + 2) % 3) * 64 + (wid == 1 ? lane : kpix)];    // (step - 1) % 3
+                const float4* cells = s_cell + ((step + 1) & 1) * CAP;
+                const float* colb = s_col + (a_batch & 3) * BATCH * 3;
+                const int* metab = s_meta + (a_batch & 3) * BATCH;
                 float4 cur = cells[span.y > 0 ? span.x : 0];
                 if (!(span.y > 0)) cur.w = 0.f;
                 for (int k = 0; ballot(k < span.y) != 0ull; k++) {
                     float4 nxt = cells[k + 1 < span.y ? span.x + k + 1 : 0];
                     if (!(k + 1 < span.y)) nxt.w = 0.f;
-                    if (wid == 0) apply_kbuf(p, cur, s.q);
-                    else apply_colour<RGB, KCAP>(p, cur, colb, tbase, s);
+                    if (wid == 1) apply_colour<RGB, KCAP>(p, cur, colb, metab, tbase, s);
+                    else if (K4) {
+                        const unsigned aux = __builtin_bit_cast(unsigned, cur.w);
+                        if (kvalid && (aux & (CELL_LIVE | CELL_DEPTH)) == (CELL_LIVE | CELL_DEPTH))
+                            q4.insert(face_id(metab[aux & CELL_SLOT]), cur.x, p.K);
+                    } else apply_kbuf(p, cur, metab, s.q);
                     cur = nxt;
                 }
                 if (tune::fwd_pipe_prio) __builtin_amdgcn_s_setprio(0);
@@ -1177,7 +1419,9 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
             }
             // ---- claimable tasks: evaluate chunks of this step's round, mask tasks of a freshly staged batch ----
             // (tune::fwd_pipe_consumer_tasks: bit 0 / 1 = wavefront 0 / 1 joins after its apply)
-            if (wid >= 2 || ((tune::fwd_pipe_consumer_tasks >> wid) & 1)) {
+            // (K4: the wavefronts 4 .. 6 that own a quarter of the K-buffers join like wavefront 0, after their apply)
+            if ((wid >= 2 && !(K4 && kw > 0) && !((tune::fwd_pipe_idle_mask >> wid) & 1)) ||
+                ((tune::fwd_pipe_consumer_tasks >> (kw >= 0 ? 0 : wid)) & 1)) {
                 const int nchunks = e_valid ? (e_total + 63) >> 6 : 0;
                 const int ntasks = nchunks + (offer ? 4 : 0);
                 const FaceRec* recE = s_rec + (e_batch & 1) * BATCH;
@@ -1208,12 +1452,16 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                     bool deferred = false;
                     if (q < e_total) {
                         const unsigned pr = pl[q];
+                        if (JR_TUNE_DIAG & 8192) {       // (diagnostic bit 13, WRONG images: cells without the evaluate arithmetic and its record reads - what does the apply chain cost with the SIMDs and the LDS to itself?)
+                            cells[q] = make_float4(0.25f + 0.001f * (float)(q & 63), 0.5f, 0.3f, __builtin_bit_cast(float, (pr & 63u) | CELL_LIVE | CELL_DEPTH | CELL_FRONT));
+                        } else {
                         const FaceRec& r = recE[pr & 63u];
                         const float2 c = s_pix[pr >> 6];
                         float4 cell;
                         if (face_safe(r.meta) && p.consts_safe) cell = evaluate_pair<DIST, RGB, true>(p, r, c.x, c.y, pr & 63u, deferred);
                         else cell = evaluate_pair<DIST, RGB, false>(p, r, c.x, c.y, pr & 63u, deferred);
                         cells[q] = cell;
+                        }
                     }
                     if (DIST >= 2) {
                         const unsigned long long im = ballot(deferred);
@@ -1233,7 +1481,8 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
         }
     }
     if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
-    if (wid == 0) store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+    if (K4 && kw >= 0) q4.store_rest(p.K, kvalid);
+    if (wid == 0 && !K4) store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
     if (wid == tune::sections_wave) {
         clk.lap(7);
         if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2] && lane == 0) clk.flush0(counters, 4);   // the 16 tiles of the heaviest bin
@@ -1311,9 +1560,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fwd_wav
                                              textures, geo, seg, counters, aggrs, rgba, ids);
 }
 
+#ifndef JR_FWD_PRECISE          // (one definition: the policy does not depend on the arithmetic)
+}  // namespace JR_FWD_NAMESPACE
+namespace jr {
 bool forward_uses_heavy_path(const RasterParams& p, const BinWorkspace& ws) {
     return ws.heavy_min > 0 && p.tex == 0 && (long)p.B * p.IS * p.IS <= (long)tune::fwd_heavy_pixels;
 }
+}  // namespace jr
+namespace JR_FWD_NAMESPACE {
+#endif
 
 template <int DIST, int RGB, int KCAP>
 static void launch_kk(hipStream_t st, const RasterParams& p, const float* textures,
@@ -1341,14 +1596,19 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
             // more than 64 KB of dynamic LDS per workgroup is an opt-in PER DEVICE and per kernel instantiation: asked once
             // per context (= device) and instantiation; a refusal falls back to four wavefronts instead of a failed launch
             const unsigned long long bit = 1ull << ((DIST * 3 + RGB) * 3 + (KCAP <= 16 ? 0 : (KCAP <= 32 ? 1 : 2)));
-            if (!(ws.lds_optin_tried & bit)) {
-                ws.lds_optin_tried |= bit;
+#ifdef JR_FWD_PRECISE
+            constexpr int SET = 1;
+#else
+            constexpr int SET = 0;
+#endif
+            if (!(ws.lds_optin_tried[SET] & bit)) {
+                ws.lds_optin_tried[SET] |= bit;
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softras_forward_mixed<DIST, RGB, KCAP, 8>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, mixed_lds_bytes(8)) == hipSuccess)
-                    ws.lds_optin_ok |= bit;
+                    ws.lds_optin_ok[SET] |= bit;
                 else (void)hipGetLastError();
             }
-            eight = (ws.lds_optin_ok & bit) != 0;
+            eight = (ws.lds_optin_ok[SET] & bit) != 0;
         }
         ws.heavy_waves_used = eight ? 8 : 4;
         if (eight) launch(std::integral_constant<int, 8>());
@@ -1398,4 +1658,4 @@ void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* 
 #undef JR_FWD
 }
 
-}  // namespace jr
+}  // namespace JR_FWD_NAMESPACE

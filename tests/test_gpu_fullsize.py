@@ -213,6 +213,57 @@ def test_whole_view_dense_backward_vs_oracle(scene):
     assert (np.abs(gfo) > 0).mean() > 0.2            # the view's gradient is dense, not a corner case
 
 
+def test_whole_view_end_to_end_gradient_vs_the_references_own_forward(scene):
+    """VERDICT r4 (weak 2, next 3b): the dense-backward test above runs the oracle's backward on the GPU's OWN saved tensors
+    - it gates the backward alone (5 - 9e-5), not what a caller gets.  END TO END: own forward + own backward of view 5
+    against the exact sum (float atomics shadowed in double, oracle/ref_driver.cpp) of the REFERENCE's backward on the
+    REFERENCE's own forward (cuda/soft_rasterize.py:344, :401-411 -> :1281-1347), element-wise
+    |a - b| / (|b| + 1e-3 max|b|) for grad_faces and for the vertex gradient (face -> vertex scatter of the 39 000-face
+    mesh), next to the reference's own atomic-order noise on the same input.  Measured (BENCH_r04 / r05): grad_faces
+    1.0 - 1.1e-4, vertex gradient 2.0e-4 against a noise of 4 - 6e-5 - the excess is the forward's colour path
+    (v_exp / v_rcp instead of expf + double division).  Bound max(2.5e-4, 4 x noise): today's figures pass,
+    a regression to 1e-3 - which every other gradient test would wave through - fails."""
+    from oracle import have_ref
+    if not have_ref():
+        pytest.skip("oracle/_ref (the reference's kernels compiled for the host) is not built")
+    from jrender_amd.structures.mesh import face_vertices_backward
+    ctx, fv, tex, fn, saved = scene
+    view = 5
+    ref = Oracle("reference", nthreads=0)
+    fwd = ref.forward(fv[view:view + 1], tex[view:view + 1], image_size=IS, max_faces_per_pixel_for_grad=K)
+    g = np.zeros((B, 4, IS, IS), np.float32)
+    g[view] = np.random.default_rng(19).uniform(-1, 1, (4, IS, IS))
+    gf = fn.grad(g)[0].numpy().reshape(B, NF, 9)[view:view + 1]
+    rf, _ = ref.backward(fwd, g[view:view + 1], nthreads=ref.num_procs())
+    sf, _ = ref.backward_exactsum(fwd, g[view:view + 1])
+    _, faces = syn.sphere_mesh(NF)
+    fb = np.asarray(faces, np.int64).reshape(1, -1, 3)
+    nv = int(fb.max()) + 1
+    gv = lambda x: face_vertices_backward(np.asarray(x, np.float32).reshape(1, -1, 3, 3), fb, nv)      # noqa: E731
+    noise_f, noise_v = grad_err_elementwise(rf, sf), grad_err_elementwise(gv(rf), gv(sf))
+    e_f, e_v = grad_err_elementwise(gf, sf.reshape(1, NF, 9)), grad_err_elementwise(gv(gf), gv(sf))
+    bound_f, bound_v = max(2.5e-4, 4 * noise_f), max(2.5e-4, 4 * noise_v)
+    print("end to end, view %d: grad_faces element-wise(1e-3 floor) %.3g (reference's order noise %.3g, bound %.3g) | "
+          "vertex gradient %.3g (noise %.3g, bound %.3g) | max-norm %.3g" % (view, e_f, noise_f, bound_f, e_v, noise_v, bound_v,
+                                                                          grad_err(gf, sf.reshape(1, NF, 9))))
+    assert grad_err(gf, sf.reshape(1, NF, 9)) <= 2e-5          # 50 x inside the 1e-4 max-norm bar (measured 4 - 6e-7)
+    assert e_f <= bound_f and e_v <= bound_v
+    # precise_colour=True (jr_softras_set_precise_colour): the forward's coverage sigmoid and softmax weights in the
+    # reference's own arithmetic - the only variant that measured under 1e-4 in round 4 (7.8e-5 against a noise of 5e-5;
+    # RGBA 8e-6 instead of 4.8e-5).  The view rendered on its own takes the multi-wavefront kernel, i.e. the precise set
+    # of BOTH forward organisations is exercised between this and the small scenes of test_gpu_parity.py.
+    fp = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, precise_colour=True, ctx=ctx)
+    out_p = fp(fv[view:view + 1], tex[view:view + 1]).numpy()
+    assert bits_equal(fp.save_vars[5].numpy(), fwd["faces_id_buffer"]) and bits_equal(fp.save_vars[3].numpy(), fwd["faces_info"])
+    gp = fp.grad(g[view:view + 1])[0].numpy().reshape(1, NF, 9)
+    p_f, p_v = grad_err_elementwise(gp, sf.reshape(1, NF, 9)), grad_err_elementwise(gv(gp), gv(sf))
+    rgba_fast, rgba_precise = rel_err(saved[2][view:view + 1], fwd["soft_colors"], RGBA_ATOL), rel_err(out_p, fwd["soft_colors"], RGBA_ATOL)
+    print("precise colour: grad_faces %.3g (fast path %.3g) vertex gradient %.3g (%.3g) | RGBA error / tolerance %.3g (%.3g)"
+          % (p_f, e_f, p_v, e_v, rgba_precise, rgba_fast))
+    assert rgba_precise <= 0.5 * max(rgba_fast, 0.2) and rgba_precise <= 0.3
+    assert p_f <= max(1.3e-4, 2.5 * noise_f) and p_v <= max(2.0e-4, 3 * noise_v)
+
+
 def test_heavy_tile_path_whole_view_forward_and_dense_backward():
     """Round 3: launches of up to 4 Mpixels run the four-wavefront kernel - the tiles of bins with more than 512 listed
     faces (the sphere's limb) are evaluated by four wavefronts on a dense pair list and applied by two.  ONE 39k-face

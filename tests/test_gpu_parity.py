@@ -41,7 +41,11 @@ def port():
 # distance keeps 1e-2: with dis = w^2 up to 1 and sigma 1e-4 the coverage saturates to 1 within an ulp, so (1 - D) and the
 # (1 - alpha) factor of the 'prod' gradient are the forward's last bit - the reference's own float gradient is only within
 # 3e-4 ... 1 (!) of its double instantiation on these scenes (oracle.backward_f64), measured in profiles/r04_experiments.md.
-ELEMENTWISE_TOL, ELEMENTWISE_TOL_BARYCENTRIC = 2e-3, 1e-2
+# Round 5 (VERDICT r4 next #3b): every check_against call of the suite was recorded on the GPU (JR_RECORD_ELEMENTWISE,
+# profiles/r05_c3_elementwise_curated.txt: 295 comparisons): 204 are under 1e-4, all but 19 under 6e-4, the largest 6.2e-4 -
+# except two scenes that sit at 1.5 - 1.7e-3 (vertex colours under 'hard' rgb, regress_hard_alpha_b: gradients that are a few
+# large cancelling terms) and keep the old 2e-3 by name (ELEMENTWISE_TOL_OUTLIERS); barycentric scenes measure up to 3.9e-3.
+ELEMENTWISE_TOL, ELEMENTWISE_TOL_OUTLIERS, ELEMENTWISE_TOL_BARYCENTRIC = 1e-3, 2e-3, 1e-2
 
 
 def check_against(ref, fn, g, ref_grads, elementwise_tol=ELEMENTWISE_TOL):
@@ -58,10 +62,14 @@ def check_against(ref, fn, g, ref_grads, elementwise_tol=ELEMENTWISE_TOL):
             assert np.nanmax(np.abs(a)) == 0, name
             continue
         assert grad_err(a, b) <= GRAD_TOL, (name, grad_err(a, b))
+        if os.environ.get("JR_RECORD_ELEMENTWISE"):       # how the tolerance below was set: what the curated scenes measure (x 3)
+            with open(os.environ["JR_RECORD_ELEMENTWISE"], "a") as fh:
+                fh.write("%s %s %.3e %.3e tol %.1e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], name,
+                                                        grad_err(a, b), grad_err_elementwise(a, b), elementwise_tol))
         assert grad_err_elementwise(a, b) <= elementwise_tol, (name, grad_err_elementwise(a, b))
 
 
-def run_case(ctx, port, fv, tex, seed=0, g=None, **kw):
+def run_case(ctx, port, fv, tex, seed=0, g=None, elementwise_tol=None, **kw):
     ref = port.forward(fv, tex, **kw)
     if port.ub_events():
         pytest.skip("input hits the reference's undefined-behaviour corner (SRK:107-121)")
@@ -70,7 +78,7 @@ def run_case(ctx, port, fv, tex, seed=0, g=None, **kw):
     if g is None:
         g = np.random.default_rng(seed).uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
     check_against(ref, fn, g, port.backward(ref, g),
-                  ELEMENTWISE_TOL_BARYCENTRIC if kw.get("dist_func") == "barycentric" else ELEMENTWISE_TOL)
+                  elementwise_tol or (ELEMENTWISE_TOL_BARYCENTRIC if kw.get("dist_func") == "barycentric" else ELEMENTWISE_TOL))
     return ref, fn
 
 
@@ -126,7 +134,8 @@ def test_fuzz_regressions(ctx, port, path):
     regress_hard_alpha_inside_noise (round 4): a pixel centre 3e-7 inside an edge - its squared distance (1e-13) is float
     noise, 'hard' alpha decides D > 0.5 from it, so with 'hard' alpha the inside distance keeps the reference's IEEE quotients."""
     z = np.load(path)
-    run_case(ctx, port, z["fv"], z["tex"], g=z["g"] if "g" in z.files else None, **eval(str(z["kw"])))
+    run_case(ctx, port, z["fv"], z["tex"], g=z["g"] if "g" in z.files else None,
+             elementwise_tol=ELEMENTWISE_TOL_OUTLIERS if "regress_hard_alpha_b" in path else None, **eval(str(z["kw"])))
 
 
 def test_default_sphere(ctx, port):
@@ -155,7 +164,8 @@ def test_all_modes_surface(ctx, port, dist, rgb, alpha):
 @pytest.mark.parametrize("rgb,fill_back", [("hard", True), ("softmax", True), ("softmax", False), ("hard", False)])
 def test_vertex_textures(ctx, port, rgb, fill_back):
     fv, tex = syn.sphere_views(280, 1, texels=3)
-    run_case(ctx, port, fv, tex, image_size=56, texture_type="vertex", aggr_func_rgb=rgb, fill_back=fill_back)
+    run_case(ctx, port, fv, tex, image_size=56, texture_type="vertex", aggr_func_rgb=rgb, fill_back=fill_back,
+             elementwise_tol=ELEMENTWISE_TOL_OUTLIERS if rgb == "hard" else None)
 
 
 @pytest.mark.parametrize("K", [1, 2, 7, 16, 17, 40, 64])
@@ -322,3 +332,35 @@ def test_bin_size_kwargs_are_equivalent_to_bin_size_zero(ctx):
         for a, b in zip(o[:-1], outs[0][:-1]):
             assert bits_equal(a, b)
         assert grad_err(o[-1], outs[0][-1]) <= 1e-6           # float atomics: order of the sums may differ
+
+
+@pytest.mark.parametrize("policy", ["one_wavefront", "pipeline4", "pipeline8"])
+@pytest.mark.parametrize("dist,rgb,alpha", [("euclidean", "softmax", "prod"), ("barycentric", "softmax", "sum"),
+                                            ("euclidean", "hard", "hard"), ("hard", "softmax", "prod")])
+def test_precise_colour_mode(port, dist, rgb, alpha, policy):
+    """precise_colour=True (round 5; jr_softras_set_precise_colour): the forward kernels of softras_forward_precise.hip -
+    coverage sigmoid and softmax weights as the reference evaluates them (SRK:338-344, :401-411) - through every kernel
+    organisation.  Same bars as the default mode, the index buffer and faces_info bit-exact; RGBA must come out at
+    least as close to the oracle as the default arithmetic's."""
+    ctx = _ffi.Context(0)
+    try:
+        ctx.set_bin_size(32)
+        ctx.set_launch_policy(0 if policy == "one_wavefront" else 96, 8 if policy == "pipeline8" else 4)
+        fv, tex = syn.triangle_soup(900, 1, seed=41, texels=4, scale=5.0)
+        fv[..., :2] *= 0.55
+        kw = dict(image_size=64, dist_func=dist, aggr_func_rgb=rgb, aggr_func_alpha=alpha, sigma_val=1e-4)
+        ref = port.forward(fv, tex, **kw)
+        if port.ub_events():
+            pytest.skip("input hits the reference's undefined-behaviour corner (SRK:107-121)")
+        g = np.random.default_rng(3).uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
+        rg = port.backward(ref, g)
+        errs = {}
+        for precise in (False, True):
+            fn = SoftRasterizeFunction(ctx=ctx, precise_colour=precise, **kw)
+            fn(fv, tex)
+            assert ctx.last_launch()["four_wavefront_kernel"] == (policy != "one_wavefront")
+            check_against(ref, fn, g, rg, ELEMENTWISE_TOL_BARYCENTRIC if dist == "barycentric" else ELEMENTWISE_TOL)
+            errs[precise] = rel_err(fn.save_vars[2].numpy(), ref["soft_colors"], RGBA_ATOL)
+        assert errs[True] <= max(errs[False], 0.05), errs
+    finally:
+        ctx.close()

@@ -49,9 +49,12 @@ if SETUP:
     sys.exit(0)
 if HEAVY:
     tot = c[0:8].sum()
-    print("heaviest bin, wavefront 0 of its 16 tiles, %d launches: %.3g clocks per tile and launch" % (5, tot / 16 / 5))
-    for i, lab in enumerate(["stage (+ wait)", "masks", "pair list", "evaluate (+ barriers)", "-", "inside pairs", "apply", "stores"]):
-        print("   %-24s %5.1f %%   %9.0f clocks per tile" % (lab, 100 * c[i] / max(tot, 1), c[i] / 16 / 5))
+    nt = (ctx.bin_size() // 8) ** 2      # tiles of the heaviest bin (JR_BIN_SIZE=8: the ONE tile that lists the most faces)
+    info = ctx.last_launch()
+    print("heaviest bin (%d faces listed, bin size %d: %d tile(s)), wavefront %s of a %d-wavefront workgroup, %d launches: %.3g clocks per tile and launch"
+          % (ctx.last_stats()["max_faces_in_bin"], ctx.bin_size(), nt, os.environ.get("JR_SECTIONS_WAVE_LABEL", "?"), info["wavefronts_per_workgroup"], 5, tot / nt / 5))
+    for i, lab in enumerate(["barrier wait / stage", "masks", "pair list", "claimed tasks / evaluate", "-", "inside pairs", "apply", "stores"]):
+        print("   %-24s %5.1f %%   %9.0f clocks per tile" % (lab, 100 * c[i] / max(tot, 1), c[i] / nt / 5))
     sys.exit(0)
 for name, lo, labels in (("forward", 0, ["set-up", "cull + stage", "ballots + pre-cull", "raster loop", "stores"]),
                          ("backward", 8, ["tile state + sort", "extraction", "staging + items", "gather", "pair arithmetic", "reduce + atomics"])):

@@ -26,6 +26,7 @@ ap.add_argument("--quick", action="store_true")
 ap.add_argument("--steps", type=int, default=25)
 ap.add_argument("--configs", default="")
 ap.add_argument("--bins", default="32,16,8")
+ap.add_argument("--one", default="", help="bin,heavy_min,waves: time this ONE policy per configuration (e.g. under rocprofv3) instead of the sweep")
 args = ap.parse_args()
 ctx = _ffi.Context(0)
 
@@ -40,11 +41,12 @@ def configs():
             ("b1_39k_1024", *syn.sphere_views(39000, 1), 1024, {}),
             ("b2_39k_1024", *syn.sphere_views(39000, 2), 1024, {}),
             ("b4_39k_1024", *syn.sphere_views(39000, 4), 1024, {}),
+            ("b8_39k_1024", *syn.sphere_views(39000, 8), 1024, {}),
             ("s3300_1024", *syn.sphere_views(3300, 1), 1024, {}),
             ("s280_256", *syn.sphere_views(280, 1), 256, {}),
             ("s39k_256_b8", *syn.sphere_views(39000, 8), 256, {})]
     want = [c for c in args.configs.split(",") if c]
-    return [r for r in rows if not want or r[0] in want]
+    return [r for r in rows if (r[0] in want if want else r[0] != "b8_39k_1024")]      # (the headline batch only when asked for)
 
 
 THRESH = {32: (512, 384, 256, 768, 0), 16: (192, 128, 96, 64, 256, 384, 0), 8: (96, 64, 48, 32, 128, 192, 0)}
@@ -80,9 +82,10 @@ for name, fv, tex, IS, kw in configs():
     t0, ph0, ref, li0, st0 = run(fv_d, tex_d, g_d, IS, kw, args.steps)
     gmax = max(np.abs(ref["gf"]).max(), 1e-30)
     best = (t0, 32, -1, 0)
-    for b in bins:
-        for hm in THRESH[b]:
-            for w in ((0,) if hm == 0 else (0, 4, 8)):
+    one = [int(x) for x in args.one.split(",")] if args.one else None
+    for b in ([one[0]] if one else bins):
+        for hm in ([one[1]] if one else THRESH[b]):
+            for w in ([one[2]] if one else ((0,) if hm == 0 else (0, 4, 8))):
                 ctx.set_bin_size(b); ctx.set_launch_policy(hm, w)
                 t, ph, out, li, st = run(fv_d, tex_d, g_d, IS, kw, args.steps)
                 bad = [k for k in ("ids", "rgba", "aggrs", "info") if not np.array_equal(out[k].view(np.int32), ref[k].view(np.int32))]
