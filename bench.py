@@ -598,6 +598,27 @@ def launch_ranks(n, argv, timeout_s=1500.0):
         sys.exit(1)
 
 
+def dry_run(args, ctx, rank, world):
+    """`bench.py --dry-run-ranks N`: the N-rank start-up up to (not including) ncclCommInitRank, on however many GPUs the box
+    has (VERDICT r4 next #7a).  Every rank validates its environment, takes part in the unique-id rendezvous, maps to its
+    device and allocates the buffers the bench's exchange step would move (the all-gathered image batch, the all-reduced
+    shared-vertex gradient); rank 0 prints ONE JSON line with every rank's report.  Exit code 1 when a check fails."""
+    from jrender_amd import comm as jcomm, synthetic as syn
+    B, NF, IS = args.batch, args.faces, args.image_size
+    nv = syn.sphere_mesh(NF)[0].shape[0] if args.scene == "sphere" and NF in syn.SPHERE_SHAPES else 3 * NF
+    payload = {"allgather_images_recv": 4 * 4 * IS * IS * B * world, "allgather_images_send": 4 * 4 * IS * IS * B,
+               "allreduce_vertex_grads": 4 * 3 * nv}
+    rep = jcomm.rccl_dry_run(ctx, rank, world, payload)
+    if rank == 0:
+        line = {"dry_run": True, "n_ranks": world, "ok": rep["ok"], "problems": rep["problems"],
+                "one_gpu_per_rank": rep["one_gpu_per_rank"], "stopped_before": rep["stopped_before"],
+                "unique_id_sha256": rep["id_sha256"], "payload_bytes": payload, "ranks": rep["ranks"],
+                "note": "no communicator was created: ncclCommInitRank with more than one rank needs one GPU per rank"}
+        print(json.dumps(line), flush=True)
+        if not rep["ok"]:
+            sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="softras", choices=["softras", "n3mr"])
@@ -615,11 +636,16 @@ def main():
                     help="exchange step at the end of every step (default: allreduce_vertex_grads when N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline + parity)")
     ap.add_argument("--no-secondary", action="store_true", help="skip latency_ms_b1 / secondary (K=32, K=64, soup, NMR)")
+    ap.add_argument("--dry-run-ranks", type=int, default=0, metavar="N",
+                    help="spawn N ranks that do everything an N-GPU start-up does up to ncclCommInitRank - environment, rendezvous, "
+                         "unique id, device mapping, exchange buffers - without creating the communicator; one JSON line (runs on a 1-GPU box)")
     ap.add_argument("--allow-shared-gpus", action="store_true",
                     help="plumbing runs only: let ranks share GPUs over the host communicator when fewer GPUs than ranks are "
                          "visible (without it such a launch exits non-zero: an N-rank line must mean N GPUs)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.dry_run_ranks > 1:
+        return launch_ranks(args.dry_run_ranks, sys.argv[1:], timeout_s=300.0)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args.gpus, sys.argv[1:])
 
@@ -636,6 +662,8 @@ def main():
     if ndev < 1:
         sys.exit("bench.py: no HIP device visible (there is no CPU fallback)")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if args.dry_run_ranks:
+        return dry_run(args, _ffi.Context(local_rank % ndev), rank, world)
     if ndev < local_world and not args.allow_shared_gpus:
         sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible - an N-rank line must mean N GPUs "
                  "(--allow-shared-gpus runs the plumbing over the host communicator instead)" % (local_world, ndev))

@@ -283,7 +283,7 @@ int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]);
  * kernel organisation computes them).  heavy_min_faces: a bin that lists at least this many faces (rounded DOWN to the
  * launch order's bucket boundary: 12 buckets per octave of the list length, i.e. up to 6 % below the value) gets a whole
  * workgroup per tile in forwards of up to 4 Mpixels (and four wavefronts per tile in small backwards); 0 = never,
- * < 0 = the built-in default of the launch's bin size (512 / 192 / 96 for 32 / 16 / 8-pixel bins).  heavy_waves: 4 or 8 wavefronts per such workgroup, 0 = chosen per launch from the
+ * < 0 = the built-in default of the launch's bin size (512 / 128 or 64 / 48 for 32 / 16 / 8-pixel bins).  heavy_waves: 4 or 8 wavefronts per such workgroup, 0 = chosen per launch from the
  * number of heavy tiles.  Environment JR_FWD_HEAVY_MIN / JR_FWD_HEAVY_WAVES set the same two values at jr_ctx_create. */
 int jr_softras_set_launch_policy(jr_ctx* ctx, int heavy_min_faces, int heavy_waves);
 /* Screen-bin size in pixels: replaces the `bin_size` argument of the reference's operator (soft_rasterize.py:85-99 ->
@@ -292,9 +292,10 @@ int jr_softras_set_launch_policy(jr_ctx* ctx, int heavy_min_faces, int heavy_wav
  * wavefront tiles per bin).  Sticky per context.  It selects how finely the face lists, the launch order and the
  * heavy-bin classification follow the image - results are bit-identical for every value (the reference's own binned path
  * is NOT: it truncates lists at max_elems_per_bin and fills them in a nondeterministic order).  The default threshold of
- * jr_softras_set_launch_policy follows the bin size (512 / 192 / 96 listed faces for 32 / 16 / 8 pixels).
- * jr_softras_bin_size: the size a launch at `image_size` would use now; image_size <= 0: the size the workspace's
- * current face records / lists were built with (0 before the first forward). */
+ * jr_softras_set_launch_policy follows the bin size (512 listed faces for 32-pixel bins, 128 for 16 - 64 for meshes of up to 10 000 faces -, 48 for 8).
+ * jr_softras_bin_size: the size a launch of `batch` views at `image_size` would use now (automatic choice: 8-pixel bins up to
+ * 128^2 images, 16 up to 512^2 and above while batch x image_size^2 <= 4 Mpixels, else 32); image_size <= 0: the size the
+ * workspace's current face records / lists were built with (0 before the first forward). */
 int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size);
 /* Colour-path arithmetic of the forward (sticky per context; default 0).  0: the coverage sigmoid and the softmax weights
  * use the hardware's exp2 / reciprocal (cuda/soft_rasterize.py:338-344, :401-411 evaluate them with expf and a
@@ -303,7 +304,7 @@ int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size);
  * reference's own arithmetic for both quantities (a second set of forward kernels): RGBA 8e-6, gradients under 1e-4
  * element-wise; forward +15 % on the headline batch.  The face-index buffer and faces_info are bit-exact in both modes. */
 int jr_softras_set_precise_colour(jr_ctx* ctx, int on);
-int jr_softras_bin_size(const jr_ctx* ctx, int image_size);
+int jr_softras_bin_size(const jr_ctx* ctx, int image_size, int batch);
 /* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
  * previous call, [0..7] forward raster, [8..15] backward raster; all zero in the product build */
 int jr_debug_section_clocks(jr_ctx* ctx, uint64_t clocks[20]);

@@ -167,18 +167,25 @@ int validate(int B, int NF, int T, int IS, int K, int dist, int rgb, int alpha, 
 // or, by default, one that follows the image - a 32-pixel bin is HALF of a 64^2 image (demo2: every bin lists a third of
 // the mesh and every tile walks that list), while on a 1024^2 image it keeps the lists, the ordering kernel and the
 // launch order cheap.  Results do not depend on it.
-int resolve_bin_log2(const jr_ctx* ctx, int IS) {
+int resolve_bin_log2(const jr_ctx* ctx, int B, int IS) {
     const int user = ctx->bin_size_user;
     if (user > 0) return user <= 8 ? 3 : (user <= 16 ? 4 : 5);
+    // measured (profiles/r05_experiments.md, calls 1 and 4): 64^2 x 64 views 0.48 -> 0.35 ms with 8-pixel bins (the list IS the
+    // tile's, half of the tiles are limb-heavy), 256^2 - 12 % with 16; at 1024^2 16-pixel bins pay (- 2 ... - 7 %) while the
+    // launch fits the multi-wavefront kernel, the headline batch keeps 32 (+ 2 % otherwise: twice the list entries to order)
     if (IS <= jr::tune::auto_bin8_max_image) return 3;
     if (IS <= jr::tune::auto_bin16_max_image) return 4;
-    return 5;
+    return (long)B * IS * IS <= (long)jr::tune::fwd_heavy_pixels ? 4 : 5;
 }
 // Bins that list more faces than this are HEAVY (a workgroup per tile in the forward, split tiles in the backward): the
-// caller's value, or the default of the bin size (a smaller bin lists fewer faces for the same load per tile).
-int resolve_heavy_min(const jr_ctx* ctx, int bin_log2) {
+// caller's value, or the default of the bin size (a smaller bin lists fewer faces for the same load per tile; with 16-pixel
+// bins small meshes - the spot cow's 5 856 faces, a 3 300-face sphere - want the pipeline from 64 listed faces on, the
+// 39 000-face sphere from 128: below that too many of its tiles queue for workgroups).
+int resolve_heavy_min(const jr_ctx* ctx, int bin_log2, int NF) {
     if (ctx->heavy_min_user >= 0) return ctx->heavy_min_user;
-    return bin_log2 >= 5 ? jr::tune::fwd_heavy : (bin_log2 == 4 ? jr::tune::fwd_heavy16 : jr::tune::fwd_heavy8);
+    if (bin_log2 >= 5) return jr::tune::fwd_heavy;
+    if (bin_log2 == 4) return NF <= jr::tune::small_mesh_faces ? jr::tune::fwd_heavy16_small_mesh : jr::tune::fwd_heavy16;
+    return jr::tune::fwd_heavy8;
 }
 
 jr::RasterParams make_params(const jr_ctx* ctx, int B, int NF, int T, int IS, int K, float near_, float far_, float eps,
@@ -191,7 +198,7 @@ jr::RasterParams make_params(const jr_ctx* ctx, int B, int NF, int T, int IS, in
     p.rad = sqrtf(p.thr);                                                                  // SRK:316
     p.dist = dist; p.rgb = rgb; p.alpha = alpha; p.tex = tex; p.double_side = double_side ? 1 : 0;
     for (int k = 0; k < 3; k++) p.bg[k] = bg ? bg[k] : 0.f;
-    p.bin_log2 = resolve_bin_log2(ctx, IS);
+    p.bin_log2 = resolve_bin_log2(ctx, B, IS);
     p.sub_log2 = p.bin_log2 - jr::TILE_LOG2;
     p.bins_x = (IS + (1 << p.bin_log2) - 1) >> p.bin_log2;
     p.bins_y = p.bins_x;
@@ -251,7 +258,7 @@ int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, cons
 int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
                      float* faces_info, float* aggrs_info, float* soft_colors, int32_t* faces_id_buffer) {
     jr::BinWorkspace& ws = ctx->ws;
-    ws.heavy_min = resolve_heavy_min(ctx, p.bin_log2);
+    ws.heavy_min = resolve_heavy_min(ctx, p.bin_log2, p.NF);
     const bool heavy_path = jr::forward_uses_heavy_path(p, ws);
     // Workgroup size of the multi-wavefront kernel.  Eight wavefronts per heavy tile cut a lone view's critical path
     // further (one 39k-face view: 0.33 -> 0.28 ms), but they and the eight light tiles per workgroup cost throughput as
@@ -262,7 +269,13 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     auto waves_for = [&](int64_t heavy_bins) {
         if (!(jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8)) return 4;
         if (ctx->forced_waves == 4 || ctx->forced_waves == 8) return ctx->forced_waves;
-        return heavy_bins * 16 * 8 <= jr::tune::fwd_heavy_waves8_budget ? 8 : 4;
+        if (heavy_bins <= 0) return 4;            // nothing for the pipeline: four light tiles per workgroup beat eight (3 300 faces at 1024^2: 0.247 against 0.256 ms)
+        // eight while the heavy tiles' wavefronts fit a budget: generous for launches that cannot fill the GPU anyway (one 39k
+        // view: 1 152 tiles of 16-pixel bins at eight wavefronts 0.489 ms, at four 0.571), tight for the others (four views)
+        const int64_t tiles = heavy_bins << (2 * p.sub_log2);
+        const long budget = (long)p.B * p.IS * p.IS <= jr::tune::fwd_waves8_small_pixels ? jr::tune::fwd_heavy_waves8_budget_small
+                                                                                          : jr::tune::fwd_heavy_waves8_budget;
+        return tiles * 8 <= budget ? 8 : 4;
     };
     jr_ctx::ShapeHist* hist = nullptr;
     for (auto& h : ctx->hist)
@@ -533,9 +546,9 @@ int jr_softras_backward_ex(jr_ctx* ctx, const float* face_vertices, const float*
     // faces_info write, no lists: the backward finds its faces through the id buffer).
     const bool reuse = forward_token != 0 && forward_token == ctx->geo_epoch && ctx->bins_B == B &&
                        ctx->bins_NF == NF && ctx->bins_IS == IS && ctx->bins_rad == p.rad && ctx->bins_T == T &&
-                       ctx->bins_bin_log2 == p.bin_log2 && ctx->ws.heavy_min == resolve_heavy_min(ctx, p.bin_log2);
+                       ctx->bins_bin_log2 == p.bin_log2 && ctx->ws.heavy_min == resolve_heavy_min(ctx, p.bin_log2, NF);
     if (!reuse) {
-        ctx->ws.heavy_min = resolve_heavy_min(ctx, p.bin_log2);
+        ctx->ws.heavy_min = resolve_heavy_min(ctx, p.bin_log2, NF);
         if (setup_faces(ctx, p, face_vertices, textures, nullptr)) return 1;
         ctx->ws.heavy_bound = -1;           // nobody read this schedule's totals: the pool-capacity bound
     }
@@ -885,10 +898,10 @@ int jr_softras_set_precise_colour(jr_ctx* ctx, int on) {
     return 0;
 }
 
-int jr_softras_bin_size(const jr_ctx* ctx, int image_size) {
+int jr_softras_bin_size(const jr_ctx* ctx, int image_size, int batch) {
     if (!ctx) return -1;
     if (image_size <= 0) return ctx->bins_bin_log2 ? 1 << ctx->bins_bin_log2 : 0;     // of the set-up pass the workspace holds
-    return 1 << resolve_bin_log2(ctx, image_size);
+    return 1 << resolve_bin_log2(ctx, batch > 0 ? batch : 1, image_size);
 }
 
 int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]) {

@@ -48,17 +48,29 @@
 #ifndef JR_TUNE_FWD_HEAVY        // forward: bins whose list is longer than this get FOUR wavefronts per tile (evaluate / apply split); 0 = one wavefront per tile everywhere
 #define JR_TUNE_FWD_HEAVY 512
 #endif
-#ifndef JR_TUNE_FWD_HEAVY16      // the same threshold for 16-pixel bins (2x2 tiles) and 8-pixel bins (one tile: the list IS the tile's)
-#define JR_TUNE_FWD_HEAVY16 192
+#ifndef JR_TUNE_FWD_HEAVY16      // the same threshold for 16-pixel bins (2x2 tiles): meshes above / up to JR_TUNE_SMALL_MESH_FACES faces
+#define JR_TUNE_FWD_HEAVY16 128
 #endif
-#ifndef JR_TUNE_FWD_HEAVY8
-#define JR_TUNE_FWD_HEAVY8 96
+#ifndef JR_TUNE_FWD_HEAVY16_SMALL_MESH
+#define JR_TUNE_FWD_HEAVY16_SMALL_MESH 64
+#endif
+#ifndef JR_TUNE_SMALL_MESH_FACES
+#define JR_TUNE_SMALL_MESH_FACES 10000
+#endif
+#ifndef JR_TUNE_FWD_HEAVY8       // ... and for 8-pixel bins (one tile: the list IS the tile's)
+#define JR_TUNE_FWD_HEAVY8 48
 #endif
 #ifndef JR_TUNE_AUTO_BIN8_MAX_IMAGE    // bin size by image size when the caller does not choose (jr_softras_set_bin_size): 8-pixel bins up to this image size,
-#define JR_TUNE_AUTO_BIN8_MAX_IMAGE 0
+#define JR_TUNE_AUTO_BIN8_MAX_IMAGE 128
 #endif
-#ifndef JR_TUNE_AUTO_BIN16_MAX_IMAGE   // 16-pixel bins up to this one, 32 above
-#define JR_TUNE_AUTO_BIN16_MAX_IMAGE 0
+#ifndef JR_TUNE_AUTO_BIN16_MAX_IMAGE   // 16-pixel bins up to this one; above it 16 while the launch fits the multi-wavefront kernel (JR_TUNE_FWD_HEAVY_PIXELS), else 32
+#define JR_TUNE_AUTO_BIN16_MAX_IMAGE 512
+#endif
+#ifndef JR_TUNE_FWD_HEAVY_WAVES8_BUDGET_SMALL   // the eight-wavefront budget of launches of up to JR_TUNE_FWD_WAVES8_SMALL_PIXELS pixels
+#define JR_TUNE_FWD_HEAVY_WAVES8_BUDGET_SMALL 10240
+#endif
+#ifndef JR_TUNE_FWD_WAVES8_SMALL_PIXELS
+#define JR_TUNE_FWD_WAVES8_SMALL_PIXELS 2621440
 #endif
 #ifndef JR_TUNE_FWD_HEAVY_DEFER_COPY // forward, heavy tiles: the record copies of a batch in one round after the list walk
 #define JR_TUNE_FWD_HEAVY_DEFER_COPY 1
@@ -179,6 +191,9 @@
 #define JR_TUNE_PROFILE_SECTIONS 0
 #endif
 
+#ifndef JR_TUNE_FIXED_BIN32       // diagnostics: 32-pixel bins as a compile-time constant in the raster kernels (the library must then be used with bin size 32 only)
+#define JR_TUNE_FIXED_BIN32 0
+#endif
 #ifndef JR_TUNE_COUNT_PATHS       // instrumented build: trips and lanes per region of the forward's raster loop (tools/sim/min_valu.py --measure)
 #define JR_TUNE_COUNT_PATHS 0
 #endif
@@ -191,6 +206,7 @@ namespace tune {
 constexpr int sections_wave = JR_TUNE_SECTIONS_WAVE;
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
 constexpr bool count_paths = JR_TUNE_COUNT_PATHS != 0;
+constexpr bool fixed_bin32 = JR_TUNE_FIXED_BIN32 != 0;
 constexpr bool n3_pixmap_all = JR_TUNE_N3_PIXMAP_ALL != 0;
 constexpr int n3_xcd_group = JR_TUNE_N3_XCD_GROUP;
 constexpr int n3_walks = JR_TUNE_N3_WALKS;
@@ -232,6 +248,8 @@ constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
 constexpr bool fwd_empty_bins = JR_TUNE_FWD_EMPTY_BINS != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY, fwd_heavy16 = JR_TUNE_FWD_HEAVY16, fwd_heavy8 = JR_TUNE_FWD_HEAVY8;
+constexpr int fwd_heavy16_small_mesh = JR_TUNE_FWD_HEAVY16_SMALL_MESH, small_mesh_faces = JR_TUNE_SMALL_MESH_FACES;
+constexpr long fwd_heavy_waves8_budget_small = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET_SMALL, fwd_waves8_small_pixels = JR_TUNE_FWD_WAVES8_SMALL_PIXELS;
 constexpr int auto_bin8_max_image = JR_TUNE_AUTO_BIN8_MAX_IMAGE, auto_bin16_max_image = JR_TUNE_AUTO_BIN16_MAX_IMAGE;
 constexpr bool fwd_heavy_defer_copy = JR_TUNE_FWD_HEAVY_DEFER_COPY != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;

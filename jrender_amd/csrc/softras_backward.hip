@@ -234,6 +234,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TEXLDS ? (KC
     // before it (one VMEM counter, in order): each trip paid the round trip of the previous trip's texel atomics.  BASELINE
     // configs[1] (spot cow, 25 texels per face, 1024^2, one view): backward 0.28 ms, 4 x the 3 300-face sphere's at T = 1.
     float* s_tex = s_vcol;                                                     // [BATCH][T*3] iff TEXLDS (never together with vertex colours)
+    // ... and the texel GRADIENTS of a batch are summed in LDS too: a pair adds its three colour components to the face's texel
+    // (ds_add_f32), one global atomic per touched (face, texel, channel) leaves at the end of the batch.  Straight to global
+    // (the other path) a face that covers 2 000 pixels of a 1024^2 image takes 6 000 float atomics on the five cache lines of
+    // its 25 texels, sixteen lanes of a row often on the SAME address in one instruction.
+    float* s_gtex = s_tex + BATCH * (TEXLDS ? p.T * 3 : 0);                    // [BATCH][T*3] iff TEXLDS
     __shared__ unsigned long long s_has[BATCH];     // slot -> pixels (lanes) that hold the face
     __shared__ int s_ioff[CHUNK + 1];                // slot -> first work item (exclusive prefix), [64] = total
 
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TEXLDS ? (KC
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;      // k-th workgroup of its XCD
     const int nheavy = heavy_cap > 0 ? min((int)counters[3], heavy_cap) : 0;
     const int hx = (nheavy - xcd + 7) >> 3;                   // heavy bins dealt to this XCD (launch ranks xcd, xcd + 8, ...)
-    const int tl = 2 * p.sub_log2, tmask = (1 << tl) - 1;     // a bin has 1 << tl tiles
+    const int tl = 2 * sub_log2_of(p), tmask = (1 << tl) - 1;     // a bin has 1 << tl tiles
     int brank, sub, part = -1;
     if (k < (hx << tl) * SPLIT) { brank = ((k / SPLIT) >> tl) * 8 + xcd; sub = (k / SPLIT) & tmask; part = k % SPLIT; }
     else { const int k2 = k - (hx << tl) * SPLIT; brank = (hx + (k2 >> tl)) * 8 + xcd; sub = k2 & tmask; }   // bins are dealt round-robin to the XCDs ...
@@ -258,8 +263,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TEXLDS ? (KC
     const int b = bin / bins_per_img;
     const int bb = bin - b * bins_per_img;
     const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
-    const int col0 = (bx << p.bin_log2) + ((sub & ((1 << p.sub_log2) - 1)) << TILE_LOG2);
-    const int row0 = (by << p.bin_log2) + ((sub >> p.sub_log2) << TILE_LOG2);
+    const int col0 = (bx << bin_log2_of(p)) + ((sub & ((1 << sub_log2_of(p)) - 1)) << TILE_LOG2);
+    const int row0 = (by << bin_log2_of(p)) + ((sub >> sub_log2_of(p)) << TILE_LOG2);
     if (col0 >= p.IS || row0 >= p.IS) return;
 
     // Work items are (face, up to 16 of its holders) and the 16 lanes of a DPP row take one.  (Half rows of 8 were built and
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TEXLDS ? (KC
                 if (slot < fill) {
                     const float* src = tbase + (size_t)id * t3;
                     float* dst = s_tex + slot * t3;
-                    for (int k = l16; k < t3; k += 16) dst[k] = src[k];
+                    float* gdst = s_gtex + slot * t3;
+                    for (int k = l16; k < t3; k += 16) { dst[k] = src[k]; gdst[k] = 0.f; }
                 }
             }
         }
@@ -465,8 +471,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TEXLDS ? (KC
                 const int texel = (face_safe(fr.meta) && p.consts_safe)
                     ? backward_pair<DIST, RGB, true>(p, fr, vc, tb, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters)
                     : backward_pair<DIST, RGB, false>(p, fr, vc, tb, q, qx, qy, tbase, gv, wcw, tgs, tex_on, counters);
-                if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: straight to global
-                    float* gtf = gtbase + (size_t)face_id(fr.meta) * p.T * 3;
+                if (tex_on && p.tex == 0 && p.T != 1) {      // per-pixel texel: into the batch's LDS sums (TEXLDS) or straight to global
+                    float* gtf = TEXLDS ? s_gtex + jc * (p.T * 3) : gtbase + (size_t)face_id(fr.meta) * p.T * 3;
                     const float c0 = tgs * q.g0, c1 = tgs * q.g1, c2 = tgs * q.g2;
                     atomicAdd(gtf + texel * 3 + 0, c0);
                     atomicAdd(gtf + texel * 3 + 1, c1);
@@ -525,6 +531,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TEXLDS ? (KC
             clk.lap(5);
         }
         if (RANGES && !(JR_TUNE_DIAG & 32)) flush();
+        if (TEXLDS) {            // the batch's texel sums leave: one global atomic per touched component, 16 lanes per slot as in the staging
+            __syncthreads();
+            const int t3 = p.T * 3, sub = lane >> 4, l16 = lane & 15;
+            for (int s0 = 0; s0 < fill; s0 += 4) {
+                const int slot = s0 + sub;
+                const int id = __builtin_amdgcn_ds_bpermute((slot < fill ? slot : 0) << 2, myid);
+                if (slot < fill) {
+                    float* dst = gtbase + (size_t)id * t3;
+                    const float* src = s_gtex + slot * t3;
+                    for (int k = l16; k < t3; k += 16) {
+                        const float v = src[k];
+                        if (v != 0.f) atomicAdd(dst + k, v);           // (a NaN sum compares unequal to zero: the poison leaves too)
+                    }
+                }
+            }
+        }
         __syncthreads();                        // the batch's records and tables are free again
     }
     clk.lap(1);
@@ -535,7 +557,7 @@ template <int DIST, int RGB>
 static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const float* textures,
                      const BinWorkspace& ws, const float* rgba, const float* aggrs, const int32_t* ids,
                      const float* grad_rgba, float* grad_faces, float* grad_textures) {
-    const int tl = 2 * p.sub_log2;
+    const int tl = 2 * sub_log2_of(p);
     const int nbins = ntiles >> tl;
     // heavy bins' tiles by tune::bwd_split wavefronts each when the launch is too small to fill the GPU anyway
     const int heavy_cap = backward_splits_heavy_tiles(p, ws) ? heavy_bins_cap(ws, nbins) : 0;   // (bound of counters[3], as in the forward)
@@ -544,7 +566,7 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
     const int tex_lds = (p.tex == 0 && p.T > 1 && p.T <= tune::bwd_tex_lds_max && RGB == 1 &&
                          (long)p.B * p.IS * p.IS <= (long)tune::bwd_tex_lds_pixels) ? 1 : 0;
     const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0) +
-                        (tex_lds ? sizeof(float) * 3 * p.T * tune::bwd_batch : 0);
+                        (tex_lds ? sizeof(float) * 2 * 3 * p.T * tune::bwd_batch : 0);      // texel colours + texel gradient sums
 #define JR_BWD_K(KC, TL) \
     k_softras_backward<DIST, RGB, KC, TL><<<grid, 64, smem, st>>>( \
         p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba, \
@@ -585,7 +607,7 @@ void launch_softras_backward(hipStream_t st, const RasterParams& p, const float*
                              const float* rgba, const float* aggrs, const int32_t* ids,
                              const float* grad_rgba, const BinWorkspace& ws, float* grad_faces,
                              float* grad_textures) {
-    const int ntiles = (p.B * p.bins_x * p.bins_y) << (2 * p.sub_log2);
+    const int ntiles = (p.B * p.bins_x * p.bins_y) << (2 * sub_log2_of(p));
     {                                                                                           // SRK:1374-1375
         const size_t na = (size_t)p.B * p.NF * 9, nb = (size_t)p.B * p.NF * p.T * 3;
         const size_t wgs = ((na + nb) / 4 + 255) / 256;

@@ -403,9 +403,11 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
 
 // wavefronts per SIMD asked of the register allocator: K <= 16: the single-wavefront kernel fits 96 VGPRs (5), the
 // four-wavefront one 128 (4); K <= 32: 168 (3); K <= 64: 256 (2) - all without scratch
-constexpr int fwd_waves(int kcap, bool mixed) {
+constexpr int fwd_waves(int kcap, bool mixed, int rgb = 1) {
+    // ('hard' rgb at K <= 64 keeps depth_min / face_min / the colour next to 64 K-buffer depths: 12 - 16 B of scratch at three
+    //  wavefronts per SIMD, none at two - VERDICT r4 next #6)
     return kcap <= 16 ? (mixed ? 4 : tune::fwd_waves16)
-                      : (kcap <= 32 ? (mixed ? 3 : tune::fwd_waves32) : (mixed ? 2 : tune::fwd_waves64));   // (the four-wavefront kernel spills at one more)
+                      : (kcap <= 32 ? (mixed ? 3 : tune::fwd_waves32) : (mixed || rgb == 0 ? 2 : tune::fwd_waves64));   // (the four-wavefront kernel spills at one more)
 }
 
 // LDS hand-over inside ONE wavefront (writes by some lanes, reads by others): LDS instructions of a wavefront
@@ -428,14 +430,15 @@ struct TileGeom {
     float xp, yp;                       // its centre in NDC (SRK:280-283)
 };
 
-__device__ inline bool tile_geom(const RasterParams& p, int bin, int sub, int n, int lane, TileGeom& t) {
+__device__ inline bool tile_geom(const RasterParams& p, int bin, int sub, int n, int lane, TileGeom& t, int bl) {      // bl = log2 of the bin size (a constant in the headline kernel)
     const int bins_per_img = p.bins_x * p.bins_y;
     t.bin = bin; t.sub = sub; t.n = n;
     t.b = bin / bins_per_img;
     const int bb = bin - t.b * bins_per_img;
     const int by = bb / p.bins_x, bx = bb - by * p.bins_x;
-    const int col0 = (bx << p.bin_log2) + ((sub & ((1 << p.sub_log2) - 1)) << TILE_LOG2);
-    const int row0 = (by << p.bin_log2) + ((sub >> p.sub_log2) << TILE_LOG2);
+    const int sl = bl - TILE_LOG2;
+    const int col0 = (bx << bl) + ((sub & ((1 << sl) - 1)) << TILE_LOG2);
+    const int row0 = (by << bl) + ((sub >> sl) << TILE_LOG2);
     if (col0 >= p.IS || row0 >= p.IS) return false;      // tile lies outside the image
     t.col = col0 + (lane & 7); t.row = row0 + (lane >> 3);
     t.valid = t.col < p.IS && t.row < p.IS;
@@ -529,10 +532,10 @@ __device__ inline void store_empty_bin_t(const RasterParams& p, int bin, int lan
     }
 }
 template <int RGB, int KCAP>
-__device__ inline void store_empty_bin(const RasterParams& p, int bin, int lane,
+__device__ inline void store_empty_bin(const RasterParams& p, int bin, int lane, int bl,
                                        float* __restrict__ aggrs, float* __restrict__ rgba, int32_t* __restrict__ ids) {
-    if (p.bin_log2 == 5) store_empty_bin_t<RGB, KCAP, 5>(p, bin, lane, aggrs, rgba, ids);
-    else if (p.bin_log2 == 4) store_empty_bin_t<RGB, KCAP, 4>(p, bin, lane, aggrs, rgba, ids);
+    if (bl == 5) store_empty_bin_t<RGB, KCAP, 5>(p, bin, lane, aggrs, rgba, ids);
+    else if (bl == 4) store_empty_bin_t<RGB, KCAP, 4>(p, bin, lane, aggrs, rgba, ids);
     else store_empty_bin_t<RGB, KCAP, 3>(p, bin, lane, aggrs, rgba, ids);
 }
 template <int KCAP, bool WRITTEN_THROUGH, class KB>
@@ -1491,8 +1494,12 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
 
 // ---- kernels -----------------------------------------------------------------------------------------------------------
 // One wavefront per workgroup, one tile per wavefront (rounds 1-2; tune::fwd_heavy = 0, and vertex colours).
-template <int DIST, int RGB, int KCAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP, false)))) void k_softras_forward(
+// BL: log2 of the bin size as a COMPILE-TIME constant (5: the headline batch and every launch above 4 Mpixels under the
+// automatic policy), or 0 = read it from the launch parameters.  Round 5 measured what the run-time value costs this kernel:
+// forward 0.841 -> 0.878 ms on the headline batch (same-box A/B against a build with the constant, profiles/r05_experiments.md
+// call 5) - two more scalars live across a kernel that already spills SGPRs into VGPR lanes.
+template <int DIST, int RGB, int KCAP, int BL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP, false, RGB)))) void k_softras_forward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,
@@ -1503,17 +1510,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     // XCD-aware order: consecutive workgroup ids land on different XCDs (id % 8); the tiles of a
     // bin (same list, same records) go to ONE XCD so that they share its L2.
     const int k = blockIdx.x >> 3;                       // k-th workgroup of XCD (blockIdx.x & 7)
-    const int tl = 2 * p.sub_log2, tmask = (1 << tl) - 1; // a bin has 1 << tl tiles
+    const int bl = BL ? BL : bin_log2_of(p);
+    const int tl = 2 * (bl - TILE_LOG2), tmask = (1 << tl) - 1; // a bin has 1 << tl tiles
     const int brank = (k >> tl) * 8 + (blockIdx.x & 7);  // bins are dealt round-robin to the XCDs ...
     if ((brank << tl) >= ntiles_total) return;
     const int bin = bin_order[brank];                    // ... heaviest first (k_bin_alloc_schedule)
     const int n = bin_count[bin];
-    if (tune::fwd_empty_bins && n == 0 && (p.IS & ((1 << p.bin_log2) - 1)) == 0) {    // empty bin: tile 0's wavefront writes all its tiles
-        if ((k & tmask) == 0) store_empty_bin<RGB, KCAP>(p, bin, threadIdx.x, aggrs, rgba, ids);
+    if (tune::fwd_empty_bins && n == 0 && (p.IS & ((1 << bl) - 1)) == 0) {    // empty bin: tile 0's wavefront writes all its tiles
+        if ((k & tmask) == 0) store_empty_bin<RGB, KCAP>(p, bin, threadIdx.x, bl, aggrs, rgba, ids);
         return;
     }
     TileGeom t;
-    if (!tile_geom(p, bin, k & tmask, n, threadIdx.x, t)) return;
+    if (!tile_geom(p, bin, k & tmask, n, threadIdx.x, t, bl)) return;
     tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
 }
 
@@ -1535,7 +1543,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fwd_wav
     const int nheavy = min((int)counters[3], heavy_cap);
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const int hx = (nheavy - xcd + 7) >> 3;              // heavy bins dealt to this XCD (launch ranks xcd, xcd + 8, ...)
-    const int tl = 2 * p.sub_log2, tmask = (1 << tl) - 1; // a bin has 1 << tl tiles
+    const int bl = bin_log2_of(p);
+    const int tl = 2 * (bl - TILE_LOG2), tmask = (1 << tl) - 1; // a bin has 1 << tl tiles
     const bool heavy = k < (hx << tl);
     int brank, sub;
     if (heavy) { brank = (k >> tl) * 8 + xcd; sub = k & tmask; }
@@ -1543,12 +1552,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fwd_wav
     if (brank >= nbins) return;
     const int bin = bin_order[brank];
     const int n = bin_count[bin];
-    if (tune::fwd_empty_bins && n == 0 && (p.IS & ((1 << p.bin_log2) - 1)) == 0) {    // empty bin (never heavy): the wavefront that holds its tile 0
-        if (sub == 0) store_empty_bin<RGB, KCAP>(p, bin, lane, aggrs, rgba, ids);
+    if (tune::fwd_empty_bins && n == 0 && (p.IS & ((1 << bl) - 1)) == 0) {    // empty bin (never heavy): the wavefront that holds its tile 0
+        if (sub == 0) store_empty_bin<RGB, KCAP>(p, bin, lane, bl, aggrs, rgba, ids);
         return;
     }
     TileGeom t;
-    if (!tile_geom(p, bin, sub, n, lane, t)) return;     // (a heavy tile: uniform for the workgroup)
+    if (!tile_geom(p, bin, sub, n, lane, t, bl)) return;     // (a heavy tile: uniform for the workgroup)
     const unsigned long long* seg = pool + bin_base[bin];
     if ((JR_TUNE_DIAG & 512) && !heavy) return;          // (diagnostic bits 9 / 10, WRONG images: the makespan of the heavy / of the light tiles alone)
     if ((JR_TUNE_DIAG & 1024) && heavy) return;
@@ -1574,7 +1583,7 @@ template <int DIST, int RGB, int KCAP>
 static void launch_kk(hipStream_t st, const RasterParams& p, const float* textures,
                       const BinWorkspace& ws, float* aggrs, float* rgba, int32_t* ids) {
     const int nbins = p.B * p.bins_x * p.bins_y;
-    const int tl = 2 * p.sub_log2;                   // a bin has 1 << tl tiles
+    const int tl = 2 * sub_log2_of(p);                   // a bin has 1 << tl tiles
     const int ntiles = nbins << tl;
     // Four wavefronts per heavy tile cut the critical path of a launch (one 39k-face view: 0.69 -> 0.38 ms), but the
     // waiting wavefronts hold slots that a full GPU has better uses for (eight views: 0.89 -> 0.98 ms even when only the
@@ -1621,8 +1630,12 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
     // JR_FWD_LDS_PAD (bytes, diagnostics only): more dynamic LDS per wavefront = fewer wavefronts per CU
     static const size_t pad = getenv("JR_FWD_LDS_PAD") ? (size_t)atol(getenv("JR_FWD_LDS_PAD")) : 0;
     const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0) + pad;
-    k_softras_forward<DIST, RGB, KCAP><<<grid, 64, smem, st>>>(
-        p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+    if (bin_log2_of(p) == 5)
+        k_softras_forward<DIST, RGB, KCAP, 5><<<grid, 64, smem, st>>>(
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
+    else
+        k_softras_forward<DIST, RGB, KCAP, 0><<<grid, 64, smem, st>>>(
+            p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
 }
 
 template <int DIST, int RGB>

@@ -199,3 +199,20 @@ def test_backward_never_reuses_stale_face_records(ctx):
     _raw_forward(ctx, lib, args, other, tex_d, B, NF, IS, K)
     assert grad_err(backward(savedB, 0), refs["B"]) <= 1e-4
     assert grad_err(backward(savedB, tokB), refs["B"]) <= 1e-4            # stale token: rebuilt, still right
+
+
+def test_bench_dry_run_ranks_goes_up_to_the_communicator_on_one_gpu():
+    """VERDICT r4 next #7a: `bench.py --dry-run-ranks 4` on this 1-GPU box - four ranks, launcher, private rendezvous, rank 0's
+    ncclGetUniqueId read back identically by the other three, HSA_ENABLE_IPC_MODE_LEGACY=0 in every rank, device mapping, the
+    exchange buffers of the headline configuration allocated (16.8 MB image shard, 134 MB gathered batch, 234 KB vertex
+    gradient) - everything an 8-GPU start-up does except ncclCommInitRank itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-ranks", "4"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["dry_run"] and line["ok"] and line["n_ranks"] == 4 and not line["problems"]
+    assert len(line["ranks"]) == 4 and len({r["id_sha256"] for r in line["ranks"]}) == 1 and len({r["pid"] for r in line["ranks"]}) == 4
+    assert all(r["ipc_mode_legacy"] == "0" and r["world"] == 4 for r in line["ranks"])
+    assert line["payload_bytes"]["allreduce_vertex_grads"] == 234024 and line["payload_bytes"]["allgather_images_send"] == 8 * 4 * 1024 * 1024 * 4
+    assert line["stopped_before"].startswith("jr_comm_create")

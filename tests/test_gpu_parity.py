@@ -202,8 +202,9 @@ def test_crowded_bin(ctx, port):
     tex = rng.uniform(0, 1, (1, n, 1, 3)).astype(np.float32)
     # sigma large enough that every face's border box reaches a pixel centre (the lists are exact: a face
     # whose box falls between the centres is not listed at all)
-    ref, fn = run_case(ctx, port, fv, tex, image_size=32, sigma_val=3e-4)
-    assert ctx.last_stats()["max_faces_in_bin"] > 4096
+    with ctx.bin_size_scope(32):              # (one 32-pixel bin = the whole image lists every face: the sort fall-back for > 4096 entries)
+        ref, fn = run_case(ctx, port, fv, tex, image_size=32, sigma_val=3e-4)
+        assert ctx.last_stats()["max_faces_in_bin"] > 4096
 
 
 def test_degenerate_faces_do_not_break_parity(ctx, port):

@@ -70,7 +70,7 @@ def census(ins):
 
 
 def main():
-    blocks = blocks_of("k_softras_forwardILi2ELi1ELi16")
+    blocks = blocks_of("k_softras_forwardILi2ELi1ELi16ELi5")
     count = lambda ins, key: sum(1 for i in ins if i.startswith(key))        # noqa: E731
     # the raster loop's head: the block that fetches the pixel's next face slot (ds_read) and carries the per-trip copies
     # of the live state (>= 8 plain v_mov); the code is emitted twice (FAST faces / the rest), the first copy is the FAST one

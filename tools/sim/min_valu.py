@@ -37,7 +37,7 @@ SRC = os.path.join(ROOT, "jrender_amd", "csrc", "softras_forward.hip")
 ASM = os.environ.get("MIN_VALU_ASM", "/tmp/min_valu_forward.s")
 COUNTS = os.path.join(ROOT, "profiles", "r05_path_counts.json")
 OUT = os.path.join(ROOT, "profiles", "min_valu_latest.json")
-KERNEL = "k_softras_forwardILi2ELi1ELi16"
+KERNEL = "k_softras_forwardILi2ELi1ELi16ELi5"
 CHEAP = ("v_mov_b32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32",
          "v_add_u32", "v_sub_u32", "v_and_b32")
 SLOW = ("v_rcp_f32", "v_exp_f32", "v_sqrt_f32", "v_rsq_f32", "v_log_f32")
