@@ -157,6 +157,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     if (JR_TUNE_PROFILE_SECTIONS == 3 && (threadIdx.x & 63) == 0) clk.flush0(counters, 4);
 }
 
+template <int U>
 __global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4* __restrict__ face_rect,
                                                   const int* __restrict__ bin_base,
                                                   int* __restrict__ bin_cursor,
@@ -179,11 +180,10 @@ __global__ __launch_bounds__(256) void k_bin_fill(RasterParams p, const ushort4*
     const int sl = p.sub_log2, subs = 1 << sl;             // tiles per bin side: 1, 2 or 4
     int cx = 0, cy = 0;
     if (tune::profile_sections) { asm volatile("" :: "v"(nb)); clk.lap(0); }
-    // FOUR bins of every face per pass (round 5): the matching is ALU work, the four cursor bumps and the four segment-base
+    // U = 4 bins of every face per pass (round 5; small launches and sub-32-pixel bins): the matching is ALU work, the four cursor bumps and the four segment-base
     // loads are independent memory operations that travel together - a pass costs one round trip instead of four (a single
     // view's launch is ~600 wavefronts with nothing to hide a chain of round trips behind; with 8-pixel bins a face reaches
     // 3 - 9 bins instead of 1 - 2).
-    constexpr int U = 4;
     for (int it0 = 0; ballot(it0 < nb) != 0; it0 += U) {
         int t[U], leader[U], rank[U], base[U], seg[U];
         unsigned mask[U];
@@ -439,7 +439,11 @@ void launch_bin_fill_sort(hipStream_t st, const RasterParams& p, BinWorkspace& w
     const unsigned long long cap = ws.pool_cap;
     // k_bin_alloc_schedule left the cursors at zero; only a second attempt (after the pool grew) has to clear them
     if (reset_cursors) (void)hipMemsetAsync(ws.bin_cursor, 0, sizeof(int) * (size_t)nbins, st);
-    k_bin_fill<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.bin_base, ws.bin_cursor, ws.pool_scratch,
+    // Four bins per pass pay where a face reaches many bins (8/16-pixel bins) or the launch is too small to hide a chain of
+    // round trips (one view); on the headline batch (312k faces, 32-pixel bins, 1 - 2 bins per face, 4 900 wavefronts that
+    // hide each other's latency) the extra slots are pure bookkeeping: 35 -> 54 us measured, so that shape keeps one.
+    const bool unroll4 = bin_log2_of(p) < 5 || nfaces <= tune::bin_fill_unroll_max_faces;
+    (unroll4 ? k_bin_fill<4> : k_bin_fill<1>)<<<(nfaces + 255) / 256, 256, 0, st>>>(p, ws.face_rect, ws.bin_base, ws.bin_cursor, ws.pool_scratch,
                                                      ws.counters, cap);
     if (p.NF <= BITMAP_MAX_FACES) {
         const size_t lds = sizeof(unsigned) * 2 * (size_t)((p.NF + 31) >> 5);

@@ -54,6 +54,9 @@
 #ifndef JR_TUNE_FWD_HEAVY16_SMALL_MESH
 #define JR_TUNE_FWD_HEAVY16_SMALL_MESH 64
 #endif
+#ifndef JR_TUNE_BIN_FILL_UNROLL_MAX_FACES   // k_bin_fill: launches of up to this many faces (batch x mesh) append 4 bins per pass at 32-pixel bins too
+#define JR_TUNE_BIN_FILL_UNROLL_MAX_FACES 65536
+#endif
 #ifndef JR_TUNE_SMALL_MESH_FACES
 #define JR_TUNE_SMALL_MESH_FACES 10000
 #endif
@@ -102,27 +105,12 @@
 #ifndef JR_TUNE_FWD_PIPE_CONSUMER_TASKS   // pipelined heavy tile: which applying wavefronts also take evaluate / mask tasks once their apply is done (bit 0: the K-buffer wavefront, bit 1: the colour wavefront)
 #define JR_TUNE_FWD_PIPE_CONSUMER_TASKS 3
 #endif
-#ifndef JR_TUNE_FWD_MIXED8_LDS_PAD  // diagnostics: bytes of dynamic LDS added to the eight-wavefront workgroup (16384: one workgroup per CU instead of two)
-#define JR_TUNE_FWD_MIXED8_LDS_PAD 0
-#endif
-#ifndef JR_TUNE_FWD_PIPE_K4        // eight-wavefront pipeline: the K-buffer of a pixel spread over the four lanes of a quad, four wavefronts own 16 pixels each (0: one wavefront, 64 pixels, KCAP registers per lane)
-#define JR_TUNE_FWD_PIPE_K4 0
-#endif
-#ifndef JR_TUNE_FWD_PIPE_COLOUR_SW   // pipelined heavy tile: the colour wavefront's loop software-pipelined (front of cell k + 1 - running maximum, exponential - before the sums of cell k)
-#define JR_TUNE_FWD_PIPE_COLOUR_SW 0
-#endif
-#ifndef JR_TUNE_FWD_PIPE_IDLE_MASK   // pipelined heavy tile: wavefronts (bit = index, >= 2) that take NO evaluate / mask tasks: e.g. 0x30 leaves the K-buffer and the colour wavefront's SIMDs to them (wavefront i runs on SIMD i % 4)
-#define JR_TUNE_FWD_PIPE_IDLE_MASK 0
-#endif
-#ifndef JR_TUNE_FWD_PIPE_PRIO     // pipelined heavy tile: s_setprio 3 for the two applying wavefronts while they apply (the per-pixel sequential chain is the tile's critical path)
-#define JR_TUNE_FWD_PIPE_PRIO 0
-#endif
 #ifndef JR_TUNE_FWD_HEAVY_PIXELS // forward: launches of up to this many pixels (B x IS x IS) use the four-wavefront kernel, larger ones one wavefront per tile
 #define JR_TUNE_FWD_HEAVY_PIXELS 4194304
 #endif
 #ifndef JR_TUNE_DIAG             // diagnostic builds (WRONG results): bit 0 skips the forward's softmax update, bit 1 the K-buffer insert;
                                  // backward: bit 2 no three-projection path, bit 3 no n-th-holder search, bit 4 no row reduction, bit 5 no atomics, bit 7 atomics as plain stores, bit 8 no gathers;
-                                 // multi-wavefront forward: bit 9 heavy tiles only, bit 10 light tiles only, bit 13 cells without the evaluate arithmetic
+                                 // multi-wavefront forward: bit 9 heavy tiles only, bit 10 light tiles only
 #define JR_TUNE_DIAG 0
 #endif
 #ifndef JR_TUNE_BWD_ROW_RANGES   // backward: a row takes a contiguous quarter of the work items and adds up consecutive items of one face before its atomic
@@ -191,9 +179,6 @@
 #define JR_TUNE_PROFILE_SECTIONS 0
 #endif
 
-#ifndef JR_TUNE_FIXED_BIN32       // diagnostics: 32-pixel bins as a compile-time constant in the raster kernels (the library must then be used with bin size 32 only)
-#define JR_TUNE_FIXED_BIN32 0
-#endif
 #ifndef JR_TUNE_COUNT_PATHS       // instrumented build: trips and lanes per region of the forward's raster loop (tools/sim/min_valu.py --measure)
 #define JR_TUNE_COUNT_PATHS 0
 #endif
@@ -206,7 +191,6 @@ namespace tune {
 constexpr int sections_wave = JR_TUNE_SECTIONS_WAVE;
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
 constexpr bool count_paths = JR_TUNE_COUNT_PATHS != 0;
-constexpr bool fixed_bin32 = JR_TUNE_FIXED_BIN32 != 0;
 constexpr bool n3_pixmap_all = JR_TUNE_N3_PIXMAP_ALL != 0;
 constexpr int n3_xcd_group = JR_TUNE_N3_XCD_GROUP;
 constexpr int n3_walks = JR_TUNE_N3_WALKS;
@@ -224,11 +208,6 @@ constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
 constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;
 constexpr bool fwd_heavy_pipe = JR_TUNE_FWD_HEAVY_PIPE != 0;
 constexpr int fwd_pipe_consumer_tasks = JR_TUNE_FWD_PIPE_CONSUMER_TASKS;
-constexpr bool fwd_pipe_prio = JR_TUNE_FWD_PIPE_PRIO != 0;
-constexpr bool fwd_pipe_colour_sw = JR_TUNE_FWD_PIPE_COLOUR_SW != 0;
-constexpr bool fwd_pipe_k4 = JR_TUNE_FWD_PIPE_K4 != 0;
-constexpr int fwd_mixed8_lds_pad = JR_TUNE_FWD_MIXED8_LDS_PAD;
-constexpr int fwd_pipe_idle_mask = JR_TUNE_FWD_PIPE_IDLE_MASK;
 constexpr int fwd_heavy_waves = JR_TUNE_FWD_HEAVY_WAVES;
 constexpr int fwd_pipe8_cap = JR_TUNE_FWD_PIPE8_CAP, fwd_pipe8_batch = JR_TUNE_FWD_PIPE8_BATCH;
 constexpr int fwd_pipe_list_depth = JR_TUNE_FWD_PIPE_LIST_DEPTH;
@@ -248,6 +227,7 @@ constexpr bool fwd_fill_shift = JR_TUNE_FWD_FILL_SHIFT != 0;
 constexpr bool fwd_empty_bins = JR_TUNE_FWD_EMPTY_BINS != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY, fwd_heavy16 = JR_TUNE_FWD_HEAVY16, fwd_heavy8 = JR_TUNE_FWD_HEAVY8;
+constexpr int bin_fill_unroll_max_faces = JR_TUNE_BIN_FILL_UNROLL_MAX_FACES;
 constexpr int fwd_heavy16_small_mesh = JR_TUNE_FWD_HEAVY16_SMALL_MESH, small_mesh_faces = JR_TUNE_SMALL_MESH_FACES;
 constexpr long fwd_heavy_waves8_budget_small = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET_SMALL, fwd_waves8_small_pixels = JR_TUNE_FWD_WAVES8_SMALL_PIXELS;
 constexpr int auto_bin8_max_image = JR_TUNE_AUTO_BIN8_MAX_IMAGE, auto_bin16_max_image = JR_TUNE_AUTO_BIN16_MAX_IMAGE;

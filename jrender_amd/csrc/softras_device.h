@@ -56,10 +56,8 @@ struct RasterParams {
     int consts_safe;
 };
 
-// (diagnostic builds: JR_TUNE_FIXED_BIN32 makes the raster kernels' bin geometry a compile-time constant again, to price what
-// the run-time shifts cost the headline kernels)
-__host__ __device__ inline int bin_log2_of(const RasterParams& p) { return tune::fixed_bin32 ? 5 : p.bin_log2; }
-__host__ __device__ inline int sub_log2_of(const RasterParams& p) { return tune::fixed_bin32 ? 2 : p.sub_log2; }
+__host__ __device__ inline int bin_log2_of(const RasterParams& p) { return p.bin_log2; }
+__host__ __device__ inline int sub_log2_of(const RasterParams& p) { return p.sub_log2; }
 
 constexpr int FLAG_FRONT = 1;    // check_face_frontside (SRK:37-40)
 constexpr int FLAG_SAFE = 2;     // per-face divisors/operands inside the fast-division range

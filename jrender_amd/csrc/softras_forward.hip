@@ -151,78 +151,6 @@ struct KBuffer {
     }
 };
 
-// ---- the K-buffer of ONE pixel spread over the FOUR lanes of a quad (eight-wavefront pipeline of a heavy tile; built in round 4,
-// in the product since round 5 together with the lighter colour chain) ----
-// In tile_heavy_pipe the K-buffer wavefront walks the cells of its 64 pixels in lockstep, and a trip in which ANY pixel replaces
-// costs the whole replace + rescan (~100 VALU instructions; 305 of the heaviest tile's 421 trips).  Here a wavefront owns 16
-// pixels, lane = (pixel, quarter), and each lane keeps KCAP / 4 depth slots (slot s lives in lane quarter s / R, register
-// s % R): the write touches R registers instead of KCAP, the rescan is a local maximum plus two quad_perm exchanges of
-// (depth, slot) - first maximum wins, i.e. the larger depth, on a tie the lower slot, exactly the reference's strict '>' scan
-// from -1 (SRK:379-385) - and four such wavefronts share the tile's pixels.  The four lanes of a quad read the same cell and
-// hold the same size / max_z / max_slot: they never diverge from each other.
-template <int KCAP>
-struct KBuffer4 {
-    static constexpr int R = KCAP / 4;
-    float z[R];
-    int32_t* gplane;
-    unsigned goff, gstride;
-    int size, max_slot, quarter;
-    float max_z;
-    __device__ inline void init(int32_t* plane0, unsigned pixel, unsigned stride, int quarter_) {
-        gplane = plane0; goff = pixel; gstride = stride; quarter = quarter_;
-#pragma unroll
-        for (int i = 0; i < R; i++) z[i] = -__builtin_inff();      // never the maximum, never equal to one
-        size = 0; max_z = -1.f; max_slot = -1;
-    }
-    template <int CTRL>
-    __device__ static inline float xf(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false)); }
-    template <int CTRL>
-    __device__ static inline int xi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-    __device__ inline void rescan() {
-        float m = z[0];
-#pragma unroll
-        for (int i = 1; i < R; i++) m = fmaxf(m, z[i]);                     // (NaN depths are skipped, like the reference's compare)
-        int li = 0;
-#pragma unroll
-        for (int i = R - 1; i >= 0; i--) li = z[i] == m ? i : li;           // first register that holds it
-        int sl = quarter * R + li;
-        if (!(m > -1.f)) { m = -1.f; sl = 0x7fffffff; }                     // nothing above the scan's start value here
-        {   const float m2 = xf<0xB1>(m); const int s2 = xi<0xB1>(sl);      // quad_perm [1,0,3,2]
-            const bool take = m2 > m || (m2 == m && s2 < sl);
-            m = take ? m2 : m; sl = take ? s2 : sl; }
-        {   const float m2 = xf<0x4E>(m); const int s2 = xi<0x4E>(sl);      // quad_perm [2,3,0,1]
-            const bool take = m2 > m || (m2 == m && s2 < sl);
-            m = take ? m2 : m; sl = take ? s2 : sl; }
-        max_z = m;
-        if (m > -1.f) max_slot = sl;                                        // else: the slot variable stays where it was (SRK:379-385)
-    }
-    __device__ inline void insert(int fn, float zp, int K) {
-        const bool filling = size < K;
-        if (!filling && !(zp < max_z)) return;
-        const int slot = filling ? size : max_slot;
-        if (slot < 0) return;                                               // (the reference indexes slot -1 here: undefined behaviour)
-        if (quarter == (int)((unsigned)slot / (unsigned)R)) {
-            const int r = (int)((unsigned)slot % (unsigned)R);
-#pragma unroll
-            for (int i = 0; i < R; i++) z[i] = i == r ? zp : z[i];
-            gplane[(unsigned)slot * gstride + goff] = fn;
-        }
-        if (filling) {
-            if (zp > max_z) { max_z = zp; max_slot = size; }
-            size++;
-        } else rescan();
-    }
-    // the slots that were never filled get their -1 (the filled ones were stored when they were filled)
-    __device__ inline void store_rest(int K, bool valid) const {
-        if (!valid) return;
-#pragma unroll
-        for (int i = 0; i < R; i++) {
-            const int slot = quarter * R + i;
-            if (slot < K && slot >= size) gplane[(unsigned)slot * gstride + goff] = -1;
-        }
-    }
-};
-
 template <int KCAP>
 struct PixelState {                 // SRK:291-309
     float c0, c1, c2, alpha, ssum, smax, depth_min;
@@ -956,57 +884,6 @@ __device__ inline void apply_colour(const RasterParams& p, const float4 cell, co
     }
 }
 
-// The same colour half cut in two for a software-pipelined loop (tune::fwd_pipe_colour_sw, round 5).  The chain of a cell was
-// cell -> colour read -> x = zn - smax -> v_exp -> selects -> FMAs, every link waiting for the one before in a wavefront that
-// shares its SIMD with three others.  But the exponential only needs the RUNNING MAXIMUM before the cell - one v_max per cell -
-// not the sums: colour_front (flags, colour read, running maximum, exponential, the two selects) of cell k + 1 is issued
-// before colour_back (alpha, the five FMAs of the sums) of cell k, two independent instruction streams for the issue logic
-// to interleave.  Operation by operation the same arithmetic in the same per-pixel order as apply_colour: the same bits.
-struct ColourFront { float D, zp, ed, ez, k0, k1, k2; unsigned aux; int fn; bool use; };
-template <int RGB>
-__device__ inline ColourFront colour_front(const RasterParams& p, const float4 cell, const float* s_col, const int* s_meta,
-                                           const float* __restrict__ tbase, float& smax) {
-    ColourFront c;
-    c.aux = __builtin_bit_cast(unsigned, cell.w);
-    c.D = cell.z; c.zp = cell.x; c.ed = 1.f; c.ez = 1.f; c.k0 = 0.f; c.k1 = 0.f; c.k2 = 0.f; c.fn = 0;
-    c.use = RGB != 2 && (c.aux & (CELL_LIVE | CELL_DEPTH | CELL_FRONT)) == (CELL_LIVE | CELL_DEPTH | CELL_FRONT) &&
-            (RGB != 0 || (c.aux & CELL_INCLOSED));
-    if (c.use) {
-        if (p.T == 1) { const float* col = s_col + (c.aux & CELL_SLOT) * 3; c.k0 = col[0]; c.k1 = col[1]; c.k2 = col[2]; }
-        if (p.T != 1 || RGB == 0) c.fn = face_id(s_meta[c.aux & CELL_SLOT]);
-        if (p.T != 1) {
-            const float* tx_ = tbase + ((size_t)c.fn * p.T + (c.aux >> CELL_TEXEL_SHIFT)) * 3;
-            c.k0 = tx_[0]; c.k1 = tx_[1]; c.k2 = tx_[2];
-        }
-        if (RGB == 1) {
-            const float zn = cell.y;
-            const float x = zn - smax;
-            const bool up = x > 0.f;
-            const float e = exp_over_gamma<tune::fwd_exact>(-fabsf(x), p);
-            c.ed = up ? e : 1.f; c.ez = up ? 1.f : e;
-            smax = fmaxf(smax, zn);
-        }
-    }
-    return c;
-}
-template <int RGB, int KCAP>
-__device__ inline void colour_back(const RasterParams& p, const ColourFront& c, PixelState<KCAP>& s) {
-    if (!(c.aux & CELL_LIVE)) return;
-    if (p.alpha == 0) { if (c.aux & CELL_AHARD) s.alpha = 1.f; }
-    else if (p.alpha == 1) s.alpha += c.D;
-    else s.alpha = __builtin_fmaf(-s.alpha, c.D, s.alpha);
-    if (!c.use) return;
-    if (RGB == 0) {
-        if (c.zp < s.depth_min) { s.depth_min = c.zp; s.face_min = c.fn; s.c0 = c.k0; s.c1 = c.k1; s.c2 = c.k2; }
-    } else if (RGB == 1) {
-        const float t = c.ez * c.D;
-        s.ssum = __builtin_fmaf(c.ed, s.ssum, t);
-        s.c0 = __builtin_fmaf(c.ed, s.c0, t * c.k0);
-        s.c1 = __builtin_fmaf(c.ed, s.c1, t * c.k1);
-        s.c2 = __builtin_fmaf(c.ed, s.c2, t * c.k2);
-    }
-}
-
 template <int DIST, int RGB, int KCAP>
 __device__ inline void tile_heavy(const RasterParams& p, const TileGeom& t, int wid, int lane, float4* s_mem,
                                   const float* __restrict__ textures, const FaceGeo* __restrict__ geo,
@@ -1215,10 +1092,9 @@ constexpr int pipe_lds_bytes(int nw) {
 }
 // dynamic LDS of a workgroup: what nw single-wavefront tiles use, or the pipelined heavy tile if that is (a few hundred bytes) more
 constexpr int mixed_lds_bytes(int nw) {
-    return (nw * (int)sizeof(FaceRec) * HEAVY_BATCH > pipe_lds_bytes(nw) ? nw * (int)sizeof(FaceRec) * HEAVY_BATCH : pipe_lds_bytes(nw))
-           + (nw >= 8 ? tune::fwd_mixed8_lds_pad : 0);       // (diagnostics: more LDS = ONE eight-wavefront workgroup per CU)
+    return nw * (int)sizeof(FaceRec) * HEAVY_BATCH > pipe_lds_bytes(nw) ? nw * (int)sizeof(FaceRec) * HEAVY_BATCH : pipe_lds_bytes(nw);
 }
-static_assert(4 * mixed_lds_bytes(4) <= 160 * 1024 && (tune::fwd_mixed8_lds_pad > 0 || 2 * mixed_lds_bytes(8) <= 160 * 1024), "four / two workgroups per CU");
+static_assert(4 * mixed_lds_bytes(4) <= 160 * 1024 && 2 * mixed_lds_bytes(8) <= 160 * 1024, "four / two workgroups per CU");
 enum { PS_VALID = 0, PS_BATCH, PS_J0, PS_J1, PS_TOTAL, PS_LAST, PS_MASKS, PS_MBATCH, PS_MFILL, PS_CLAIM, PS_DONE, PS_WORDS = 16 };
 
 template <int DIST, int RGB, int KCAP, int NW>
@@ -1241,25 +1117,14 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
     const float xp = t.xp, yp = t.yp;
     const float* tbase = textures + (size_t)t.b * p.NF * p.T * 3;
     PixelState<KCAP> s;                                  // the K-buffer lives in wavefront 0, the colour state in wavefront 1
-    // tune::fwd_pipe_k4 (eight wavefronts): the K-buffer is spread over quads (KBuffer4) and FOUR wavefronts own 16 pixels each:
-    // wavefronts 0, 4, 5, 6 = pixel quarters 0 .. 3 (wavefront 1 colour, 3 stages / lists, 2 and 7 only take tasks)
-    constexpr bool K4 = NW == 8 && tune::fwd_pipe_k4;
-    const int kw = !K4 ? (wid == 0 ? 0 : -1) : (wid == 0 ? 0 : (wid >= 4 && wid <= 6 ? wid - 3 : -1));   // K-buffer owner index, -1: none
-    const int kpix = K4 ? 16 * max(kw, 0) + (lane >> 2) : lane;          // the pixel of the tile whose K-buffer this lane works on
-    KBuffer4<KCAP> q4;
-    bool kvalid = false;
     ListWalkerT<tune::fwd_pipe_list_depth> lw;   // wavefront 3 walks alone: several list chunks in flight
     SectionClock clk;            // instrumented builds only (wavefront tune::sections_wave): 0 barrier wait, 3 claimed tasks (wavefront 3: + staging / lists), 6 apply, 7 stores
     clk.start();
     if (wid == 1) init_colour_state<RGB>(p, s);
-    if (wid == 0) s_pix[lane] = make_float2(xp, yp);
-    if (K4) {
-        if (kw >= 0) {
-            const int col = t.col - (lane & 7) + (kpix & 7), row = t.row - (lane >> 3) + (kpix >> 3);
-            kvalid = col < p.IS && row < p.IS;
-            q4.init(ids + (size_t)t.b * p.K * p.IS * p.IS, kvalid ? (unsigned)(row * p.IS + col) : 0u, (unsigned)(p.IS * p.IS), lane & 3);
-        }
-    } else if (wid == 0) init_kbuffer(p, t, ids, s.q);
+    if (wid == 0) {
+        init_kbuffer(p, t, ids, s.q);
+        s_pix[lane] = make_float2(xp, yp);
+    }
     // ---- wavefront 3: staging and pair lists ----
     auto stage_batch = [&](int nb) -> int {
         FaceRec* rec = s_rec + (nb & 1) * BATCH;
@@ -1350,32 +1215,8 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
             if (st[PS_DONE] && !a_valid) break;
             if (wid == tune::sections_wave) clk.lap(0);
             // ---- apply round step-1: lane = pixel, K-buffer | colour ----
-            if (wid == 1 && a_valid && tune::fwd_pipe_colour_sw) {
-                // colour wavefront, software-pipelined: the cell two ahead is in flight, the front of the cell one ahead is
-                // issued while the current one updates the sums
+            if (wid <= 1 && a_valid) {
                 const int2 span = s_span[((step + 2) % 3) * 64 + lane];                        // (step - 1) % 3
-                const float4* cells = s_cell + ((step + 1) & 1) * CAP;
-                const float* colb = s_col + (a_batch & 3) * BATCH * 3;
-                const int* metab = s_meta + (a_batch & 3) * BATCH;
-                auto cell_at = [&](int k) {
-                    float4 c = cells[k < span.y ? span.x + k : 0];
-                    if (!(k < span.y)) c.w = 0.f;                                              // beyond the pixel's last cell: "not live"
-                    return c;
-                };
-                float smax = s.smax;
-                ColourFront cur = colour_front<RGB>(p, cell_at(0), colb, metab, tbase, smax);
-                float4 nxt = cell_at(1);
-                for (int k = 0; ballot(k < span.y) != 0ull; k++) {
-                    const float4 nn = cell_at(k + 2);
-                    const ColourFront nf = colour_front<RGB>(p, nxt, colb, metab, tbase, smax);
-                    colour_back<RGB, KCAP>(p, cur, s);
-                    cur = nf; nxt = nn;
-                }
-                s.smax = smax;
-                if (wid == tune::sections_wave) clk.lap(6);
-            } else if ((wid == 1 || kw >= 0) && a_valid) {
-                if (tune::fwd_pipe_prio) __builtin_amdgcn_s_setprio(3);     // the tile's critical chain: win the SIMD's issue arbitration against the task wavefronts
-                const int2 span = s_span[((step + 2) % 3) * 64 + (wid == 1 ? lane : kpix)];    // (step - 1) % 3
                 const float4* cells = s_cell + ((step + 1) & 1) * CAP;
                 const float* colb = s_col + (a_batch & 3) * BATCH * 3;
                 const int* metab = s_meta + (a_batch & 3) * BATCH;
@@ -1384,15 +1225,10 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                 for (int k = 0; ballot(k < span.y) != 0ull; k++) {
                     float4 nxt = cells[k + 1 < span.y ? span.x + k + 1 : 0];
                     if (!(k + 1 < span.y)) nxt.w = 0.f;
-                    if (wid == 1) apply_colour<RGB, KCAP>(p, cur, colb, metab, tbase, s);
-                    else if (K4) {
-                        const unsigned aux = __builtin_bit_cast(unsigned, cur.w);
-                        if (kvalid && (aux & (CELL_LIVE | CELL_DEPTH)) == (CELL_LIVE | CELL_DEPTH))
-                            q4.insert(face_id(metab[aux & CELL_SLOT]), cur.x, p.K);
-                    } else apply_kbuf(p, cur, metab, s.q);
+                    if (wid == 0) apply_kbuf(p, cur, metab, s.q);
+                    else apply_colour<RGB, KCAP>(p, cur, colb, metab, tbase, s);
                     cur = nxt;
                 }
-                if (tune::fwd_pipe_prio) __builtin_amdgcn_s_setprio(0);
                 if (wid == tune::sections_wave) clk.lap(6);
             }
             // ---- wavefront 3: the batch after, the next round's list, the next step's state ----
@@ -1422,9 +1258,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
             }
             // ---- claimable tasks: evaluate chunks of this step's round, mask tasks of a freshly staged batch ----
             // (tune::fwd_pipe_consumer_tasks: bit 0 / 1 = wavefront 0 / 1 joins after its apply)
-            // (K4: the wavefronts 4 .. 6 that own a quarter of the K-buffers join like wavefront 0, after their apply)
-            if ((wid >= 2 && !(K4 && kw > 0) && !((tune::fwd_pipe_idle_mask >> wid) & 1)) ||
-                ((tune::fwd_pipe_consumer_tasks >> (kw >= 0 ? 0 : wid)) & 1)) {
+            if (wid >= 2 || ((tune::fwd_pipe_consumer_tasks >> wid) & 1)) {
                 const int nchunks = e_valid ? (e_total + 63) >> 6 : 0;
                 const int ntasks = nchunks + (offer ? 4 : 0);
                 const FaceRec* recE = s_rec + (e_batch & 1) * BATCH;
@@ -1455,16 +1289,12 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
                     bool deferred = false;
                     if (q < e_total) {
                         const unsigned pr = pl[q];
-                        if (JR_TUNE_DIAG & 8192) {       // (diagnostic bit 13, WRONG images: cells without the evaluate arithmetic and its record reads - what does the apply chain cost with the SIMDs and the LDS to itself?)
-                            cells[q] = make_float4(0.25f + 0.001f * (float)(q & 63), 0.5f, 0.3f, __builtin_bit_cast(float, (pr & 63u) | CELL_LIVE | CELL_DEPTH | CELL_FRONT));
-                        } else {
                         const FaceRec& r = recE[pr & 63u];
                         const float2 c = s_pix[pr >> 6];
                         float4 cell;
                         if (face_safe(r.meta) && p.consts_safe) cell = evaluate_pair<DIST, RGB, true>(p, r, c.x, c.y, pr & 63u, deferred);
                         else cell = evaluate_pair<DIST, RGB, false>(p, r, c.x, c.y, pr & 63u, deferred);
                         cells[q] = cell;
-                        }
                     }
                     if (DIST >= 2) {
                         const unsigned long long im = ballot(deferred);
@@ -1484,8 +1314,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
         }
     }
     if (wid == 1) store_colour<RGB>(p, t, s, aggrs, rgba);
-    if (K4 && kw >= 0) q4.store_rest(p.K, kvalid);
-    if (wid == 0 && !K4) store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
+    if (wid == 0) store_ids<KCAP, ids_in_global<KCAP>()>(p, t, s.q, ids);
     if (wid == tune::sections_wave) {
         clk.lap(7);
         if (JR_TUNE_PROFILE_SECTIONS == 2 && t.n == (int)counters[2] && lane == 0) clk.flush0(counters, 4);   // the 16 tiles of the heaviest bin

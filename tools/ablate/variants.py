@@ -78,12 +78,7 @@ VARIANTS = {
     "n3_face_walks": ["JR_TUNE_N3_LINE_WALKS=0", "JR_TUNE_N3_PIXMAP_WAVES=4"], "n3_lp1": ["JR_TUNE_N3_LINE_PARTS=1"], "n3_lp4": ["JR_TUNE_N3_LINE_PARTS=4"], "n3_lp16": ["JR_TUNE_N3_LINE_PARTS=16"], "n3_lw4": ["JR_TUNE_N3_PIXMAP_WAVES=4"],           # round 4: NMR out-walks by the per-face kernel through the L2s (before the per-line regrouping)
     "hard_exact_off": ["JR_TUNE_FWD_HARD_EXACT=0"],          # round 4: what does the uniform 'hard alpha -> IEEE inside distance' branch cost the default modes?
     # round 5
-    "k4": ["JR_TUNE_FWD_PIPE_K4=1"], "csw": ["JR_TUNE_FWD_PIPE_COLOUR_SW=1"], "k4csw": ["JR_TUNE_FWD_PIPE_K4=1", "JR_TUNE_FWD_PIPE_COLOUR_SW=1"],   # pipelined heavy tile: quad K-buffer over four wavefronts / software-pipelined colour loop
-    "idle30": ["JR_TUNE_FWD_PIPE_IDLE_MASK=48"], "idle20": ["JR_TUNE_FWD_PIPE_IDLE_MASK=32"], "k4csw_idle": ["JR_TUNE_FWD_PIPE_K4=1", "JR_TUNE_FWD_PIPE_COLOUR_SW=1", "JR_TUNE_FWD_PIPE_IDLE_MASK=4"],   # task wavefronts that share a SIMD with the K-buffer / colour wavefront take no tasks
-    "diag_noeval": ["JR_TUNE_DIAG=8192"], "wg1": ["JR_TUNE_FWD_MIXED8_LDS_PAD=16384"], "idleF0": ["JR_TUNE_FWD_PIPE_IDLE_MASK=240"], "wg1_k4csw": ["JR_TUNE_FWD_MIXED8_LDS_PAD=16384", "JR_TUNE_FWD_PIPE_K4=1", "JR_TUNE_FWD_PIPE_COLOUR_SW=1"],   # WRONG images / diagnostics: what binds the applying wavefronts of the pipelined heavy tile?
-    "fixed_bin32": ["JR_TUNE_FIXED_BIN32=1"],            # diagnostics: compile-time 32-pixel bins in the raster kernels (what do the run-time shifts cost the headline?)
     "count_paths": ["JR_TUNE_COUNT_PATHS=1", "JR_TUNE_FWD_HEAVY=0"],   # instrumented: trips / lanes per region of the raster loop (tools/sim/min_valu.py --measure)
-    "pipe_prio": ["JR_TUNE_FWD_PIPE_PRIO=1"],              # pipelined heavy tile: s_setprio 3 while wavefronts 0 / 1 apply
     "sections_setup": ["JR_TUNE_PROFILE_SECTIONS=3"],     # instrumented: k_face_setup / k_bin_fill section clocks (tools/ablate/sections.py --setup)
     "base": [],                                              # a library built from another commit, copied to libjrender_hip_base.so by hand
     "sections": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0"],              # instrumented: tools/ablate/sections.py
