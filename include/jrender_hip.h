@@ -292,10 +292,12 @@ int jr_softras_set_launch_policy(jr_ctx* ctx, int heavy_min_faces, int heavy_wav
  * wavefront tiles per bin).  Sticky per context.  It selects how finely the face lists, the launch order and the
  * heavy-bin classification follow the image - results are bit-identical for every value (the reference's own binned path
  * is NOT: it truncates lists at max_elems_per_bin and fills them in a nondeterministic order).  The default threshold of
- * jr_softras_set_launch_policy follows the bin size (512 listed faces for 32-pixel bins, 128 for 16 - 64 for meshes of up to 10 000 faces -, 48 for 8).
- * jr_softras_bin_size: the size a launch of `batch` views at `image_size` would use now (automatic choice: 8-pixel bins up to
- * 128^2 images, 16 up to 512^2 and above while batch x image_size^2 <= 4 Mpixels, else 32); image_size <= 0: the size the
- * workspace's current face records / lists were built with (0 before the first forward). */
+ * jr_softras_set_launch_policy follows the bin size (512 listed faces for 32-pixel bins, 192 for 16 - 64 for meshes of up to 10 000 faces -, 48 for 8).
+ * jr_softras_bin_size: the size a launch of `batch` views of `num_faces` faces at `image_size` would use now (automatic choice:
+ * 8-pixel bins up to 128^2 images; 16 up to 512^2 unless the mesh is dense for the image - more than 100 faces per 16-pixel bin
+ * on average, num_faces x 256 > 100 x image_size^2 -, which keeps 32; above 512^2 16 while batch x image_size^2 <= 4 Mpixels,
+ * else 32; num_faces <= 0: a sparse mesh); image_size <= 0: the size the workspace's current face records / lists were built
+ * with (0 before the first forward). */
 int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size);
 /* Colour-path arithmetic of the forward (sticky per context; default 0).  0: the coverage sigmoid and the softmax weights
  * use the hardware's exp2 / reciprocal (cuda/soft_rasterize.py:338-344, :401-411 evaluate them with expf and a
@@ -304,7 +306,7 @@ int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size);
  * reference's own arithmetic for both quantities (a second set of forward kernels): RGBA 8e-6, gradients under 1e-4
  * element-wise; forward +15 % on the headline batch.  The face-index buffer and faces_info are bit-exact in both modes. */
 int jr_softras_set_precise_colour(jr_ctx* ctx, int on);
-int jr_softras_bin_size(const jr_ctx* ctx, int image_size, int batch);
+int jr_softras_bin_size(const jr_ctx* ctx, int image_size, int batch, int num_faces);
 /* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
  * previous call, [0..7] forward raster, [8..15] backward raster; all zero in the product build */
 int jr_debug_section_clocks(jr_ctx* ctx, uint64_t clocks[20]);

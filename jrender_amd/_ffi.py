@@ -77,7 +77,7 @@ SIGNATURES = {
     "jr_softras_last_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "jr_softras_set_launch_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "jr_softras_set_bin_size": (C.c_int, [C.c_void_p, C.c_int]),
-    "jr_softras_bin_size": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "jr_softras_bin_size": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "jr_softras_set_precise_colour": (C.c_int, [C.c_void_p, C.c_int]),
     "jr_debug_section_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "jr_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -347,9 +347,10 @@ class Context:
         _check(load().jr_softras_set_bin_size(self.handle, int(bin_size)))
         self._bin_size = int(bin_size)
 
-    def bin_size(self, image_size=0, batch=1):
-        """Bin size a launch of ``batch`` views at ``image_size`` would use now; 0: the one the workspace's lists were built with."""
-        return int(load().jr_softras_bin_size(self.handle, int(image_size), int(batch)))
+    def bin_size(self, image_size=0, batch=1, num_faces=0):
+        """Bin size a launch of ``batch`` views of ``num_faces`` faces at ``image_size`` would use now; image_size 0: the one the
+        workspace's lists were built with."""
+        return int(load().jr_softras_bin_size(self.handle, int(image_size), int(batch), int(num_faces)))
 
     def set_precise_colour(self, on=True):
         """Forward colour path in the reference's own arithmetic (jr_softras_set_precise_colour): element-wise 1e-4 gradients

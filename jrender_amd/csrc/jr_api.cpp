@@ -66,7 +66,7 @@ struct jr_ctx {
     // next forward of the same shape sizes its multi-wavefront launch (workgroup size, heavy-tile workgroups) from it while
     // the schedule kernel is still running.  A shape that is NOT in here launches its raster kernel after the host has read
     // this forward's own totals, so that the first call of a shape takes the same path as the second.
-    struct ShapeHist { int B, NF, IS, heavy_min, bin_log2; int64_t heavy; uint64_t stamp; };
+    struct ShapeHist { int B, NF, IS, heavy_min, bin_log2; int64_t heavy, pairs; uint64_t stamp; };
     ShapeHist hist[8] = {};
     uint64_t hist_clock = 0;
     int forced_waves = 0;                    // jr_softras_set_launch_policy / JR_FWD_HEAVY_WAVES: 4 or 8 whatever the policy says; 0 = automatic
@@ -167,14 +167,17 @@ int validate(int B, int NF, int T, int IS, int K, int dist, int rgb, int alpha, 
 // or, by default, one that follows the image - a 32-pixel bin is HALF of a 64^2 image (demo2: every bin lists a third of
 // the mesh and every tile walks that list), while on a 1024^2 image it keeps the lists, the ordering kernel and the
 // launch order cheap.  Results do not depend on it.
-int resolve_bin_log2(const jr_ctx* ctx, int B, int IS) {
+int resolve_bin_log2(const jr_ctx* ctx, int B, int IS, int NF) {
     const int user = ctx->bin_size_user;
     if (user > 0) return user <= 8 ? 3 : (user <= 16 ? 4 : 5);
     // measured (profiles/r05_experiments.md, calls 1 and 4): 64^2 x 64 views 0.48 -> 0.35 ms with 8-pixel bins (the list IS the
     // tile's, half of the tiles are limb-heavy), 256^2 - 12 % with 16; at 1024^2 16-pixel bins pay (- 2 ... - 7 %) while the
     // launch fits the multi-wavefront kernel, the headline batch keeps 32 (+ 2 % otherwise: twice the list entries to order)
     if (IS <= jr::tune::auto_bin8_max_image) return 3;
-    if (IS <= jr::tune::auto_bin16_max_image) return 4;
+    // a mesh that is DENSE for its image (39 000 faces at 256^2: 150 per 16-pixel bin on average, lists of up to 1 900) gains
+    // nothing from finer bins - every bin is heavy either way - and pays their set-up: 8 views 0.86 ms with 16, 0.70 with 32 (call 6)
+    if (IS <= jr::tune::auto_bin16_max_image)
+        return (long)NF * 256 > (long)jr::tune::auto_dense_faces_per_bin16 * IS * IS ? 5 : 4;
     return (long)B * IS * IS <= (long)jr::tune::fwd_heavy_pixels ? 4 : 5;
 }
 // Bins that list more faces than this are HEAVY (a workgroup per tile in the forward, split tiles in the backward): the
@@ -198,7 +201,7 @@ jr::RasterParams make_params(const jr_ctx* ctx, int B, int NF, int T, int IS, in
     p.rad = sqrtf(p.thr);                                                                  // SRK:316
     p.dist = dist; p.rgb = rgb; p.alpha = alpha; p.tex = tex; p.double_side = double_side ? 1 : 0;
     for (int k = 0; k < 3; k++) p.bg[k] = bg ? bg[k] : 0.f;
-    p.bin_log2 = resolve_bin_log2(ctx, B, IS);
+    p.bin_log2 = resolve_bin_log2(ctx, B, IS, NF);
     p.sub_log2 = p.bin_log2 - jr::TILE_LOG2;
     p.bins_x = (IS + (1 << p.bin_log2) - 1) >> p.bin_log2;
     p.bins_y = p.bins_x;
@@ -266,12 +269,16 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     // fraction of the GPU, else four.  How many heavy tiles a launch has is known on the device only: a shape seen before
     // is launched speculatively with what it found then (an optimisation loop renders the same scene again and again), a
     // new shape waits for this forward's own count (the host reads the totals anyway).
-    auto waves_for = [&](int64_t heavy_bins) {
+    auto waves_for = [&](int64_t heavy_bins, int64_t pairs) {
         if (!(jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8)) return 4;
         if (ctx->forced_waves == 4 || ctx->forced_waves == 8) return ctx->forced_waves;
         if (heavy_bins <= 0) return 4;            // nothing for the pipeline: four light tiles per workgroup beat eight (3 300 faces at 1024^2: 0.247 against 0.256 ms)
         // eight while the heavy tiles' wavefronts fit a budget: generous for launches that cannot fill the GPU anyway (one 39k
         // view: 1 152 tiles of 16-pixel bins at eight wavefronts 0.489 ms, at four 0.571), tight for the others (four views)
+        // a launch whose bins ALL carry long lists (39 000 faces at 256^2: 740 per bin on average) is bounded by its heavy tiles whatever
+        // its size: eight wavefronts per tile 0.70 ms against 0.81 with four (8 views, call 6); a batch of 64^2 views has as many
+        // heavy bins, but of 90 faces each, and loses 13 % with eight
+        if (pairs >= (int64_t)jr::tune::fwd_waves8_mean_list * p.B * p.bins_x * p.bins_y) return 8;
         const int64_t tiles = heavy_bins << (2 * p.sub_log2);
         const long budget = (long)p.B * p.IS * p.IS <= jr::tune::fwd_waves8_small_pixels ? jr::tune::fwd_heavy_waves8_budget_small
                                                                                           : jr::tune::fwd_heavy_waves8_budget;
@@ -286,8 +293,8 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
         ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
         jr::launch_bin_fill_sort(ctx->stream, p, ws, again);
     };
-    auto enqueue_raster = [&](int64_t heavy_bins, bool exact) {
-        ws.heavy_waves = waves_for(heavy_bins);
+    auto enqueue_raster = [&](int64_t heavy_bins, int64_t pairs, bool exact) {
+        ws.heavy_waves = waves_for(heavy_bins, pairs);
         ws.heavy_bound = exact ? (long)heavy_bins : (long)(heavy_bins + heavy_bins / 4 + 16);
         ProfScope ps(ctx, JR_PHASE_FWD_RASTER);
         if (ctx->precise_colour) jr_precise::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
@@ -296,7 +303,7 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     const bool spec_lists = ws.pool != nullptr && ws.pool_cap > 0;
     const bool spec_raster = spec_lists && (!heavy_path || hist != nullptr);
     if (spec_lists) enqueue_lists(false);
-    if (spec_raster) enqueue_raster(hist ? hist->heavy : 0, false);
+    if (spec_raster) enqueue_raster(hist ? hist->heavy : 0, hist ? hist->pairs : 0, false);
     JR_HIP(hipEventSynchronize(ctx->ev_counters));
     const size_t pairs = (size_t)ctx->h_counters[0];
     const int64_t heavy_now = (int64_t)ctx->h_counters[3];
@@ -310,7 +317,7 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
             for (auto& h : ctx->hist) if (h.stamp < hist->stamp) hist = &h;
             hist->B = p.B; hist->NF = p.NF; hist->IS = p.IS; hist->heavy_min = ws.heavy_min; hist->bin_log2 = p.bin_log2;
         }
-        hist->heavy = heavy_now; hist->stamp = ++ctx->hist_clock;
+        hist->heavy = heavy_now; hist->pairs = (int64_t)pairs; hist->stamp = ++ctx->hist_clock;
     }
     if (pairs > 0x7fffffffULL)       // segment bases are 32-bit
         return fail("%zu (bin, face) pairs exceed the 2^31 - 1 the bin lists index: render fewer views per call", pairs);
@@ -323,8 +330,8 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
             ws.pool_cap = c0;
         }
         enqueue_lists(spec_lists);
-        enqueue_raster(heavy_now, true);
-    } else if (!spec_raster) enqueue_raster(heavy_now, true);
+        enqueue_raster(heavy_now, (int64_t)pairs, true);
+    } else if (!spec_raster) enqueue_raster(heavy_now, (int64_t)pairs, true);
     ctx->launch_info[0] = heavy_path ? 1 : 0;
     ctx->launch_info[1] = heavy_path ? std::min<int64_t>(heavy_now, jr::heavy_bins_cap(ws, p.B * p.bins_x * p.bins_y)) : 0;
     ctx->launch_info[2] = ws.heavy_waves_used;
@@ -898,10 +905,10 @@ int jr_softras_set_precise_colour(jr_ctx* ctx, int on) {
     return 0;
 }
 
-int jr_softras_bin_size(const jr_ctx* ctx, int image_size, int batch) {
+int jr_softras_bin_size(const jr_ctx* ctx, int image_size, int batch, int num_faces) {
     if (!ctx) return -1;
     if (image_size <= 0) return ctx->bins_bin_log2 ? 1 << ctx->bins_bin_log2 : 0;     // of the set-up pass the workspace holds
-    return 1 << resolve_bin_log2(ctx, batch > 0 ? batch : 1, image_size);
+    return 1 << resolve_bin_log2(ctx, batch > 0 ? batch : 1, image_size, num_faces > 0 ? num_faces : 0);
 }
 
 int jr_softras_last_launch(jr_ctx* ctx, int64_t info[4]) {

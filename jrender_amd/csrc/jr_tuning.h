@@ -49,10 +49,16 @@
 #define JR_TUNE_FWD_HEAVY 512
 #endif
 #ifndef JR_TUNE_FWD_HEAVY16      // the same threshold for 16-pixel bins (2x2 tiles): meshes above / up to JR_TUNE_SMALL_MESH_FACES faces
-#define JR_TUNE_FWD_HEAVY16 128
+#define JR_TUNE_FWD_HEAVY16 192
 #endif
 #ifndef JR_TUNE_FWD_HEAVY16_SMALL_MESH
 #define JR_TUNE_FWD_HEAVY16_SMALL_MESH 64
+#endif
+#ifndef JR_TUNE_AUTO_DENSE_FACES_PER_BIN16   // automatic bin size: images of up to 512^2 whose mesh would put more than this many faces into a 16-pixel bin ON AVERAGE (faces x 256 / image_size^2) keep 32-pixel bins
+#define JR_TUNE_AUTO_DENSE_FACES_PER_BIN16 100
+#endif
+#ifndef JR_TUNE_FWD_WAVES8_MEAN_LIST      // workgroup size: launches whose bins list this many faces on average (pairs / bins) take eight wavefronts whatever their size
+#define JR_TUNE_FWD_WAVES8_MEAN_LIST 512
 #endif
 #ifndef JR_TUNE_BIN_FILL_UNROLL_MAX_FACES   // k_bin_fill: launches of up to this many faces (batch x mesh) append 4 bins per pass at 32-pixel bins too
 #define JR_TUNE_BIN_FILL_UNROLL_MAX_FACES 65536
@@ -169,6 +175,9 @@
 #ifndef JR_TUNE_N3_LINE_WALKS     // NMR pixel-map gradient: the out-walks regrouped by scan line and run from an LDS copy of the line (0: every face walks its own lines through the L2s)
 #define JR_TUNE_N3_LINE_WALKS 1
 #endif
+#ifndef JR_TUNE_N3_LINE_FAST      // NMR line walks (round 5): per-crossing sign of the eps, uniform trip counts, four groups of 64 pixels per trip (0: the round-4 loop)
+#define JR_TUNE_N3_LINE_FAST 1
+#endif
 #ifndef JR_TUNE_N3_LINE_PARTS     // NMR line walks: sub-lists (= workgroups of the walk kernel) per scan line; power of two, 1024 crossings per line in total
 #define JR_TUNE_N3_LINE_PARTS 8
 #endif
@@ -196,6 +205,7 @@ constexpr int n3_xcd_group = JR_TUNE_N3_XCD_GROUP;
 constexpr int n3_walks = JR_TUNE_N3_WALKS;
 constexpr bool n3_line_walks = JR_TUNE_N3_LINE_WALKS != 0;
 constexpr int n3_line_parts = JR_TUNE_N3_LINE_PARTS;
+constexpr bool n3_line_fast = JR_TUNE_N3_LINE_FAST != 0;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr int fwd_exact = JR_TUNE_FWD_EXACT, bwd_exact = JR_TUNE_BWD_EXACT;
 constexpr bool fwd_hard_exact = JR_TUNE_FWD_HARD_EXACT != 0;
@@ -228,6 +238,7 @@ constexpr bool fwd_empty_bins = JR_TUNE_FWD_EMPTY_BINS != 0;
 constexpr bool fwd_exp1 = JR_TUNE_FWD_EXP1 != 0;
 constexpr int fwd_heavy = JR_TUNE_FWD_HEAVY, fwd_heavy16 = JR_TUNE_FWD_HEAVY16, fwd_heavy8 = JR_TUNE_FWD_HEAVY8;
 constexpr int bin_fill_unroll_max_faces = JR_TUNE_BIN_FILL_UNROLL_MAX_FACES;
+constexpr int auto_dense_faces_per_bin16 = JR_TUNE_AUTO_DENSE_FACES_PER_BIN16, fwd_waves8_mean_list = JR_TUNE_FWD_WAVES8_MEAN_LIST;
 constexpr int fwd_heavy16_small_mesh = JR_TUNE_FWD_HEAVY16_SMALL_MESH, small_mesh_faces = JR_TUNE_SMALL_MESH_FACES;
 constexpr long fwd_heavy_waves8_budget_small = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET_SMALL, fwd_waves8_small_pixels = JR_TUNE_FWD_WAVES8_SMALL_PIXELS;
 constexpr int auto_bin8_max_image = JR_TUNE_AUTO_BIN8_MAX_IMAGE, auto_bin16_max_image = JR_TUNE_AUTO_BIN16_MAX_IMAGE;

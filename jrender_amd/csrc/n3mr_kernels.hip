@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void k_n3mr_resolve(
 //   * gradient-only arithmetic in float with v_rcp_f32 (the reference promotes dist to double and divides);
 //     per-lane partial sums are reduced once per face and stored without atomics, like the reference.
 struct N3Planes {
-    const float4* sg;        // (S, g_alpha, g_r, g_g)
-    const float* gb;         // g_b
+    const float4* sg;        // (g_alpha, g_r, g_g, g_b)   (round 5: the four gradients travel together - the products with the reference pixel pair up
+    const float* gb;         // S = sum_k map_k * grad_k       without register moves; the scalar plane holds S)
     const int32_t* fidx;
 };
 
@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256) void k_n3mr_pack(
         if (p.return_alpha) { ga = grad_alpha_map[i]; S += alpha_map[i] * ga; }
         if (p.return_rgb)
             for (int k = 0; k < 3; k++) { g[k] = grad_rgb_map[3 * i + k]; S += rgb_map[3 * i + k] * g[k]; }
-        const float4 v = make_float4(S, ga, g[0], g[1]);
+        const float4 v = make_float4(ga, g[0], g[1], g[2]);
         const int32_t fi = face_index_map[i];
-        sg[i] = v; gb[i] = g[2]; fidx_r[i] = fi;
-        s_v[ty][tx] = v; s_g[ty][tx] = g[2]; s_f[ty][tx] = fi;
+        sg[i] = v; gb[i] = S; fidx_r[i] = fi;
+        s_v[ty][tx] = v; s_g[ty][tx] = S; s_f[ty][tx] = fi;
     }
     __syncthreads();
 #pragma unroll
@@ -248,8 +248,9 @@ __global__ __launch_bounds__(256) void k_n3mr_pack(
 
 struct N3Ref { float a, c0, c1, c2; };       // the reference pixel of a walk (alpha, r, g, b)
 
-__device__ inline float n3_diff(const float4 v, float gbv, const N3Ref& r) {
-    return v.x - (((r.a * v.y + r.c0 * v.z) + r.c1 * v.w) + r.c2 * gbv);
+// diff = S - sum_k ref_k * grad_k, the products summed in the order the pack pass sums S: a pixel with the reference's colours gives exactly 0
+__device__ inline float n3_diff(const float4 g, float S, const N3Ref& r) {
+    return S - (((r.a * g.x + r.c0 * g.y) + r.c1 * g.z) + r.c2 * g.w);
 }
 
 // -= diff / (dist +- eps) for the two vertices of the edge (N3K:496-505, :583-592)
@@ -420,10 +421,75 @@ struct N3Crossing {
 };
 static_assert(sizeof(N3Crossing) == 36, "crossing record");
 
+// Round 5: the walk loop was VALU-issue bound (22 VGPRs, 8 wavefronts per SIMD, ~117 issue cycles per 64 visited pixels at the
+// measured opcode prices against ~6 LDS cycles).  What it sheds:
+//   * the sign of dist = t * (d1 - cross) * 2 / is is the SAME for every pixel of an out-walk (the walk starts beyond the crossing
+//     and runs away from it): the +-eps is chosen once per crossing and dist is one FMA (was mul, compare, select, add); a walk
+//     that does straddle its crossing point - or touches it exactly - keeps the per-pixel compare (UNI = false);
+//   * which of the edge's two vertices take a gradient (ha, hb) is wave-uniform: three instantiations instead of two selects per pixel;
+//   * the trip count is wave-uniform (scalar loop, no per-lane compare except in the last partial group of 64), four groups per trip
+//     with their LDS reads issued together and one address update per trip;
+//   * the two sums of a crossing leave through row_bcast steps and ONE v_readlane each (was four + three adds).
+template <bool HA, bool HB, bool UNI>
+__device__ inline void n3_line_push(float diff, float dd, float fa, float ea, float fb, float eb, float eps, float& pa, float& pb) {
+    // (a real branch around this body: if-converted, the four pixels of a trip were packed ACROSS pixels - 14 register moves per trip -
+    // and a group of 64 pixels without a positive diff, e.g. zero image gradients, paid both v_rcp all the same)
+    asm volatile("");
+    if (HA) {
+        float dist;
+        if (UNI) dist = __builtin_fmaf(fa, dd, ea);
+        else { dist = fa * dd; dist += 0 < dist ? eps : -eps; }
+        pa = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(dist), pa);
+    }
+    if (HB) {
+        float dist;
+        if (UNI) dist = __builtin_fmaf(fb, dd, eb);
+        else { dist = fb * dd; dist += 0 < dist ? eps : -eps; }
+        pb = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(dist), pb);
+    }
+}
+template <bool HA, bool HB, bool UNI>
+__device__ inline void n3_line_walk(const float4* s_g, const float* s_S, int wf, int wt, int lane, const N3Ref& r, float cross,
+                                    float fa, float ea, float fb, float eb, float eps, float& pa, float& pb) {
+    const int n = wt + 1 - wf, groups = n >> 6, rem = n & 63;          // wave-uniform: scalar loop control
+    int d1 = wf + lane, gi = 0;
+    for (; gi + 4 <= groups; gi += 4, d1 += 256) {
+        float4 g[4];
+        float S[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { g[k] = s_g[d1 + 64 * k]; S[k] = s_S[d1 + 64 * k]; }
+        const float dd = (float)d1 - cross;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float diff = n3_diff(g[k], S[k], r);
+            if (diff <= 0) continue;
+            n3_line_push<HA, HB, UNI>(diff, dd + 64.f * k, fa, ea, fb, eb, eps, pa, pb);      // ((float)d1 - cross, one rounding further)
+        }
+    }
+    for (; gi < groups; gi++, d1 += 64) {
+        const float diff = n3_diff(s_g[d1], s_S[d1], r);
+        if (diff <= 0) continue;
+        n3_line_push<HA, HB, UNI>(diff, (float)d1 - cross, fa, ea, fb, eb, eps, pa, pb);
+    }
+    if (lane < rem) {
+        const float diff = n3_diff(s_g[d1], s_S[d1], r);
+        if (diff > 0) n3_line_push<HA, HB, UNI>(diff, (float)d1 - cross, fa, ea, fb, eb, eps, pa, pb);
+    }
+}
+__device__ inline float n3_wave_sum_last(float v) {       // all lanes active; the sum of the 64 lanes, wave-uniform
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror: every lane holds its row's sum
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+    return n3_bcast(v, 63);
+}
+
 __global__ __launch_bounds__(256) void k_n3mr_backward_line_walks(
     N3Params p, int nsub, const float4* __restrict__ sg2, const float* __restrict__ gb2, const int* __restrict__ line_count,
     const N3Crossing* __restrict__ line_rec, float* __restrict__ grad_faces) {
-    extern __shared__ float4 s_line[];           // [is] (S, g_alpha, g_r, g_g), then [is] g_b
+    extern __shared__ float4 s_line[];           // [is] (g_alpha, g_r, g_g, g_b), then [is] S
     // the sub-lists of ONE line go to one XCD (workgroup ids are dealt round-robin to the eight): its L2 serves the line once
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const int S = ((k / N3_LINE_PARTS) * 8 + xcd) * N3_LINE_PARTS + (k % N3_LINE_PARTS), L = S / N3_LINE_PARTS, is = p.IS;   // sub-list S of scan line L
@@ -456,6 +522,26 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_line_walks(
         // -= diff / (dist +- eps), dist = t * (d1 - cross) * 2 / is (N3K:496-505; the constant factors folded: one rounding apart)
         const float fa = ta * two_over_is, fb = tb * two_over_is, eps = p.eps;
         float pa = 0.f, pb = 0.f;
+        if (tune::n3_line_fast) {
+            // every pixel of the walk strictly on one side of the crossing point?  ((float)d1 - cross is monotone in d1)
+            const bool above = (float)wf - cross > 0.f, below = (float)wt - cross < 0.f;
+            if (above || below) {
+                // 0 < f * dd  <=>  f and dd have the same sign (f == 0: dist = 0, the reference subtracts eps)
+                const float ea = (above ? fa > 0.f : fa < 0.f) ? eps : -eps, eb = (above ? fb > 0.f : fb < 0.f) ? eps : -eps;
+                if (ha && hb) n3_line_walk<true, true, true>(s_line, s_gbl, wf, wt, lane, r, cross, fa, ea, fb, eb, eps, pa, pb);
+                else if (ha) n3_line_walk<true, false, true>(s_line, s_gbl, wf, wt, lane, r, cross, fa, ea, fb, eb, eps, pa, pb);
+                else if (hb) n3_line_walk<false, true, true>(s_line, s_gbl, wf, wt, lane, r, cross, fa, ea, fb, eb, eps, pa, pb);
+            } else if (ha || hb) {
+                // (a vertex without a gradient still walks here; its slope is 0, its sum is dropped below)
+                n3_line_walk<true, true, false>(s_line, s_gbl, wf, wt, lane, r, cross, ha ? fa : 0.f, 0.f, hb ? fb : 0.f, 0.f, eps, pa, pb);
+            }
+            const float sa = ha ? n3_wave_sum_last(pa) : 0.f, sb = hb ? n3_wave_sum_last(pb) : 0.f;
+            if (lane == 0) {
+                if (sa != 0.f) atomicAdd(grad_faces + (size_t)face * 9 + ia, sa);
+                if (sb != 0.f) atomicAdd(grad_faces + (size_t)face * 9 + ib, sb);
+            }
+            continue;
+        }
         for (int d1 = wf + lane; d1 <= wt; d1 += 64) {
             const float diff = n3_diff(s_line[d1], s_gbl[d1], r);
             if (diff <= 0) continue;
@@ -481,7 +567,7 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_line_walks(
 //   * the out-walks of the whole face form ONE list and are taken FOUR at a time: the four lines' loads of a walk step
 //     are independent and issued together (4x the memory-level parallelism per wavefront), their parameters are
 //     wave-uniform (v_readlane from the scan lane that owns the line);
-//   * planes: [0] row-major, [1] column-major copies of (S, g_alpha, g_r, g_g | g_b | face index) in ONE buffer each, so
+//   * planes: [0] row-major, [1] column-major copies of (g_alpha, g_r, g_g, g_b | S | face index) in ONE buffer each, so
 //     that "the orientation in which this walk is contiguous" is an index offset, not a pointer select.
 // Same arithmetic per visited pixel (n3_diff / n3_push); only the order of the float sums differs.
 

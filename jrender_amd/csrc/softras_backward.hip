@@ -216,8 +216,18 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
     return texel;
 }
 
+
+// wavefronts per SIMD asked of the register allocator: every instantiation without scratch (tools/kernel_resources.sh).  The
+// 'barycentric' distance keeps three more live values through the pair loop than 'euclidean': <1,0,16> and <1,1,16> carried
+// 20 / 32 B at five wavefronts, <1,1,32> with the LDS texel sums 16 B at four - one wavefront fewer for those three.
+constexpr int bwd_waves(int dist, int rgb, int kcap, bool texlds) {
+    const int w = texlds ? (kcap <= 32 ? 4 : 3) : (kcap <= 16 ? JR_TUNE_BWD_WAVES : (kcap <= 32 ? 4 : JR_TUNE_BWD_WAVES64));
+    const bool spills = dist == 1 && rgb != 2 && ((kcap <= 16 && !texlds) || (kcap == 32 && texlds));
+    return spills && w > 3 ? w - 1 : w;
+}
+
 template <int DIST, int RGB, int KCAP, bool TEXLDS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TEXLDS ? (KCAP <= 32 ? 4 : 3) : (KCAP <= 16 ? JR_TUNE_BWD_WAVES : (KCAP <= 32 ? 4 : JR_TUNE_BWD_WAVES64))))) void k_softras_backward(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DIST, RGB, KCAP, TEXLDS)))) void k_softras_backward(
     RasterParams p, int nbins, int heavy_cap, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,

@@ -331,10 +331,11 @@ __device__ inline void forward_pair(const RasterParams& p, const FaceRec& r, con
 
 // wavefronts per SIMD asked of the register allocator: K <= 16: the single-wavefront kernel fits 96 VGPRs (5), the
 // four-wavefront one 128 (4); K <= 32: 168 (3); K <= 64: 256 (2) - all without scratch
-constexpr int fwd_waves(int kcap, bool mixed, int rgb = 1) {
+constexpr int fwd_waves(int kcap, bool mixed, int rgb = 1, int dist = 2) {
     // ('hard' rgb at K <= 64 keeps depth_min / face_min / the colour next to 64 K-buffer depths: 12 - 16 B of scratch at three
     //  wavefronts per SIMD, none at two - VERDICT r4 next #6)
-    return kcap <= 16 ? (mixed ? 4 : tune::fwd_waves16)
+    // (and the all-'hard' kernel <0,0,16> carried 8 B at five wavefronts per SIMD: four)
+    return kcap <= 16 ? (mixed ? 4 : (rgb == 0 && dist == 0 && tune::fwd_waves16 > 4 ? 4 : tune::fwd_waves16))
                       : (kcap <= 32 ? (mixed ? 3 : tune::fwd_waves32) : (mixed || rgb == 0 ? 2 : tune::fwd_waves64));   // (the four-wavefront kernel spills at one more)
 }
 
@@ -1328,7 +1329,7 @@ __device__ inline void tile_heavy_pipe(const RasterParams& p, const TileGeom& t,
 // forward 0.841 -> 0.878 ms on the headline batch (same-box A/B against a build with the constant, profiles/r05_experiments.md
 // call 5) - two more scalars live across a kernel that already spills SGPRs into VGPR lanes.
 template <int DIST, int RGB, int KCAP, int BL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP, false, RGB)))) void k_softras_forward(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KCAP, false, RGB, DIST)))) void k_softras_forward(
     RasterParams p, int ntiles_total, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const int* __restrict__ bin_base, const unsigned long long* __restrict__ pool,

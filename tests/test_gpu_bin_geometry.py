@@ -153,3 +153,18 @@ def test_backward_rebuilds_when_the_geometry_changed_in_between(gctx):
         assert gctx.bin_size() == bwd_bin
     for gf in grads[1:]:
         assert grad_err(gf, grads[0]) <= 2e-6
+
+
+def test_automatic_bin_size_follows_image_batch_and_mesh_density(gctx):
+    """The default geometry (jr_softras_bin_size, jrender_hip.h): 8-pixel bins up to 128^2, 16 up to 512^2 unless the mesh is dense
+    for the image (more than 100 faces per 16-pixel bin on average), above 512^2 16 while the launch stays under 4 Mpixels; and the
+    launch really runs under what the query reports."""
+    gctx.set_bin_size(0); gctx.set_launch_policy(-1, 0)
+    for IS, B, NF, expect in ((64, 64, 3300, 8), (128, 1, 39000, 8), (256, 1, 5856, 16), (256, 8, 39000, 32), (512, 1, 39000, 16),
+                              (512, 1, 110000, 32), (1024, 1, 39000, 16), (1024, 4, 39000, 16), (1024, 8, 39000, 32), (2048, 1, 5856, 16),
+                              (2048, 2, 5856, 32), (256, 1, 0, 16)):
+        assert gctx.bin_size(IS, B, NF) == expect, (IS, B, NF, gctx.bin_size(IS, B, NF))
+    for nf, IS, expect in ((3300, 256, 16), (39000, 256, 32)):
+        fv, tex = syn.sphere_views(nf, 1)
+        SoftRasterizeFunction(image_size=IS, ctx=gctx)(fv, tex)
+        assert gctx.bin_size() == expect == gctx.bin_size(IS, 1, fv.shape[1])
