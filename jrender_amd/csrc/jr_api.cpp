@@ -72,6 +72,7 @@ struct jr_ctx {
     int forced_waves = 0;                    // jr_softras_set_launch_policy / JR_FWD_HEAVY_WAVES: 4 or 8 whatever the policy says; 0 = automatic
     unsigned long long* zkey = nullptr;     // n3mr z-buffer keys [B*IS*IS]
     size_t zkey_cap = 0;
+    size_t zkey_clean = 0;                  // leading entries of zkey known to hold ~0 (k_n3mr_resolve clears what it read)
     unsigned char* n3_scratch = nullptr;    // n3mr backward: packed per-pixel planes in both orientations
     size_t n3_scratch_cap = 0;
     // two-stage sums of the loss / optimiser kernels: [red_cap] double accumulators + [red_cap] tickets, zeroed when
@@ -759,12 +760,17 @@ int jr_n3mr_forward(jr_ctx* ctx, const float* faces, const float* textures, floa
     if (!(near_ >= 0.f)) return fail("jr_n3mr_forward: near must be >= 0 (depth keys are ordered by bit pattern)");
     JR_HIP(hipSetDevice(ctx->device));
     const size_t P = (size_t)B * IS * IS;
+    if (P > ctx->zkey_cap || !ctx->zkey) ctx->zkey_clean = 0;
     if (grow(ctx->zkey, ctx->zkey_cap, P, 1.0)) return 1;
+    const size_t was_clean = ctx->zkey_clean;
+    const bool clean = P <= was_clean;
+    ctx->zkey_clean = 0;                     // (until the launches below are known to be in the stream)
     jr::launch_n3mr_forward(ctx->stream, faces, textures, faces_inv, ctx->zkey, face_index_map, weight_map,
                             depth_map, face_inv_map, rgb_map, alpha_map, sampling_index_map,
                             sampling_weight_map, B, NF, TS, IS, near_, far_, eps, background_rgb, return_rgb,
-                            return_alpha, return_depth);
+                            return_alpha, return_depth, clean);
     JR_HIP(hipGetLastError());
+    ctx->zkey_clean = clean ? was_clean : P;
     return 0;
 }
 

@@ -107,7 +107,7 @@ void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textur
                          unsigned long long* zkey, int32_t* face_index_map, float* weight_map, float* depth_map,
                          float* face_inv_map, float* rgb_map, float* alpha_map, int32_t* sampling_index_map,
                          float* sampling_weight_map, int B, int NF, int TS, int IS, float near_, float far_,
-                         float eps, const float* bg, int rrgb, int ralpha, int rdepth);
+                         float eps, const float* bg, int rrgb, int ralpha, int rdepth, bool zkey_clean);
 void launch_n3mr_backward(hipStream_t st, const float* faces, const int32_t* face_index_map,
                           const float* weight_map, const float* depth_map, const float* face_inv_map,
                           const float* rgb_map, const float* alpha_map, const float* sampling_weight_map,

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_n3mr_zbuffer(N3Params p, const float* _
 // per pixel: winner -> face_index / depth / weights / face_inv; texture sample, background, alpha
 __global__ __launch_bounds__(256) void k_n3mr_resolve(
     N3Params p, const float* __restrict__ faces, const float* __restrict__ textures,
-    const float* __restrict__ faces_inv, const unsigned long long* __restrict__ zkey,
+    const float* __restrict__ faces_inv, unsigned long long* __restrict__ zkey,
     int32_t* __restrict__ face_index_map, float* __restrict__ weight_map, float* __restrict__ depth_map,
     float* __restrict__ face_inv_map, float* __restrict__ rgb_map, float* __restrict__ alpha_map,
     int32_t* __restrict__ sampling_index_map, float* __restrict__ sampling_weight_map) {
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_n3mr_resolve(
     const long pp = (long)p.IS * p.IS;
     if (i >= p.B * pp) return;
     const unsigned long long key = zkey[i];
+    zkey[i] = ~0ull;                       // the keys leave this kernel cleared: the next forward of the context needs no memset launch in front of its z-buffer pass
     const bool hit = key != ~0ull;
     const int fn = hit ? (int)(unsigned)key : -1;
     face_index_map[i] = fn;
@@ -205,6 +206,10 @@ struct N3Planes {
 // One 32x32-pixel tile per workgroup: the row-major copies are written as the pixels are read; the column-major copies go
 // through an LDS tile so that they, too, leave as contiguous runs (round 4: a thread writing its own transposed element touched
 // one cache line per lane - 0.034 of the backward's 0.41 ms).
+// sum_k map_k * grad_k over (alpha, r, g, b) in the association both the pack pass and the walks use
+__device__ inline float n3_dot4(float a, float c0, float c1, float c2, const float4 g) {
+    return __builtin_fmaf(c1, g.z, a * g.x) + __builtin_fmaf(c2, g.w, c0 * g.y);
+}
 constexpr int N3_PACK_TILE = 32;
 __global__ __launch_bounds__(256) void k_n3mr_pack(
     N3Params p, const int32_t* __restrict__ face_index_map, const float* __restrict__ rgb_map,
@@ -227,10 +232,11 @@ __global__ __launch_bounds__(256) void k_n3mr_pack(
         const int ty = ty0 + r, x = x0 + tx, y = y0 + ty;
         if (x >= is || y >= is) continue;
         const size_t i = pbase + (size_t)y * is + x;
-        float S = 0.f, ga = 0.f, g[3] = {0.f, 0.f, 0.f};
-        if (p.return_alpha) { ga = grad_alpha_map[i]; S += alpha_map[i] * ga; }
+        float a = 0.f, ga = 0.f, c[3] = {0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};
+        if (p.return_alpha) { ga = grad_alpha_map[i]; a = alpha_map[i]; }
         if (p.return_rgb)
-            for (int k = 0; k < 3; k++) { g[k] = grad_rgb_map[3 * i + k]; S += rgb_map[3 * i + k] * g[k]; }
+            for (int k = 0; k < 3; k++) { g[k] = grad_rgb_map[3 * i + k]; c[k] = rgb_map[3 * i + k]; }
+        const float S = n3_dot4(a, c[0], c[1], c[2], make_float4(ga, g[0], g[1], g[2]));
         const float4 v = make_float4(ga, g[0], g[1], g[2]);
         const int32_t fi = face_index_map[i];
         sg[i] = v; gb[i] = S; fidx_r[i] = fi;
@@ -248,9 +254,10 @@ __global__ __launch_bounds__(256) void k_n3mr_pack(
 
 struct N3Ref { float a, c0, c1, c2; };       // the reference pixel of a walk (alpha, r, g, b)
 
-// diff = S - sum_k ref_k * grad_k, the products summed in the order the pack pass sums S: a pixel with the reference's colours gives exactly 0
+// diff = S - sum_k ref_k * grad_k.  Both sums go through n3_dot4 - (alpha, g) and (r, b) paired: one v_pk_mul_f32 + one v_pk_fma_f32 + one
+// add where four products and three adds cost 20 issue cycles per visited pixel group - so a pixel with the reference's colours gives exactly 0.
 __device__ inline float n3_diff(const float4 g, float S, const N3Ref& r) {
-    return S - (((r.a * g.x + r.c0 * g.y) + r.c1 * g.z) + r.c2 * g.w);
+    return S - n3_dot4(r.a, r.c0, r.c1, r.c2, g);
 }
 
 // -= diff / (dist +- eps) for the two vertices of the edge (N3K:496-505, :583-592)
@@ -476,14 +483,17 @@ __device__ inline void n3_line_walk(const float4* s_g, const float* s_S, int wf,
         if (diff > 0) n3_line_push<HA, HB, UNI>(diff, (float)d1 - cross, fa, ea, fb, eb, eps, pa, pb);
     }
 }
-__device__ inline float n3_wave_sum_last(float v) {       // all lanes active; the sum of the 64 lanes, wave-uniform
+__device__ inline float n3_wave_sum_last(float v) {       // all lanes active; -> the sum of the 64 lanes in LANE 63 (other lanes: partial sums)
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror: every lane holds its row's sum
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
-    return n3_bcast(v, 63);
+    // rows 1, 3 += lane 15 of the row before; rows 2, 3 += lane 31: lane 63 holds the sum of all 64.  As ONE instruction each - rows outside
+    // the row mask keep their value, which the builtin can only express as mov + dpp-mov + add; the two wait states a DPP read needs
+    // after the VALU write of its source are spelled out, the compiler's hazard pass does not look into asm.
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return v;
 }
 
 __global__ __launch_bounds__(256) void k_n3mr_backward_line_walks(
@@ -491,22 +501,92 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_line_walks(
     const N3Crossing* __restrict__ line_rec, float* __restrict__ grad_faces) {
     extern __shared__ float4 s_line[];           // [is] (g_alpha, g_r, g_g, g_b), then [is] S
     // the sub-lists of ONE line go to one XCD (workgroup ids are dealt round-robin to the eight): its L2 serves the line once
-    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int S = ((k / N3_LINE_PARTS) * 8 + xcd) * N3_LINE_PARTS + (k % N3_LINE_PARTS), L = S / N3_LINE_PARTS, is = p.IS;   // sub-list S of scan line L
-    if (S >= nsub) return;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, is = p.IS;
+    const int rank = (k / N3_LINE_PARTS) * 8 + xcd;           // of the line in launch order
+    if (rank >= nsub / N3_LINE_PARTS) return;
+    int d0, axis, bn;
+    if (tune::n3_line_fast) {
+        // launch order = expected load, heaviest first: the lines through the middle of the image carry the most crossings (an object is
+        // usually centred) and the longest lists, and a workgroup that starts late with 128 crossings is the kernel's tail.  Both
+        // orientations alternate, positions run from the centre outwards: is/2, is/2 - 1, is/2 + 1, ...
+        const int q = rank % (2 * is), j = q >> 1;
+        bn = rank / (2 * is); axis = q & 1;
+        d0 = (is >> 1) + ((j & 1) ? -((j + 1) >> 1) : (j >> 1));
+    } else {
+        d0 = rank % is; axis = (rank / is) & 1; bn = rank / (2 * is);
+    }
+    const int S = ((bn * 2 + axis) * is + d0) * N3_LINE_PARTS + (k % N3_LINE_PARTS);      // sub-list S of that scan line (the producer's index)
     const int n = min(line_count[S], N3_LINE_CAP);
     if (n <= 0) return;
     float* s_gbl = reinterpret_cast<float*>(s_line + is);
-    const int d0 = L % is, axis = (L / is) & 1, bn = L / (2 * is);
     const size_t P = (size_t)p.B * is * is;
     const size_t base = (size_t)(1 - axis) * P + (size_t)bn * is * is + (size_t)d0 * is;   // the orientation in which the walks of this line are contiguous
-    for (int i = threadIdx.x; i < is; i += 256) { s_line[i] = sg2[base + i]; s_gbl[i] = gb2[base + i]; }
-    __syncthreads();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float two_over_is = 2.f / is;
     const int* words = reinterpret_cast<const int*>(line_rec + (size_t)S * N3_LINE_CAP);
     constexpr int cstep = 4;
-    int w = wid < n && lane < 9 ? words[wid * 9 + lane] : 0;              // the record of this wavefront's first crossing, one word per lane
+    int w = !tune::n3_line_fast && wid < n && lane < 9 ? words[wid * 9 + lane] : 0;   // (round-4 loop) the record of this wavefront's first crossing, one word per lane
+    if (tune::n3_line_fast) {
+        // the line's copy with ALL its loads in flight at once, the first record's behind them: a workgroup starts walking one memory
+        // round trip after its list length arrived (it was one per 256 pixels plus the record's; a CU holds 8 of these workgroups and
+        // runs ~40 of them, their start-up latencies were the gap between the kernel's issue time and its duration)
+        float4 v[4];
+        float sv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = min((int)threadIdx.x + 256 * k, is - 1);
+            v[k] = sg2[base + i]; sv[k] = gb2[base + i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = (int)threadIdx.x + 256 * k;
+            if (i < is) { s_line[i] = v[k]; s_gbl[i] = sv[k]; }
+        }
+        for (int i = threadIdx.x + 1024; i < is; i += 256) { s_line[i] = sg2[base + i]; s_gbl[i] = gb2[base + i]; }
+    } else {
+        for (int i = threadIdx.x; i < is; i += 256) { s_line[i] = sg2[base + i]; s_gbl[i] = gb2[base + i]; }
+    }
+    __syncthreads();
+    if (tune::n3_line_fast) {
+        // Per CROSSING the round-4 loop spent ~100 VALU instructions around ~85 of walking (SQ_INSTS_VALU 7.3e7 for 4.0e5 crossings of six
+        // 64-pixel groups each): nine v_readlane for the record, float compares for the side of the crossing point, two reductions with four
+        // v_readlane each, two atomics behind the compiler's uniform-address sequence (mbcnt, bcnt, cvt, mul).  Here
+        //   * the record is read with SCALAR loads (its address is wave-uniform; the list was written by the previous kernel), the next
+        //     record's before this crossing's walk;
+        //   * an out-walk starts at d1_out = floor(cross) + 1 (up) or ceil(cross) - 1 (down) and runs AWAY from the crossing point
+        //     (k_n3mr_backward_pixel_map_all, N3K:413-447): d1 - cross has the sign of the direction for every pixel, so the +-eps of a
+        //     vertex is the sign test of its slope's bit pattern - scalar;
+        //   * the two sums of a crossing end in lane 63 of their reduction (row_bcast steps) and are added to grad_faces FROM that lane:
+        //     no v_readlane, and a per-lane offset (+ lane - 63) keeps the compiler's uniform-address atomic sequence away.
+        const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+        const N3Crossing* recs = line_rec + (size_t)S * N3_LINE_CAP;
+        const float eps = p.eps;
+        const int lane_m63 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) - 63;     // (= lane - 63, from a source the compiler does not fold against `lane == 63`)
+        N3Crossing rc = recs[wid_u];
+        for (int c = wid_u; c < n; c += cstep) {
+            const N3Crossing cur = rc;
+            rc = recs[min(c + cstep, n - 1)];
+            const int packed = cur.packed, d1_out = packed & 0x1fff;
+            const bool up = packed & (1 << 13), ha = packed & (1 << 14), hb = packed & (1 << 15);
+            const int wf = up ? d1_out : 0, wt = up ? is - 1 : d1_out;        // (0 <= d1_out < is: the producer's `ok`)
+            const N3Ref r = {cur.ra, cur.r0, cur.r1, cur.r2};
+            // 0 < f * dd  <=>  f and dd have the same sign (f == +-0: dist = 0, the reference subtracts eps)
+            const int tab = __builtin_bit_cast(int, cur.ta), tbb = __builtin_bit_cast(int, cur.tb);
+            const float ea = (up ? tab > 0 : (tab < 0 && tab != (int)0x80000000)) ? eps : -eps;
+            const float eb = (up ? tbb > 0 : (tbb < 0 && tbb != (int)0x80000000)) ? eps : -eps;
+            const float fa = cur.ta * two_over_is, fb = cur.tb * two_over_is;
+            float pa = 0.f, pb = 0.f;
+            if (ha && hb) n3_line_walk<true, true, true>(s_line, s_gbl, wf, wt, lane, r, cur.cross, fa, ea, fb, eb, eps, pa, pb);
+            else if (ha) n3_line_walk<true, false, true>(s_line, s_gbl, wf, wt, lane, r, cur.cross, fa, ea, fb, eb, eps, pa, pb);
+            else if (hb) n3_line_walk<false, true, true>(s_line, s_gbl, wf, wt, lane, r, cur.cross, fa, ea, fb, eb, eps, pa, pb);
+            const float sa = ha ? n3_wave_sum_last(pa) : 0.f, sb = hb ? n3_wave_sum_last(pb) : 0.f;
+            if (lane == 63) {
+                if (sa != 0.f) atomicAdd(grad_faces + (unsigned)(cur.face * 9 + ((packed >> 16) & 15) + lane_m63), sa);
+                if (sb != 0.f) atomicAdd(grad_faces + (unsigned)(cur.face * 9 + ((packed >> 20) & 15) + lane_m63), sb);
+            }
+        }
+        return;
+    }
     for (int c = wid; c < n; c += cstep) {
         const int packed = __builtin_amdgcn_readlane(w, 0), face = __builtin_amdgcn_readlane(w, 1);
         const float cross = n3_bcast(__builtin_bit_cast(float, w), 2), ta = n3_bcast(__builtin_bit_cast(float, w), 3),
@@ -522,26 +602,6 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_line_walks(
         // -= diff / (dist +- eps), dist = t * (d1 - cross) * 2 / is (N3K:496-505; the constant factors folded: one rounding apart)
         const float fa = ta * two_over_is, fb = tb * two_over_is, eps = p.eps;
         float pa = 0.f, pb = 0.f;
-        if (tune::n3_line_fast) {
-            // every pixel of the walk strictly on one side of the crossing point?  ((float)d1 - cross is monotone in d1)
-            const bool above = (float)wf - cross > 0.f, below = (float)wt - cross < 0.f;
-            if (above || below) {
-                // 0 < f * dd  <=>  f and dd have the same sign (f == 0: dist = 0, the reference subtracts eps)
-                const float ea = (above ? fa > 0.f : fa < 0.f) ? eps : -eps, eb = (above ? fb > 0.f : fb < 0.f) ? eps : -eps;
-                if (ha && hb) n3_line_walk<true, true, true>(s_line, s_gbl, wf, wt, lane, r, cross, fa, ea, fb, eb, eps, pa, pb);
-                else if (ha) n3_line_walk<true, false, true>(s_line, s_gbl, wf, wt, lane, r, cross, fa, ea, fb, eb, eps, pa, pb);
-                else if (hb) n3_line_walk<false, true, true>(s_line, s_gbl, wf, wt, lane, r, cross, fa, ea, fb, eb, eps, pa, pb);
-            } else if (ha || hb) {
-                // (a vertex without a gradient still walks here; its slope is 0, its sum is dropped below)
-                n3_line_walk<true, true, false>(s_line, s_gbl, wf, wt, lane, r, cross, ha ? fa : 0.f, 0.f, hb ? fb : 0.f, 0.f, eps, pa, pb);
-            }
-            const float sa = ha ? n3_wave_sum_last(pa) : 0.f, sb = hb ? n3_wave_sum_last(pb) : 0.f;
-            if (lane == 0) {
-                if (sa != 0.f) atomicAdd(grad_faces + (size_t)face * 9 + ia, sa);
-                if (sb != 0.f) atomicAdd(grad_faces + (size_t)face * 9 + ib, sb);
-            }
-            continue;
-        }
         for (int d1 = wf + lane; d1 <= wt; d1 += 64) {
             const float diff = n3_diff(s_line[d1], s_gbl[d1], r);
             if (diff <= 0) continue;
@@ -954,10 +1014,10 @@ void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textur
                          unsigned long long* zkey, int32_t* face_index_map, float* weight_map, float* depth_map,
                          float* face_inv_map, float* rgb_map, float* alpha_map, int32_t* sampling_index_map,
                          float* sampling_weight_map, int B, int NF, int TS, int IS, float near_, float far_,
-                         float eps, const float* bg, int rrgb, int ralpha, int rdepth) {
+                         float eps, const float* bg, int rrgb, int ralpha, int rdepth, bool zkey_clean) {
     const N3Params p = make_n3(B, NF, TS, IS, near_, far_, eps, bg, rrgb, ralpha, rdepth);
     const long P = (long)B * IS * IS;
-    (void)hipMemsetAsync(zkey, 0xff, sizeof(unsigned long long) * P, st);
+    if (!zkey_clean) (void)hipMemsetAsync(zkey, 0xff, sizeof(unsigned long long) * P, st);     // (first use / after a regrow: k_n3mr_resolve clears what it read)
     const long waves = (long)B * NF;
     k_n3mr_zbuffer<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(p, faces, faces_inv, zkey);
     k_n3mr_resolve<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(p, faces, textures, faces_inv, zkey, face_index_map,

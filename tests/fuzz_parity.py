@@ -4,7 +4,8 @@
     python tests/fuzz_parity.py --cases 400 --seed 1
 
 Every case draws a scene (soup / sphere views / degenerate-heavy soup), the operator modes, K, image size,
-sigma, gamma, near/far, texture layout and batch size at random, renders with the HIP path, and applies the same
+sigma, gamma, near/far, texture layout and batch size at random - and, since round 5, how the launch is organised (bin size 8 / 16 / 32 /
+automatic, heavy-bin threshold, 4 / 8 wavefronts per workgroup, precise colour path) -, renders with the HIP path, and applies the same
 checks as tests/test_gpu_parity.py against the oracle: faces_info and the face-index buffer bit-exact, RGBA and
 aggrs_info within 1e-4, gradients within 1e-4 of the largest component.  Cases that hit the reference's
 undefined-behaviour corner (oracle counter) are skipped and counted."""
@@ -103,6 +104,13 @@ def draw_case(rng, big=False):
     return kind, fv, tex, kw
 
 
+def draw_launch(rng):
+    """How the library organises the launch - never what it computes: the operator's bin_size, the heavy-bin threshold and the
+    workgroup size of the multi-wavefront kernel (jr_softras_set_launch_policy), the colour-path arithmetic (round 5)."""
+    return dict(bin_size=int(rng.choice([0, 0, 8, 16, 32])), heavy_min=int(rng.choice([-1, -1, 4, 24, 100])),
+                waves=int(rng.choice([0, 0, 4, 8])), precise=bool(rng.integers(8) == 0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
@@ -121,7 +129,9 @@ def main():
         if port.ub_events():
             skipped += 1
             continue
-        fn = SoftRasterizeFunction(ctx=ctx, **kw)
+        launch = draw_launch(rng)
+        ctx.set_launch_policy(launch["heavy_min"], launch["waves"])
+        fn = SoftRasterizeFunction(ctx=ctx, bin_size=launch["bin_size"], precise_colour=launch["precise"], **kw)
         fn(fv, tex)
         g = rng.uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
         try:
@@ -129,13 +139,14 @@ def main():
             overflowed += st == "overflow"
             illcond += st == "illcond"
         except AssertionError as e:
-            print("FAIL case %d (%s, NF=%d, B=%d, %r): %s" % (i, kind, fv.shape[1], fv.shape[0], kw, e), flush=True)
+            print("FAIL case %d (%s, NF=%d, B=%d, %r, launch %r): %s" % (i, kind, fv.shape[1], fv.shape[0], kw, launch, e), flush=True)
             np.savez("gpurun_out/fuzz_fail_%d_%d.npz" % (args.seed, i), fv=fv, tex=tex, kw=repr(kw), g=g)
             failed += 1
             if failed >= args.max_failures:
                 raise SystemExit(1)
             continue
         done += 1
+    ctx.set_launch_policy(-1, 0)
     if illcond > max(2, 0.02 * max(done, 1)):
         print("WARNING: %d of %d cases are ill-conditioned (> 2 %%): a forward regression inside the 1e-4 RGBA bar would look like this" % (illcond, done))
         failed = max(failed, 1)

@@ -35,16 +35,20 @@ def test_softras_fuzz_slice(seed, cases):
         if port.ub_events():
             counts["skipped"] += 1                   # the reference's undefined-behaviour corner (SRK:107-121)
             continue
-        fn = SoftRasterizeFunction(ctx=ctx, **kw)
+        launch = fuzz_parity.draw_launch(rng)          # bin size, heavy-bin threshold, workgroup size, colour path: organisation only
+        ctx.set_launch_policy(launch["heavy_min"], launch["waves"])
+        fn = SoftRasterizeFunction(ctx=ctx, bin_size=launch["bin_size"], precise_colour=launch["precise"], **kw)
         fn(fv, tex)
         g = rng.uniform(-1, 1, ref["soft_colors"].shape).astype(np.float32)
         try:
             st = fuzz_parity.check_against(ref, fn, g, port.backward(ref, g), oracle=port)
         except AssertionError as e:
-            raise AssertionError("seed %d case %d (%s, NF=%d, %r): %s" % (seed, i, kind, fv.shape[1], kw, e))
+            ctx.set_launch_policy(-1, 0)
+            raise AssertionError("seed %d case %d (%s, NF=%d, %r, launch %r): %s" % (seed, i, kind, fv.shape[1], kw, launch, e))
         if st == "illcond":
             assert kw["aggr_func_alpha"] == "sum", "ill-conditioned gradient outside the exempt class: case %d %r" % (i, kw)
         counts[st] += 1
+    ctx.set_launch_policy(-1, 0)
     assert counts["illcond"] == 0, counts
     assert counts["ok"] >= cases // 2, counts
 

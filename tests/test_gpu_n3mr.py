@@ -264,3 +264,18 @@ def test_n3mr_silhouette_and_depth_modes_use_the_module_defaults():
     d = depth.numpy() if hasattr(depth, "numpy") else np.asarray(depth)
     refd = o.forward(faces, None, image_size=S, near=0.1, far=100, eps=1e-4, return_rgb=False, return_alpha=False, return_depth=True)
     assert np.array_equal(d.reshape(S, S), refd["depth_map"].reshape(S, S)[::-1])
+
+
+def test_n3mr_zbuffer_keys_are_reusable_across_forwards_of_one_context():
+    """k_n3mr_resolve clears the z-buffer keys it read, so that a context's next forward needs no memset launch: smaller, equal and
+    larger images in turn on ONE context (the larger one regrows the key array) must each match the oracle bit for bit."""
+    from oracle import N3mrOracle
+    o = N3mrOracle("port")
+    for nf, batch, IS, seed in ((280, 2, 96, 1), (280, 1, 48, 2), (3300, 2, 96, 3), (280, 2, 160, 4), (280, 1, 96, 5), (3300, 2, 160, 6)):
+        faces, tex = _scene(nf, batch, 2, seed, az0=10.0 * seed)
+        ref = o.forward(faces, tex, image_size=IS)
+        fn = RasterizeFunction(IS, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)
+        fn(faces, tex)
+        f, t, fim, wm, dm, rgb, alpha, fivm, sidx, swt = fn.save_vars
+        assert bits_equal(fim.numpy(), ref["face_index_map"]), (nf, batch, IS)
+        assert bits_equal(dm.numpy(), ref["depth_map"]) and bits_equal(alpha.numpy(), ref["alpha_map"])
