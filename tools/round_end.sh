@@ -7,7 +7,7 @@
 tag=$1
 out=gpurun_out/$tag
 mkdir -p $out
-(timeout 1200 python -m pytest tests -m gpu -q > $out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_pytest_gpu.log)
+(timeout 1500 python -m pytest tests -m gpu -q > $out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_pytest_gpu.log)
 tools/collect_profiles.sh $tag trace fetch write sq
 cp gpurun_out/profiles_$tag/${tag}_* $out/ 2>/dev/null
 python tools/pmc_to_json.py gpurun_out/profiles_$tag $tag > $out/${tag}_pmc_to_json.log 2>&1
@@ -21,8 +21,14 @@ timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --scene soup --no-secondary > $out/${tag}_bench_soup.json 2>> $out/${tag}_bench.err
 timeout 400 python tools/grad_parity.py > $out/${tag}_grad_parity.txt 2>&1
 timeout 400 python tools/time_configs.py > $out/${tag}_time_configs.txt 2>&1
+# round 5: randomised sweeps on the final kernels (the SoftRas one draws the launch organisation - bin size, threshold, workgroup size,
+# colour path - per case), the automatic launch policy against the 32-pixel reference on every critical-path shape, the N-rank dry run
+(timeout 900 python tests/fuzz_parity.py --cases 600 --seed ${FUZZ_SEED:-81} > $out/${tag}_fuzz_softras.log 2>&1; echo "rc=$?" >> $out/${tag}_fuzz_softras.log)
+(timeout 300 python tests/fuzz_n3mr.py --cases 1500 --seed ${FUZZ_SEED:-81} > $out/${tag}_fuzz_n3mr.log 2>&1; echo "rc=$?" >> $out/${tag}_fuzz_n3mr.log)
+timeout 600 python tools/geometry_sweep.py --quick --bins 32 > $out/${tag}_policy_vs_bin32.txt 2>&1
+timeout 120 python bench.py --dry-run-ranks 8 > $out/${tag}_dry_run_8_ranks.json 2>> $out/${tag}_bench.err
 # kernel trace of the demo2 loop with the chain around the rasteriser on the device
 (cd /tmp; export TMPDIR=/tmp; cd - > /dev/null; timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/demo2_prof -o demo2 --output-format csv -- python examples/demo2_deform.py --iters 100 --quiet > $out/${tag}_demo2_traced.log 2>&1)
 cp $(find gpurun_out/demo2_prof -name "*kernel_stats.csv" | head -1) $out/${tag}_demo2_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/demo2_prof $out/${tag}_demo2_traced.log
 rm -rf gpurun_out/profiles_$tag gpurun_out/profiles_${tag}_b1 gpurun_out/n3mr_prof
-tail -3 $out/${tag}_pytest_gpu.log; tail -c 400 $out/${tag}_bench.json
+tail -3 $out/${tag}_pytest_gpu.log; tail -2 $out/${tag}_fuzz_softras.log $out/${tag}_fuzz_n3mr.log; grep '^##' $out/${tag}_policy_vs_bin32.txt; tail -c 400 $out/${tag}_bench.json
