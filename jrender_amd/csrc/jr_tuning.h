@@ -175,6 +175,12 @@
 #ifndef JR_TUNE_N3_LINE_WALKS     // NMR pixel-map gradient: the out-walks regrouped by scan line and run from an LDS copy of the line (0: every face walks its own lines through the L2s)
 #define JR_TUNE_N3_LINE_WALKS 1
 #endif
+#ifndef JR_TUNE_N3_ZBUF_GROUP     // NMR z-buffer pass (round 5): faces per wavefront, set up in the lanes, walked one after the other (0: one wavefront per face, round 1 - 4)
+#define JR_TUNE_N3_ZBUF_GROUP 8
+#endif
+#ifndef JR_TUNE_N3_FACE_FAST      // NMR per-face depth / texture gradient (round 5): reciprocal pixel mapping, transposing reductions (0: round 4)
+#define JR_TUNE_N3_FACE_FAST 1
+#endif
 #ifndef JR_TUNE_N3_LINE_FAST      // NMR line walks (round 5): per-crossing sign of the eps, uniform trip counts, four groups of 64 pixels per trip (0: the round-4 loop)
 #define JR_TUNE_N3_LINE_FAST 1
 #endif
@@ -206,6 +212,8 @@ constexpr int n3_walks = JR_TUNE_N3_WALKS;
 constexpr bool n3_line_walks = JR_TUNE_N3_LINE_WALKS != 0;
 constexpr int n3_line_parts = JR_TUNE_N3_LINE_PARTS;
 constexpr bool n3_line_fast = JR_TUNE_N3_LINE_FAST != 0;
+constexpr int n3_zbuf_group = JR_TUNE_N3_ZBUF_GROUP;
+constexpr bool n3_face_fast = JR_TUNE_N3_FACE_FAST != 0;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr int fwd_exact = JR_TUNE_FWD_EXACT, bwd_exact = JR_TUNE_BWD_EXACT;
 constexpr bool fwd_hard_exact = JR_TUNE_FWD_HARD_EXACT != 0;

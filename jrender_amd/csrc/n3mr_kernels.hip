@@ -107,6 +107,86 @@ __global__ __launch_bounds__(256) void k_n3mr_zbuffer(N3Params p, const float* _
     }
 }
 
+__device__ inline float n3_bcast(float v, int s) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s));
+}
+
+// Round 5: the same pass with the per-FACE work in the lanes.  Above, every one of a face's 64 lanes computes the nine IEEE quotients of
+// its inverse, the bounding box and the back-face test - ~250 wave-uniform VALU instructions per front face before the first pixel
+// (SQ_INSTS_VALU 2.1e7 per launch of 78 000 faces: the kernel is VALU-bound at 34 of its 41 us).  Here a wavefront takes G consecutive
+// faces: lane l < G sets face l up (G = 16: a quarter of the lanes busy for ~1/16 of the former work; 4 900 wavefronts keep the GPU
+// filled, with G = 64 there would be 1.2 per SIMD), then the wavefront walks its front faces one after the other with the lanes over the
+// pixels of the bounding box as before - the face's 24 values arrive by v_readlane.  Bounding boxes up to 64 pixels high (all but
+// screen-filling faces) map lane -> (column, row) with one reciprocal instead of a 64-bit division per pixel.  Same arithmetic per face
+// and per pixel, same keys: bit-identical maps.
+template <int G>
+__global__ __launch_bounds__(256) void k_n3mr_zbuffer_grouped(N3Params p, const float* __restrict__ faces,
+                                                              float* __restrict__ faces_inv,
+                                                              unsigned long long* __restrict__ zkey) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int total = p.B * p.NF, face0 = wave * G;
+    if (face0 >= total) return;
+    const bool have = lane < G && face0 + lane < total;
+    const int fi = have ? face0 + lane : face0;
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = faces[(size_t)fi * 9 + k];
+    const bool back = (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]);                  // back side, N3K:63
+    float px[3], py[3], inv[9];
+    n3_face_inv(f, p.IS, px, py, inv);
+    if (have) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) faces_inv[(size_t)fi * 9 + k] = back ? 0.f : inv[k];             // (the reference's output is pre-zeroed; no memset launch here)
+    }
+    float x_min = p.IS, y_min = p.IS, x_max = 0, y_max = 0;                                          // N3K:89-99
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (px[k] < x_min) x_min = px[k];
+        if (px[k] > x_max) x_max = px[k];
+        if (py[k] < y_min) y_min = py[k];
+        if (py[k] > y_max) y_max = py[k];
+    }
+    const int ix0 = max(0, (int)x_min), ix1 = min(p.IS - 1, (int)x_max);
+    const int iy0 = max(0, (int)y_min), iy1 = min(p.IS - 1, (int)y_max);
+    const int bn_l = fi / p.NF, fn_l = fi - bn_l * p.NF;
+    unsigned long long todo = ballot(have && !back && ix0 <= ix1 && iy0 <= iy1);
+    while (todo) {
+        const int s = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        float bf[9], binv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { bf[k] = n3_bcast(f[k], s); binv[k] = n3_bcast(inv[k], s); }
+        const int bx0 = __builtin_amdgcn_readlane(ix0, s), bx1 = __builtin_amdgcn_readlane(ix1, s);
+        const int by0 = __builtin_amdgcn_readlane(iy0, s), by1 = __builtin_amdgcn_readlane(iy1, s);
+        const int bn = __builtin_amdgcn_readlane(bn_l, s), fn = __builtin_amdgcn_readlane(fn_l, s);
+        unsigned long long* zk = zkey + (size_t)bn * p.IS * p.IS;
+        const int hgt = by1 - by0 + 1;
+        auto pixel = [&](int xi, int yi) {
+            float w[3], zp;
+            if (!n3_pixel(bf, binv, xi, yi, p.IS, w, zp)) return;
+            // N3K:136 (zp <= near || far <= zp) AND N3K:147 (zp < depth_map, false for NaN): a zero-area face
+            // gives w_sum == 0 -> zp = NaN, which the reference never draws; reject unordered depths here
+            if (!(zp > p.near_ && zp < p.far_)) return;
+            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned, zp) << 32) | (unsigned)fn;
+            atomicMin(&zk[(size_t)yi * p.IS + xi], key);
+        };
+        if (hgt <= 64) {
+            // lane -> (column q, row r) of a block of 64 / hgt columns: q = floor(lane / hgt) through one reciprocal ((lane + 0.5) / hgt is
+            // at least 0.5 / 64 away from an integer: exact), then whole blocks of columns per trip
+            const float rh = __builtin_amdgcn_rcpf((float)hgt);
+            const int q = (int)(((float)lane + 0.5f) * rh), r = lane - q * hgt;
+            const int cpi = __builtin_amdgcn_readfirstlane((int)(64.5f * rh));            // columns per trip, >= 1
+            for (int c0 = bx0; c0 <= bx1; c0 += cpi) {
+                const int xi = c0 + q;
+                if (q < cpi && xi <= bx1) pixel(xi, by0 + r);
+            }
+        } else {
+            const long npix = (long)(bx1 - bx0 + 1) * hgt;
+            for (long idx = lane; idx < npix; idx += 64) pixel(bx0 + (int)(idx / hgt), by0 + (int)(idx % hgt));
+        }
+    }
+}
+
 // per pixel: winner -> face_index / depth / weights / face_inv; texture sample, background, alpha
 __global__ __launch_bounds__(256) void k_n3mr_resolve(
     N3Params p, const float* __restrict__ faces, const float* __restrict__ textures,
@@ -276,9 +356,6 @@ __device__ inline void n3_push(float diff, int d1, float cross, float ta, float 
     }
 }
 
-__device__ inline float n3_bcast(float v, int s) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s));
-}
 
 // One (edge, axis) of one face.  q = the edge's two vertices and the opposite one in pixel coordinates with
 // the walking axis second; `in` = planes in which consecutive scan positions are contiguous (lane = scan
@@ -891,6 +968,25 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_depth(
 // atomics and without a prior memset of grad_textures.  grad_faces already holds the pixel-map part
 // (k_n3mr_backward_pixel_map ran before on the same stream) and is updated in place by its only owner.
 constexpr int N3_TEX_LDS = 1536;            // floats of texel gradient per wavefront (TS <= 8)
+// Sum of 16 per-lane values over the 16 lanes of a DPP row, "transposed": lane i of the row ends up with the row total of v[i].
+// Butterfly with halving payload (8 + 4 + 2 + 1 exchanges): partners row_mirror, row_half_mirror, quad_perm [3,2,1,0], [1,0,3,2]
+// (the scheme of softras_backward.hip: row_transpose_reduce).
+template <int CTRL>
+__device__ inline float n3_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ inline float n3_row_transpose_reduce(const float (&v)[16], int li) {
+    float a[8], b[4], c[2];
+    const bool h8 = li & 8, h4 = li & 4, h2 = li & 2, h1 = li & 1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = (h8 ? v[j + 8] : v[j]) + n3_dpp<0x140>(h8 ? v[j] : v[j + 8]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = (h4 ? a[j + 4] : a[j]) + n3_dpp<0x141>(h4 ? a[j] : a[j + 4]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) c[j] = (h2 ? b[j + 2] : b[j]) + n3_dpp<0x1B>(h2 ? b[j] : b[j + 2]);
+    return (h1 ? c[1] : c[0]) + n3_dpp<0xB1>(h1 ? c[0] : c[1]);
+}
+
 __global__ __launch_bounds__(256) void k_n3mr_backward_face(
     N3Params p, const float* __restrict__ faces, const int32_t* __restrict__ face_index_map,
     const float* __restrict__ depth_map, const float* __restrict__ face_inv_map,
@@ -926,8 +1022,24 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
         const int wid = ix1 - ix0 + 1;
         const long npix = (ix1 < ix0 || iy1 < iy0) ? 0 : (long)wid * (iy1 - iy0 + 1);
         const size_t mbase = (size_t)bn * is * is;
-        for (long idx = lane; idx < npix; idx += 64) {
-            const int yi = iy0 + (int)(idx / wid), xi = ix0 + (int)(idx % wid);           // lanes along rows
+        // lanes along rows.  Boxes up to 64 pixels wide (all but screen-filling faces): lane -> (row q, column r) of a block of 64 / wid
+        // rows through one reciprocal ((lane + 0.5) / wid is at least 0.5 / 64 away from an integer: exact) instead of a 64-bit division
+        // and remainder per pixel (round 5: ~80 of this kernel's ~280 VALU instructions per face)
+        const bool small = tune::n3_face_fast && wid >= 1 && wid <= 64;
+        const float rw = __builtin_amdgcn_rcpf((float)max(wid, 1));
+        const int q = (int)(((float)lane + 0.5f) * rw), r = lane - q * wid;
+        const int rpi = small ? __builtin_amdgcn_readfirstlane((int)(64.5f * rw)) : 1;       // rows per trip
+        const long trips = npix <= 0 ? 0 : (small ? (long)(iy1 - iy0 + rpi) / rpi : (npix + 63) / 64);
+        for (long t = 0; t < trips; t++) {
+            int yi, xi;
+            if (small) {
+                yi = iy0 + (int)t * rpi + q; xi = ix0 + r;
+                if (q >= rpi || yi > iy1) continue;
+            } else {
+                const long idx = t * 64 + lane;
+                if (idx >= npix) continue;
+                yi = iy0 + (int)(idx / wid); xi = ix0 + (int)(idx % wid);
+            }
             const size_t i = mbase + (size_t)yi * is + xi;
             if (face_index_map[i] != fn) continue;
             mine = true;
@@ -975,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
                 }
             }
         }
-        if (p.return_rgb && ts == 2 && ballot(mine) != 0ull) {   // (uniform) the register sums join the LDS accumulators
+        if (!tune::n3_face_fast && p.return_rgb && ts == 2 && ballot(mine) != 0ull) {   // (uniform) the register sums join the LDS accumulators
             __builtin_amdgcn_s_waitcnt(0);
 #pragma unroll
             for (int k = 0; k < 24; k++) {
@@ -986,7 +1098,33 @@ __global__ __launch_bounds__(256) void k_n3mr_backward_face(
     }
     // three faces out of four own no pixel here (back faces, hidden front faces): they skip the reductions (round 4)
     const bool some = ballot(mine) != 0ull;
-    if (p.return_depth && some) {
+    if (tune::n3_face_fast) {
+        // Round 5: the 24 texel sums and the 9 vertex components were 33 separate wave reductions (~13 VALU instructions each: 430 per face
+        // that owns a pixel).  Two "transposing" row reductions instead - lane i of every 16-lane row ends up with the row total of value i
+        // (15 exchanges for 16 values) - then two cross-row steps: ~140 instructions for 32 values; the 33rd keeps its own reduction.
+        const bool tex2 = p.return_rgb && ts == 2;
+        if (some && (tex2 || p.return_depth)) {
+            float va[16], vb[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) va[k] = treg[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { vb[k] = treg[16 + k]; vb[8 + k] = g[k]; }
+            const int li = lane & 15;
+            float ra = n3_row_transpose_reduce(va, li), rb = n3_row_transpose_reduce(vb, li);
+            ra += __shfl_xor(ra, 16); rb += __shfl_xor(rb, 16);
+            ra += __shfl_xor(ra, 32); rb += __shfl_xor(rb, 32);
+            if (tex2) {
+                __builtin_amdgcn_s_waitcnt(0);
+                if (lane < 16) acc[lane] += ra;
+                if (lane < 8) acc[16 + lane] += rb;
+            }
+            if (p.return_depth) {
+                if (lane >= 8 && lane < 16 && rb != 0.f) grad_faces[(size_t)wave * 9 + (lane - 8)] += rb;
+                const float v8 = n3_wave_sum(g[8]);
+                if (lane == 0 && v8 != 0.f) grad_faces[(size_t)wave * 9 + 8] += v8;
+            }
+        }
+    } else if (p.return_depth && some) {
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             float v = g[k];
@@ -1019,7 +1157,12 @@ void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textur
     const long P = (long)B * IS * IS;
     if (!zkey_clean) (void)hipMemsetAsync(zkey, 0xff, sizeof(unsigned long long) * P, st);     // (first use / after a regrow: k_n3mr_resolve clears what it read)
     const long waves = (long)B * NF;
-    k_n3mr_zbuffer<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(p, faces, faces_inv, zkey);
+    if (tune::n3_zbuf_group > 0) {
+        constexpr int G = tune::n3_zbuf_group > 0 ? tune::n3_zbuf_group : 1;
+        const long groups = (waves + G - 1) / G;
+        k_n3mr_zbuffer_grouped<G><<<(unsigned)((groups * 64 + 255) / 256), 256, 0, st>>>(p, faces, faces_inv, zkey);
+    } else
+        k_n3mr_zbuffer<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, st>>>(p, faces, faces_inv, zkey);
     k_n3mr_resolve<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(p, faces, textures, faces_inv, zkey, face_index_map,
                                                                weight_map, depth_map, face_inv_map, rgb_map, alpha_map,
                                                                sampling_index_map, sampling_weight_map);

@@ -75,6 +75,8 @@ VARIANTS = {
     "n3_w5": ["JR_TUNE_N3_PIXMAP_WAVES=5"], "n3_w6": ["JR_TUNE_N3_PIXMAP_WAVES=6"],   # round 4: NMR pixel-map gradient at 5 / 6 wavefronts per SIMD (12 / 72 B of scratch; product: 4, none)
     "n3_walks2": ["JR_TUNE_N3_WALKS=2"], "n3_walks8": ["JR_TUNE_N3_WALKS=8"], "n3_walks1": ["JR_TUNE_N3_WALKS=1"],   # round 4: NMR out-walks in flight per wavefront (product: 4)
     "n3diag_noout": ["JR_TUNE_DIAG=2048"], "n3diag_noin": ["JR_TUNE_DIAG=4096"], "n3diag_nowalks": ["JR_TUNE_DIAG=6144"],   # WRONG gradients: the NMR pixel-map kernel without its out / in walks
+    "n3_face_r4": ["JR_TUNE_N3_FACE_FAST=0"],           # round 5: NMR per-face depth / texture kernel with 64-bit pixel divisions and 33 separate wave reductions (round 4)
+    "n3_zb_r4": ["JR_TUNE_N3_ZBUF_GROUP=0"], "n3_zb4": ["JR_TUNE_N3_ZBUF_GROUP=4"], "n3_zb16": ["JR_TUNE_N3_ZBUF_GROUP=16"], "n3_zb32": ["JR_TUNE_N3_ZBUF_GROUP=32"],   # round 5: NMR z-buffer pass with one wavefront per face (rounds 1 - 4) / 4 / 16 / 32 faces per wavefront (product: 8)
     "n3_line_r4": ["JR_TUNE_N3_LINE_FAST=0"],             # round 5: the round-4 walk loop of k_n3mr_backward_line_walks (per-pixel eps sign, per-lane trip count)
     "n3_face_walks": ["JR_TUNE_N3_LINE_WALKS=0", "JR_TUNE_N3_PIXMAP_WAVES=4"], "n3_lp1": ["JR_TUNE_N3_LINE_PARTS=1"], "n3_lp4": ["JR_TUNE_N3_LINE_PARTS=4"], "n3_lp16": ["JR_TUNE_N3_LINE_PARTS=16"], "n3_lw4": ["JR_TUNE_N3_PIXMAP_WAVES=4"],           # round 4: NMR out-walks by the per-face kernel through the L2s (before the per-line regrouping)
     "hard_exact_off": ["JR_TUNE_FWD_HARD_EXACT=0"],          # round 4: what does the uniform 'hard alpha -> IEEE inside distance' branch cost the default modes?
