@@ -17,6 +17,7 @@ rm -rf gpurun_out/n3mr_prof; tools/collect_profiles_n3mr.sh
 for f in gpurun_out/n3mr_prof/n3mr_*; do cp $f $out/${tag}_$(basename $f); done
 python tools/pmc_n3mr_to_json.py gpurun_out/n3mr_prof $tag > $out/${tag}_pmc_n3mr_to_json.log 2>&1
 cp profiles/traffic_latest.json profiles/valu_latest.json profiles/traffic_n3mr_latest.json $out/
+(timeout 300 python __graft_entry__.py --smoke > $out/${tag}_smoke.log 2>&1; echo "smoke rc=$?" >> $out/${tag}_smoke.log)
 timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --scene soup --no-secondary > $out/${tag}_bench_soup.json 2>> $out/${tag}_bench.err
 timeout 400 python tools/grad_parity.py > $out/${tag}_grad_parity.txt 2>&1
@@ -31,4 +32,4 @@ timeout 120 python bench.py --dry-run-ranks 8 > $out/${tag}_dry_run_8_ranks.json
 (cd /tmp; export TMPDIR=/tmp; cd - > /dev/null; timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/demo2_prof -o demo2 --output-format csv -- python examples/demo2_deform.py --iters 100 --quiet > $out/${tag}_demo2_traced.log 2>&1)
 cp $(find gpurun_out/demo2_prof -name "*kernel_stats.csv" | head -1) $out/${tag}_demo2_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/demo2_prof $out/${tag}_demo2_traced.log
 rm -rf gpurun_out/profiles_$tag gpurun_out/profiles_${tag}_b1 gpurun_out/n3mr_prof
-tail -3 $out/${tag}_pytest_gpu.log; tail -2 $out/${tag}_fuzz_softras.log $out/${tag}_fuzz_n3mr.log; grep '^##' $out/${tag}_policy_vs_bin32.txt; tail -c 400 $out/${tag}_bench.json
+tail -n 3 $out/${tag}_pytest_gpu.log; tail -n 1 $out/${tag}_smoke.log; tail -n 2 $out/${tag}_fuzz_softras.log; tail -n 2 $out/${tag}_fuzz_n3mr.log; grep '^##' $out/${tag}_policy_vs_bin32.txt; tail -c 400 $out/${tag}_bench.json
