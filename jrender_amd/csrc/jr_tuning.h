@@ -147,6 +147,9 @@
 #ifndef JR_TUNE_BWD_SPLIT         // backward: wavefronts per tile of a HEAVY bin in launches of up to BWD_SPLIT_PIXELS pixels (each keeps the ids with id % SPLIT == its part); 0 / 1 = off
 #define JR_TUNE_BWD_SPLIT 4
 #endif
+#ifndef JR_TUNE_BWD_SPLIT8_PIXELS  // ... EIGHT wavefronts per heavy tile for launches of up to this many pixels (round 5)
+#define JR_TUNE_BWD_SPLIT8_PIXELS 131072
+#endif
 #ifndef JR_TUNE_BWD_SPLIT_PIXELS
 #define JR_TUNE_BWD_SPLIT_PIXELS 1572864
 #endif
@@ -236,7 +239,7 @@ constexpr int bwd_split = JR_TUNE_BWD_SPLIT;
 constexpr int bwd_tex_lds_max = JR_TUNE_BWD_TEX_LDS_MAX;
 constexpr long bwd_tex_lds_pixels = JR_TUNE_BWD_TEX_LDS_PIXELS;
 constexpr bool bwd_one_atomic = JR_TUNE_BWD_ONE_ATOMIC != 0;
-constexpr long bwd_split_pixels = JR_TUNE_BWD_SPLIT_PIXELS;
+constexpr long bwd_split_pixels = JR_TUNE_BWD_SPLIT_PIXELS, bwd_split8_pixels = JR_TUNE_BWD_SPLIT8_PIXELS;
 constexpr int fwd_waves32 = JR_TUNE_FWD_WAVES32;
 constexpr int fwd_waves64 = JR_TUNE_FWD_WAVES64;
 constexpr long fwd_heavy_pixels = JR_TUNE_FWD_HEAVY_PIXELS;

@@ -228,7 +228,7 @@ constexpr int bwd_waves(int dist, int rgb, int kcap, bool texlds) {
 
 template <int DIST, int RGB, int KCAP, bool TEXLDS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DIST, RGB, KCAP, TEXLDS)))) void k_softras_backward(
-    RasterParams p, int nbins, int heavy_cap, const float* __restrict__ textures,
+    RasterParams p, int nbins, int heavy_cap, int split_log2, const float* __restrict__ textures,
     const FaceGeo* __restrict__ geo, const int* __restrict__ bin_order, const int* __restrict__ bin_count,
     const float* __restrict__ rgba, const float* __restrict__ aggrs,
     const int32_t* __restrict__ ids, const float* __restrict__ grad_rgba,
@@ -257,14 +257,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
     // wavefront `part` keeps the buffered ids with id % SPLIT == part and is otherwise a complete tile job.  The
     // gradient is a sum over (pixel, face) pairs, so the parts do not talk to each other; what they share is the
     // critical path of a launch that cannot fill the GPU (one view: the limb tiles' extraction + pair loop).
-    constexpr int SPLIT = tune::bwd_split > 0 ? tune::bwd_split : 1;
+    // (split_log2: 4 wavefronts per heavy tile, 8 for launches of up to tune::bwd_split8_pixels - the spot cow at 256^2: 0.203 -> 0.182 ms,
+    //  while the 1024^2 shapes lose 1 - 5 % with 8, round 5 call 15; a scalar of the prologue only, it is dead before the pair loop)
+    static_assert((tune::bwd_split & (tune::bwd_split - 1)) == 0, "JR_TUNE_BWD_SPLIT: a power of two (the parts are id & (split - 1))");
+    const int smask = (1 << split_log2) - 1;
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;      // k-th workgroup of its XCD
     const int nheavy = heavy_cap > 0 ? min((int)counters[3], heavy_cap) : 0;
     const int hx = (nheavy - xcd + 7) >> 3;                   // heavy bins dealt to this XCD (launch ranks xcd, xcd + 8, ...)
     const int tl = 2 * sub_log2_of(p), tmask = (1 << tl) - 1;     // a bin has 1 << tl tiles
     int brank, sub, part = -1;
-    if (k < (hx << tl) * SPLIT) { brank = ((k / SPLIT) >> tl) * 8 + xcd; sub = (k / SPLIT) & tmask; part = k % SPLIT; }
-    else { const int k2 = k - (hx << tl) * SPLIT; brank = (hx + (k2 >> tl)) * 8 + xcd; sub = k2 & tmask; }   // bins are dealt round-robin to the XCDs ...
+    if (k < ((hx << tl) << split_log2)) { brank = ((k >> split_log2) >> tl) * 8 + xcd; sub = (k >> split_log2) & tmask; part = k & smask; }
+    else { const int k2 = k - ((hx << tl) << split_log2); brank = (hx + (k2 >> tl)) * 8 + xcd; sub = k2 & tmask; }   // bins are dealt round-robin to the XCDs ...
     if (brank >= nbins) return;
     const int bin = bin_order[brank];                         // ... heaviest first (k_bin_alloc_schedule)
     const int n = bin_count[bin];
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
 #pragma unroll
         for (int k = 0; k < KCAP; k++) {
             live = live && raw[k] >= 0 && raw[k] < p.NF;   // -1 ends the list (ids outside [0, NF) too)
-            mine[k] = (live && (part < 0 || (int)((unsigned)raw[k] % (unsigned)SPLIT) == part)) ? raw[k] : BIG;
+            mine[k] = (live && (part < 0 || (raw[k] & smask) == part)) ? raw[k] : BIG;
         }
     }
     sort_ascending(mine);
@@ -571,7 +574,9 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
     const int nbins = ntiles >> tl;
     // heavy bins' tiles by tune::bwd_split wavefronts each when the launch is too small to fill the GPU anyway
     const int heavy_cap = backward_splits_heavy_tiles(p, ws) ? heavy_bins_cap(ws, nbins) : 0;   // (bound of counters[3], as in the forward)
-    const int grid = (8 << tl) * (tune::bwd_split * ((heavy_cap + 7) / 8) + (nbins + 7) / 8);   // whole bins per XCD slot
+    const int split = heavy_cap > 0 && (long)p.B * p.IS * p.IS <= (long)tune::bwd_split8_pixels ? 8 : (tune::bwd_split > 1 ? tune::bwd_split : 1);
+    const int split_log2 = split >= 8 ? 3 : (split >= 4 ? 2 : (split >= 2 ? 1 : 0));
+    const int grid = (8 << tl) * ((1 << split_log2) * ((heavy_cap + 7) / 8) + (nbins + 7) / 8);   // whole bins per XCD slot
     // texture blocks in LDS: 'surface' textures of a few texels in launches that are latency-, not occupancy-bound
     const int tex_lds = (p.tex == 0 && p.T > 1 && p.T <= tune::bwd_tex_lds_max && RGB == 1 &&
                          (long)p.B * p.IS * p.IS <= (long)tune::bwd_tex_lds_pixels) ? 1 : 0;
@@ -579,7 +584,7 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
                         (tex_lds ? sizeof(float) * 2 * 3 * p.T * tune::bwd_batch : 0);      // texel colours + texel gradient sums
 #define JR_BWD_K(KC, TL) \
     k_softras_backward<DIST, RGB, KC, TL><<<grid, 64, smem, st>>>( \
-        p, nbins, heavy_cap, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba, \
+        p, nbins, heavy_cap, split_log2, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba, \
         grad_faces, grad_textures, ws.counters)
     if (RGB == 1 && tex_lds) {           // (the staged-texture instantiations exist for the softmax colour path only: nothing else reads texels)
         if (p.K <= 16) JR_BWD_K(16, (RGB == 1));
