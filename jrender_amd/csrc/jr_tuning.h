@@ -224,6 +224,11 @@ constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;
 constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
+// record slots per wavefront by K capacity: at K <= 64 the registers cap both raster kernels at 3 wavefronts per SIMD (12 per CU), so 64
+// slots (11.3 KB) cost no occupancy and save batch turn-arounds: forward 1.444 -> 1.393 ms, backward 1.548 -> 1.529 (round 5 call 17);
+// at K <= 32 (4 per SIMD) 56 / 64 slots measured slower in both kernels
+constexpr int fwd_batch_for(int kcap) { return kcap > 32 ? 64 : JR_TUNE_FWD_BATCH; }
+constexpr int bwd_batch_for(int kcap) { return kcap > 32 ? 64 : JR_TUNE_BWD_BATCH; }
 constexpr int fwd_batch_mixed = JR_TUNE_FWD_BATCH_MIXED;
 constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
 constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;

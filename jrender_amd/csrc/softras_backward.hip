@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
     float* __restrict__ grad_faces, float* __restrict__ grad_textures, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 s_dyn[];
     // faces per batch: a tile of the headline workload needs ~40; 64 slots of 176 B cap a CU at 13 wavefronts
-    constexpr int BATCH = tune::bwd_batch;
+    constexpr int BATCH = TEXLDS ? tune::bwd_batch_for(16) : tune::bwd_batch_for(KCAP);     // (the staged texel blocks are 24 T bytes per slot: no larger batches there)
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
     float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
     // TEXLDS (round 5; its own instantiations: as a run-time flag it cost the default kernels 32 B of scratch and + 50 % time; 'surface' textures with 1 < T <= BWD_TEX_LDS_MAX texels, small launches): the batch's texture blocks
@@ -580,8 +580,9 @@ static void launch_k(hipStream_t st, const RasterParams& p, int ntiles, const fl
     // texture blocks in LDS: 'surface' textures of a few texels in launches that are latency-, not occupancy-bound
     const int tex_lds = (p.tex == 0 && p.T > 1 && p.T <= tune::bwd_tex_lds_max && RGB == 1 &&
                          (long)p.B * p.IS * p.IS <= (long)tune::bwd_tex_lds_pixels) ? 1 : 0;
-    const size_t smem = sizeof(FaceRec) * tune::bwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::bwd_batch : 0) +
-                        (tex_lds ? sizeof(float) * 2 * 3 * p.T * tune::bwd_batch : 0);      // texel colours + texel gradient sums
+    const int batch = (p.K <= 16 || tex_lds) ? tune::bwd_batch_for(16) : (p.K <= 32 ? tune::bwd_batch_for(32) : tune::bwd_batch_for(64));
+    const size_t smem = sizeof(FaceRec) * batch + (p.tex == 1 ? sizeof(float) * 9 * batch : 0) +
+                        (tex_lds ? sizeof(float) * 2 * 3 * p.T * batch : 0);      // texel colours + texel gradient sums
 #define JR_BWD_K(KC, TL) \
     k_softras_backward<DIST, RGB, KC, TL><<<grid, 64, smem, st>>>( \
         p, nbins, heavy_cap, split_log2, textures, ws.geo, ws.bin_order, ws.bin_count, rgba, aggrs, ids, grad_rgba, \

@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     }
     TileGeom t;
     if (!tile_geom(p, bin, k & tmask, n, threadIdx.x, t, bl)) return;
-    tile_single<DIST, RGB, KCAP, tune::fwd_batch, true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
+    tile_single<DIST, RGB, KCAP, tune::fwd_batch_for(KCAP), true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
 }
 
 // NW = four or eight wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first
@@ -1459,7 +1459,8 @@ static void launch_kk(hipStream_t st, const RasterParams& p, const float* textur
     const int grid = ((ntiles + per - 1) / per) * per;   // whole bins per XCD slot
     // JR_FWD_LDS_PAD (bytes, diagnostics only): more dynamic LDS per wavefront = fewer wavefronts per CU
     static const size_t pad = getenv("JR_FWD_LDS_PAD") ? (size_t)atol(getenv("JR_FWD_LDS_PAD")) : 0;
-    const size_t smem = sizeof(FaceRec) * tune::fwd_batch + (p.tex == 1 ? sizeof(float) * 9 * tune::fwd_batch : 0) + pad;
+    constexpr int BATCH1 = tune::fwd_batch_for(KCAP);
+    const size_t smem = sizeof(FaceRec) * BATCH1 + (p.tex == 1 ? sizeof(float) * 9 * BATCH1 : 0) + pad;
     if (bin_log2_of(p) == 5)
         k_softras_forward<DIST, RGB, KCAP, 5><<<grid, 64, smem, st>>>(
             p, ntiles, textures, ws.geo, ws.bin_order, ws.bin_count, ws.bin_base, ws.pool, ws.counters, ws.pool_cap, aggrs, rgba, ids);
