@@ -77,7 +77,7 @@ VARIANTS = {
     "n3diag_noout": ["JR_TUNE_DIAG=2048"], "n3diag_noin": ["JR_TUNE_DIAG=4096"], "n3diag_nowalks": ["JR_TUNE_DIAG=6144"],   # WRONG gradients: the NMR pixel-map kernel without its out / in walks
     "n3_face_r4": ["JR_TUNE_N3_FACE_FAST=0"],           # round 5: NMR per-face depth / texture kernel with 64-bit pixel divisions and 33 separate wave reductions (round 4)
     "n3_zb_r4": ["JR_TUNE_N3_ZBUF_GROUP=0"], "n3_zb4": ["JR_TUNE_N3_ZBUF_GROUP=4"], "n3_zb16": ["JR_TUNE_N3_ZBUF_GROUP=16"], "n3_zb32": ["JR_TUNE_N3_ZBUF_GROUP=32"],   # round 5: NMR z-buffer pass with one wavefront per face (rounds 1 - 4) / 4 / 16 / 32 faces per wavefront (product: 8)
-    "fwd56": ["JR_TUNE_FWD_BATCH=56"], "fwd64": ["JR_TUNE_FWD_BATCH=64"],   # round 5: record slots per wavefront of the one-wavefront forward for K > 16, where the VGPRs - not LDS - bound the occupancy (time with --K 32 / --K 64; at K = 16 these cost occupancy)
+    "fwd52": ["JR_TUNE_FWD_BATCH=52"], "fwd56": ["JR_TUNE_FWD_BATCH=56"], "fwd64": ["JR_TUNE_FWD_BATCH=64"],   # round 5: record slots per wavefront of the one-wavefront forward for K > 16, where the VGPRs - not LDS - bound the occupancy (time with --K 32 / --K 64; at K = 16 these cost occupancy)
     "n3_line_r4": ["JR_TUNE_N3_LINE_FAST=0"],             # round 5: the round-4 walk loop of k_n3mr_backward_line_walks (per-pixel eps sign, per-lane trip count)
     "n3_face_walks": ["JR_TUNE_N3_LINE_WALKS=0", "JR_TUNE_N3_PIXMAP_WAVES=4"], "n3_lp1": ["JR_TUNE_N3_LINE_PARTS=1"], "n3_lp4": ["JR_TUNE_N3_LINE_PARTS=4"], "n3_lp16": ["JR_TUNE_N3_LINE_PARTS=16"], "n3_lw4": ["JR_TUNE_N3_PIXMAP_WAVES=4"],           # round 4: NMR out-walks by the per-face kernel through the L2s (before the per-line regrouping)
     "hard_exact_off": ["JR_TUNE_FWD_HARD_EXACT=0"],          # round 4: what does the uniform 'hard alpha -> IEEE inside distance' branch cost the default modes?
