@@ -63,6 +63,7 @@ def main(argv=None):
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--gpus', type=int, default=1, help="spawn this many ranks (one process per GPU)")
     ap.add_argument('--history-out', default=None, help="rank 0 writes the loss of every iteration to this .npy")
+    ap.add_argument('--graph', action='store_true', help="device front end, one rank: run the iteration as ONE HIP graph (recorded at the third iteration, replayed afterwards)")
     ap.add_argument('--front-end', choices=['device', 'host'], default='device',
                     help="where the camera / gather / loss steps around the rasteriser run (see the module docstring)")
     args = ap.parse_args(argv)
@@ -84,6 +85,9 @@ def main(argv=None):
     else:
         tv, tf = jr.synthetic.uv_sphere(52, 27)                               # 1 352-vertex class template
     device = args.front_end == 'device'
+    graph_mode = bool(args.graph)
+    if graph_mode and (not device or world > 1):
+        raise SystemExit("--graph needs the device front end on one rank (a collective cannot be recorded)")
     ctx = jr.Context.default()
     model = Model(tv, tf, ctx=ctx if device else None)
     # (demo2-deform.py:65 also passes bin_size=16, max_elems_per_bin=2700 - tuning of the reference's own binned kernels.  Here
@@ -119,26 +123,49 @@ def main(argv=None):
             iou_sum = np.asarray(comm.all_reduce_sum_host(np.ascontiguousarray(iou_sum, np.float32)), np.float64)
         return (1.0 - iou_sum / B) + 0.03 * h[:, 1] + 0.0003 * h[:, 2], h
 
-    for it in range(args.iters):
-        vertices = model.forward()                                            # [1,nv,3] (device front end: a DeviceArray)
-        if device:
-            # ONE vertex set on the device; the camera step broadcasts it over this rank's eyes (demo2-deform.py:45
-            # materialises the copies with repeat())
-            mesh = jr.Mesh(vertices, model.faces)
-            pred = renderer.render_mesh(mesh, mode='silhouettes')             # DeviceArray [nb,IS,IS]
-            iou, g_sil = jr.neg_iou_loss_and_grad(pred, target_d, total_views=B)
-            g_v = renderer.grad_vertices(grad_silhouettes=g_sil)              # DeviceArray [1,nv,3]: summed over the views
-            if comm is not None:
-                g_v = comm.all_reduce_sum(g_v)           # RCCL on the device buffer
-            # the regularisers: value and gradient on the same device vertices; nothing has waited for the GPU
-            lap, g_lap = model.laplacian_loss.value_and_grad(vertices)
-            flat, g_flat = model.flatten_loss.value_and_grad(vertices)
-            # parametrisation VJP of g_v + 0.03 g_lap + 0.0003 g_flat (demo2-deform.py:85-88), Adam on the device
-            optimizer.step(model.backward(g_v, (0.03, g_lap), (0.0003, g_flat)))
+    # --graph: the iteration number lives on the device (Adam's step, the history row), two iterations run as usual, the third is
+    # RECORDED into a HIP graph (ctx.capture) and every further one is a replay of it: one launch per iteration instead of ~30
+    it_dev = ctx.array(np.zeros(1, np.int32)) if graph_mode else None
+
+    def device_iteration(it):
+        vertices = model.forward()                                            # [1,nv,3] DeviceArray
+        # ONE vertex set on the device; the camera step broadcasts it over this rank's eyes (demo2-deform.py:45
+        # materialises the copies with repeat())
+        mesh = jr.Mesh(vertices, model.faces)
+        pred = renderer.render_mesh(mesh, mode='silhouettes')             # DeviceArray [nb,IS,IS]
+        iou, g_sil = jr.neg_iou_loss_and_grad(pred, target_d, total_views=B)
+        g_v = renderer.grad_vertices(grad_silhouettes=g_sil)              # DeviceArray [1,nv,3]: summed over the views
+        if comm is not None:
+            g_v = comm.all_reduce_sum(g_v)           # RCCL on the device buffer
+        # the regularisers: value and gradient on the same device vertices; nothing has waited for the GPU
+        lap, g_lap = model.laplacian_loss.value_and_grad(vertices)
+        flat, g_flat = model.flatten_loss.value_and_grad(vertices)
+        # parametrisation VJP of g_v + 0.03 g_lap + 0.0003 g_flat (demo2-deform.py:85-88), Adam on the device
+        optimizer.step(model.backward(g_v, (0.03, g_lap), (0.0003, g_flat)), iteration=it_dev)
+        if it_dev is None:
             ctx.scalar_accumulate(hist, 3 * it + 0, iou)
             ctx.scalar_accumulate(hist, 3 * it + 1, lap.values)
             ctx.scalar_accumulate(hist, 3 * it + 2, flat.values)
         else:
+            ctx.scalar_accumulate(hist, 0, iou, iteration=it_dev, stride=3)
+            ctx.scalar_accumulate(hist, 1, lap.values, iteration=it_dev, stride=3)
+            ctx.scalar_accumulate(hist, 2, flat.values, iteration=it_dev, stride=3)
+            ctx.counter_add(it_dev, 1)
+
+    graph = None
+    for it in range(args.iters):
+        if device:
+            if graph is not None:
+                graph.launch()
+            elif graph_mode and it == 2:
+                with ctx.capture() as g:
+                    device_iteration(it)
+                graph = g
+                graph.launch()                       # (the capture itself executed nothing)
+            else:
+                device_iteration(it)
+        else:
+            vertices = model.forward()
             mesh = jr.Mesh(np.repeat(vertices, nb, 0), np.repeat(model.faces, nb, 0))
             pred = renderer.render_mesh(mesh, mode='silhouettes').numpy().reshape(nb, args.image_size, args.image_size)
             # neg-IoU over ALL views: per-view IoUs are independent, so the local part is (1/B) * sum over local views
@@ -151,6 +178,8 @@ def main(argv=None):
             reg = (model.laplacian_loss(vertices), model.laplacian_loss.backward(vertices)) + model.flatten_loss.value_and_grad(vertices)
             hist[it] = (float((inter / union).sum()), float(np.mean(reg[0])), float(np.mean(reg[2])))
             optimizer.step(model.backward(g_v, (0.03, reg[1]), (0.0003, reg[3])))
+        if graph is not None and (it % 20 == 0 or it == args.iters - 1):
+            graph.check()                            # (waits; fails when a replayed forward outgrew the captured pool)
         if not args.quiet and (it % 20 == 0 or it == args.iters - 1):          # (every rank: the IoU sums are all-reduced)
             loss, h = losses_upto(it + 1)
             iou_all = B * (1.0 - (loss[it] - 0.03 * h[it, 1] - 0.0003 * h[it, 2]))
@@ -158,6 +187,9 @@ def main(argv=None):
                 print("iter %4d  loss %.4f  (1-IoU %.4f, laplacian %.4f, flatten %.4f)" % (it, loss[it], 1.0 - iou_all / B, h[it, 1], h[it, 2]), flush=True)
     if device:
         ctx.synchronize()
+    if graph is not None:
+        graph.check()
+        graph.close()
     history = [float(x) for x in losses_upto(args.iters)[0]] if args.iters else []
     main.loop_seconds = time.time() - t0           # the optimisation loop alone (bench.py's secondary.c4_demo2 reads it)
     if rank == 0 and not args.quiet:

@@ -193,6 +193,33 @@ int jr_deform_vertices_backward(jr_ctx* ctx, const float* template_vertices, con
 int jr_adam_step(jr_ctx* ctx, float* param, const float* grad, float* m, float* v, size_t n, double lr, double beta0,
                  double beta1, double eps, double weight_decay, int step);
 int jr_scalar_accumulate(jr_ctx* ctx, float* dst, const float* src, int n, float scale, float bias, int accumulate);
+/* ---- an iteration of an optimisation loop as ONE HIP graph (round 5; the reference's loop - demo2-deform.py:74-90 - issues
+ * ~30 small device operations per iteration, here ~0.1 of the 0.55 ms of an iteration is launch overhead) -------------------
+ * jr_graph_begin ... jr_graph_end   every call on this context in between is RECORDED (hipStreamBeginCapture on the context's
+ *     stream) instead of executed; jr_graph_end returns an executable graph, jr_graph_launch replays it on the context's
+ *     stream, jr_graph_destroy frees it, jr_graph_abort closes an open capture after an error.  Rules inside a capture:
+ *       - nothing may wait for the GPU or touch host memory (no jr_memcpy_*, jr_synchronize, communicator calls);
+ *       - jr_malloc must find a cached block: run the sequence once or twice before capturing it;
+ *       - jr_softras_forward launches its lists and raster kernels against the pool and the launch history of the LAST forward of
+ *         the same shape (it cannot wait for the pair total); at every replay the kernels re-check the total on the device and
+ *         do nothing when the pool is too small - jr_graph_check (waits for the stream, then compares the last replayed
+ *         forward's total with the pool) tells: non-zero = run the sequence outside the graph once and capture again;
+ *       - host scalars are frozen into the graph: an iteration number must live on the device -
+ * jr_adam_step_counted   jr_adam_step with step = *iteration + 1 read on the device (the bias corrections are formed there, in
+ *     double as on the host);
+ * jr_scalar_accumulate_at   jr_scalar_accumulate into dst + stride * *iteration (one history row per iteration);
+ * jr_counter_add   *counter += delta (one thread): the last node of a captured iteration. */
+int jr_graph_begin(jr_ctx* ctx);
+int jr_graph_end(jr_ctx* ctx, void** graph_exec);
+int jr_graph_abort(jr_ctx* ctx);
+int jr_graph_launch(jr_ctx* ctx, void* graph_exec);
+int jr_graph_check(jr_ctx* ctx);
+int jr_graph_destroy(jr_ctx* ctx, void* graph_exec);
+int jr_adam_step_counted(jr_ctx* ctx, float* param, const float* grad, float* m, float* v, size_t n, double lr, double beta0,
+                         double beta1, double eps, double weight_decay, const int32_t* iteration);
+int jr_scalar_accumulate_at(jr_ctx* ctx, float* dst, int stride, const int32_t* iteration, const float* src, int n, float scale,
+                            float bias, int accumulate);
+int jr_counter_add(jr_ctx* ctx, int32_t* counter, int delta);
 int jr_avgpool2x2_forward(jr_ctx* ctx, const float* in, float* out, int planes, int H, int W);
 int jr_avgpool2x2_backward(jr_ctx* ctx, const float* grad_out, float* grad_in, int planes, int H,
                            int W);

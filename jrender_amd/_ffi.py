@@ -63,6 +63,15 @@ SIGNATURES = {
     "jr_deform_vertices_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int]),
     "jr_adam_step": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t] + [C.c_double] * 5 + [C.c_int]),
     "jr_scalar_accumulate": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_float, C.c_int]),
+    "jr_adam_step_counted": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t] + [C.c_double] * 5 + [C.c_void_p]),
+    "jr_scalar_accumulate_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int]),
+    "jr_counter_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "jr_graph_begin": (C.c_int, [C.c_void_p]),
+    "jr_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "jr_graph_abort": (C.c_int, [C.c_void_p]),
+    "jr_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "jr_graph_check": (C.c_int, [C.c_void_p]),
+    "jr_graph_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jr_avgpool2x2_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_avgpool2x2_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3),
     "jr_n3mr_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float] * 3 + [c_float_p] + [C.c_int] * 3),
@@ -218,6 +227,49 @@ class DeviceArray:
         return "DeviceArray(shape=%s, dtype=%s, gpu=%d)" % (self.shape, self.dtype, self.ctx.device)
 
 
+class Graph:
+    """A recorded launch sequence (Context.capture)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.handle, self._keep = ctx, None, []
+
+    def __enter__(self):
+        _check(load().jr_graph_begin(self.ctx.handle))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None:
+            load().jr_graph_abort(self.ctx.handle)
+            return False
+        h = C.c_void_p()
+        _check(load().jr_graph_end(self.ctx.handle, C.byref(h)))
+        self.handle = h
+        return False
+
+    def keep(self, *objects):
+        """Objects whose device buffers the graph reads or writes at replay and that must therefore outlive it."""
+        self._keep.extend(objects)
+        return objects[0] if len(objects) == 1 else objects
+
+    def launch(self):
+        _check(load().jr_graph_launch(self.ctx.handle, self.handle))
+
+    def check(self):
+        _check(load().jr_graph_check(self.ctx.handle))
+
+    def close(self):
+        if self.handle is not None:
+            load().jr_graph_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU: HIP stream + scratch arena (jr_ctx).  ``Context.default()`` picks the GPU from
     LOCAL_RANK (one process per GPU; set by bench.py's own launcher or by torch.distributed.run) or GPU 0."""
@@ -331,15 +383,36 @@ class Context:
         ``heavy_min_faces`` < 0 restores the default, 0 switches the multi-wavefront tiles off."""
         _check(load().jr_softras_set_launch_policy(self.handle, int(heavy_min_faces), int(heavy_waves)))
 
-    def scalar_accumulate(self, dst, index, src, scale=1.0, bias=0.0, accumulate=False):
+    def scalar_accumulate(self, dst, index, src, scale=1.0, bias=0.0, accumulate=False, iteration=None, stride=0):
         """dst[index] = (accumulate ? dst[index] : 0) + bias + scale * sum(src) on the device (jr_scalar_accumulate): loss
-        terms stay on the GPU - e.g. one slot of a history array per iteration - until the caller reads them."""
+        terms stay on the GPU - e.g. one slot of a history array per iteration - until the caller reads them.  With
+        ``iteration`` (a one-element int32 DeviceArray) the slot is index + stride * iteration[0], read on the device
+        (jr_scalar_accumulate_at: what a launch recorded into a graph needs - the caller keeps the slot inside dst)."""
         if dst.dtype != np.float32 or src.dtype != np.float32:
             raise TypeError("scalar_accumulate works on float32 arrays")
         if not 0 <= int(index) < dst.size:
             raise IndexError("index %d outside the %d elements of dst" % (index, dst.size))
+        if iteration is not None:
+            if iteration.dtype != np.int32 or iteration.size != 1:
+                raise TypeError("iteration must be a one-element int32 DeviceArray")
+            _check(load().jr_scalar_accumulate_at(self.handle, C.c_void_p(dst.ptr + 4 * int(index)), int(stride), iteration.ptr,
+                                                  src.ptr, int(src.size), float(scale), float(bias), int(bool(accumulate))))
+            return
         _check(load().jr_scalar_accumulate(self.handle, C.c_void_p(dst.ptr + 4 * int(index)), src.ptr, int(src.size),
                                            float(scale), float(bias), int(bool(accumulate))))
+
+    def counter_add(self, counter, delta=1):
+        """counter[0] += delta on the device (jr_counter_add): the iteration number of a loop that runs as a graph."""
+        if counter.dtype != np.int32 or counter.size != 1:
+            raise TypeError("counter must be a one-element int32 DeviceArray")
+        _check(load().jr_counter_add(self.handle, counter.ptr, int(delta)))
+
+    def capture(self):
+        """``with ctx.capture() as g: <device calls>`` records the calls on this context into ONE HIP graph instead of running
+        them (jr_graph_begin / jr_graph_end, include/jrender_hip.h: no host transfers or waits inside, every buffer from the
+        allocator's cache - run the sequence once or twice first -, iteration numbers on the device); ``g.launch()``
+        replays it, ``g.check()`` waits and verifies that the replayed forwards stayed inside the captured pool."""
+        return Graph(self)
 
     def set_bin_size(self, bin_size=0):
         """Screen-bin size in pixels for the next launches (the reference operator's ``bin_size``): 0 = by image size,

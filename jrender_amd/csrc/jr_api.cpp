@@ -72,6 +72,7 @@ struct jr_ctx {
     int forced_waves = 0;                    // jr_softras_set_launch_policy / JR_FWD_HEAVY_WAVES: 4 or 8 whatever the policy says; 0 = automatic
     unsigned long long* zkey = nullptr;     // n3mr z-buffer keys [B*IS*IS]
     size_t zkey_cap = 0;
+    int capturing = 0;                      // between jr_graph_begin and jr_graph_end: launches are recorded, nothing may wait for the GPU or allocate
     size_t zkey_clean = 0;                  // leading entries of zkey known to hold ~0 (k_n3mr_resolve clears what it read)
     unsigned char* n3_scratch = nullptr;    // n3mr backward: packed per-pixel planes in both orientations
     size_t n3_scratch_cap = 0;
@@ -289,6 +290,38 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
     for (auto& h : ctx->hist)
         if (h.stamp && h.B == p.B && h.NF == p.NF && h.IS == p.IS && h.heavy_min == ws.heavy_min && h.bin_log2 == p.bin_log2) hist = &h;
     if (setup_faces(ctx, p, faces, textures, faces_info)) return 1;
+    if (ctx->capturing) {
+        // Recorded into a HIP graph (jr_graph_begin): nothing here may wait for the GPU.  The launches are the speculative ones of the
+        // normal path - lists against the pool we have, raster with what this shape found last time - and the kernels re-check the
+        // pair total on the device at every replay; jr_graph_check compares it with the pool afterwards.
+        if (!ws.pool || !ws.pool_cap || (heavy_path && !hist))
+            return fail("graph capture of a forward needs one earlier forward of the same shape on this context (pool and launch history)");
+        ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
+        jr::launch_bin_fill_sort(ctx->stream, p, ws, false);
+        const int64_t hv = hist ? hist->heavy : 0, pr = hist ? hist->pairs : 0;
+        {
+            // (waves_for / enqueue_raster are defined below for the normal path; the same decisions, inline)
+            int waves = 4;
+            if (jr::tune::fwd_heavy_pipe && jr::tune::fwd_heavy_waves == 8) {
+                if (ctx->forced_waves == 4 || ctx->forced_waves == 8) waves = ctx->forced_waves;
+                else if (hv > 0) {
+                    const int64_t tiles = hv << (2 * p.sub_log2);
+                    const long budget = (long)p.B * p.IS * p.IS <= jr::tune::fwd_waves8_small_pixels ? jr::tune::fwd_heavy_waves8_budget_small
+                                                                                                      : jr::tune::fwd_heavy_waves8_budget;
+                    waves = (pr >= (int64_t)jr::tune::fwd_waves8_mean_list * p.B * p.bins_x * p.bins_y || tiles * 8 <= budget) ? 8 : 4;
+                }
+            }
+            ws.heavy_waves = waves;
+            ws.heavy_bound = (long)(hv + hv / 4 + 16);
+            if (ctx->precise_colour) jr_precise::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
+            else jr::launch_softras_forward(ctx->stream, p, textures, ws, aggrs_info, soft_colors, faces_id_buffer);
+        }
+        ctx->launch_info[0] = heavy_path ? 1 : 0;
+        ctx->launch_info[2] = ws.heavy_waves_used;
+        ctx->launch_info[3] = ws.heavy_min;
+        JR_HIP(hipGetLastError());
+        return 0;
+    }
     JR_HIP(hipEventRecord(ctx->ev_counters, ctx->stream));     // k_bin_alloc_schedule has written the totals to h_counters
     auto enqueue_lists = [&](bool again) {
         ProfScope ps(ctx, JR_PHASE_BIN_FILL_SORT);
@@ -409,6 +442,8 @@ int jr_malloc(jr_ctx* ctx, size_t bytes, void** dptr) {
         it->second.pop_back();
         ctx->cached_bytes -= sz;
     } else {
+        if (ctx->capturing)
+            return fail("jr_malloc(%zu) during graph capture found no cached block: run the sequence once (twice) before capturing it", sz);
         hipError_t e = hipMalloc(dptr, sz);
         if (e != hipSuccess && ctx->cached_bytes) {      // out of memory: drop the cache and retry
             (void)hipGetLastError();
@@ -432,6 +467,7 @@ int jr_free(jr_ctx* ctx, void* dptr) {
 }
 int jr_ctx_trim(jr_ctx* ctx) {
     if (!ctx) return fail("NULL context");
+    if (ctx->capturing) return fail("jr_ctx_trim during graph capture");
     JR_HIP(hipSetDevice(ctx->device));
     JR_HIP(hipStreamSynchronize(ctx->stream));
     for (auto& kv : ctx->cache)
@@ -729,7 +765,18 @@ int jr_adam_step(jr_ctx* ctx, float* param, const float* grad, float* m, float* 
     // the mirror's Python scalars: formed in double, rounded to float where NumPy multiplies them into a float32 array
     const double c0 = 1.0 - std::pow(beta0, step), c1 = 1.0 - std::pow(beta1, step);
     jr::launch_adam_step(ctx->stream, param, grad, m, v, n, (float)(lr / c0), (float)beta0, (float)(1.0 - beta0), (float)beta1,
-                         (float)(1.0 - beta1), (float)c1, (float)eps, (float)weight_decay);
+                         (float)(1.0 - beta1), (float)c1, (float)eps, (float)weight_decay, nullptr, lr, beta0, beta1);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_adam_step_counted(jr_ctx* ctx, float* param, const float* grad, float* m, float* v, size_t n, double lr, double beta0,
+                         double beta1, double eps, double weight_decay, const int32_t* iteration) {
+    if (!ctx || !param || !grad || !m || !v || !iteration) return fail("jr_adam_step_counted: NULL argument");
+    if (n == 0) return 0;
+    if (!(beta0 >= 0.0 && beta0 < 1.0 && beta1 >= 0.0 && beta1 < 1.0)) return fail("jr_adam_step_counted: betas must be in [0, 1)");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_adam_step(ctx->stream, param, grad, m, v, n, 0.f, (float)beta0, (float)(1.0 - beta0), (float)beta1,
+                         (float)(1.0 - beta1), 1.f, (float)eps, (float)weight_decay, iteration, lr, beta0, beta1);
     JR_HIP(hipGetLastError());
     return 0;
 }
@@ -737,8 +784,82 @@ int jr_scalar_accumulate(jr_ctx* ctx, float* dst, const float* src, int n, float
     if (!ctx || !dst || (n > 0 && !src)) return fail("jr_scalar_accumulate: NULL argument");
     if (n < 0) return fail("jr_scalar_accumulate: n must be >= 0");
     JR_HIP(hipSetDevice(ctx->device));
-    jr::launch_scalar_accumulate(ctx->stream, dst, src, n, scale, bias, accumulate);
+    jr::launch_scalar_accumulate(ctx->stream, dst, src, n, scale, bias, accumulate, nullptr, 0);
     JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_scalar_accumulate_at(jr_ctx* ctx, float* dst, int stride, const int32_t* iteration, const float* src, int n, float scale,
+                            float bias, int accumulate) {
+    if (!ctx || !dst || !iteration || (n > 0 && !src)) return fail("jr_scalar_accumulate_at: NULL argument");
+    if (n < 0 || stride < 0) return fail("jr_scalar_accumulate_at: n and stride must be >= 0");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_scalar_accumulate(ctx->stream, dst, src, n, scale, bias, accumulate, iteration, stride);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+int jr_counter_add(jr_ctx* ctx, int32_t* counter, int delta) {
+    if (!ctx || !counter) return fail("jr_counter_add: NULL argument");
+    JR_HIP(hipSetDevice(ctx->device));
+    jr::launch_counter_add(ctx->stream, counter, delta);
+    JR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- a fixed launch sequence as ONE HIP graph (round 5) ----------------------------------------------------------------------
+int jr_graph_begin(jr_ctx* ctx) {
+    if (!ctx) return fail("jr_graph_begin: NULL context");
+    if (ctx->capturing) return fail("jr_graph_begin: a capture is already open on this context");
+    if (ctx->prof_on) return fail("jr_graph_begin: switch phase profiling off first (its events are host-timed)");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    JR_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = 1;
+    return 0;
+}
+int jr_graph_end(jr_ctx* ctx, void** graph_exec) {
+    if (!ctx || !graph_exec) return fail("jr_graph_end: NULL argument");
+    if (!ctx->capturing) return fail("jr_graph_end: no capture is open");
+    ctx->capturing = 0;
+    hipGraph_t graph = nullptr;
+    JR_HIP(hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
+    *graph_exec = exec;
+    return 0;
+}
+int jr_graph_abort(jr_ctx* ctx) {
+    if (!ctx) return fail("jr_graph_abort: NULL context");
+    if (!ctx->capturing) return 0;
+    ctx->capturing = 0;
+    hipGraph_t graph = nullptr;
+    (void)hipStreamEndCapture(ctx->stream, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return 0;
+}
+int jr_graph_launch(jr_ctx* ctx, void* graph_exec) {
+    if (!ctx || !graph_exec) return fail("jr_graph_launch: NULL argument");
+    if (ctx->capturing) return fail("jr_graph_launch during capture");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), ctx->stream));
+    return 0;
+}
+int jr_graph_check(jr_ctx* ctx) {
+    if (!ctx) return fail("jr_graph_check: NULL context");
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipStreamSynchronize(ctx->stream));
+    // the last replayed forward's pair total (k_bin_alloc_schedule writes it to pinned memory) against the pool the graph was
+    // captured with: beyond it the list kernels and both raster kernels do nothing (they re-check on the device)
+    if (ctx->h_counters && ctx->ws.pool_cap && ctx->h_counters[0] > ctx->ws.pool_cap)
+        return fail("a replayed forward found %llu (bin, face) pairs, the captured pool holds %zu: run the sequence outside the graph once "
+                    "(the pool grows) and capture again", (unsigned long long)ctx->h_counters[0], ctx->ws.pool_cap);
+    return 0;
+}
+int jr_graph_destroy(jr_ctx* ctx, void* graph_exec) {
+    if (!ctx) return fail("jr_graph_destroy: NULL context");
+    if (graph_exec) JR_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
     return 0;
 }
 

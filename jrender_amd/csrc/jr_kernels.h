@@ -99,8 +99,11 @@ void launch_deform_backward(hipStream_t st, const float* tmpl, const float* disp
                             float w0, const float* g1, float w1, const float* g2, float w2, float* grad_displace,
                             float* grad_center, double* acc, unsigned* ticket, int nv);
 void launch_adam_step(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_over_c0, float b0,
-                      float one_minus_b0, float b1, float one_minus_b1, float c1, float eps, float weight_decay);
-void launch_scalar_accumulate(hipStream_t st, float* dst, const float* src, int n, float scale, float bias, int accumulate);
+                      float one_minus_b0, float b1, float one_minus_b1, float c1, float eps, float weight_decay,
+                      const int* iteration, double lr, double beta0, double beta1);
+void launch_scalar_accumulate(hipStream_t st, float* dst, const float* src, int n, float scale, float bias, int accumulate,
+                              const int* iteration, int stride);
+void launch_counter_add(hipStream_t st, int* counter, int delta);
 void launch_n3mr_image_forward(hipStream_t st, const float* in, float* out, int B, int H, int W, int C, int pool);
 void launch_n3mr_image_backward(hipStream_t st, const float* gout, float* gin, int B, int H, int W, int C, int pool);
 void launch_n3mr_forward(hipStream_t st, const float* faces, const float* textures, float* faces_inv,

@@ -90,10 +90,23 @@ __global__ __launch_bounds__(256) void k_deform_backward(const float* __restrict
 // One Adam step of jrender_amd/optim.py (the restatement of demo2-deform.py:72), in place:
 //   m = b0 m + (1 - b0) g;  v = b1 v + ((1 - b1) g) g;  p -= ((lr / c0) m) / (sqrt(v / c1) + eps)
 // c0 = 1 - b0^t, c1 = 1 - b1^t come from the host (it owns the step count); float operations in the mirror's order.
+// `iteration` (nullable): the step number lives on the DEVICE (step = *iteration + 1) - a launch captured into a HIP graph must not
+// freeze a host scalar; the two bias corrections are then formed here, in double like the host forms them, by one thread per workgroup.
 __global__ __launch_bounds__(256) void k_adam_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, float lr_over_c0, float b0,
                                                    float one_minus_b0, float b1, float one_minus_b1, float c1, float eps,
-                                                   float weight_decay) {
+                                                   float weight_decay, const int* __restrict__ iteration, double lr, double beta0,
+                                                   double beta1) {
+    __shared__ float s_sched[2];
+    if (iteration) {
+        if (threadIdx.x == 0) {
+            const int step = *iteration + 1;
+            s_sched[0] = (float)(lr / (1.0 - pow(beta0, (double)step)));
+            s_sched[1] = (float)(1.0 - pow(beta1, (double)step));
+        }
+        __syncthreads();
+        lr_over_c0 = s_sched[0]; c1 = s_sched[1];
+    }
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float gi = g[i];
@@ -108,9 +121,12 @@ __global__ __launch_bounds__(256) void k_adam_step(float* __restrict__ p, const 
 
 // dst[0] = (accumulate ? dst[0] : 0) + bias + scale * sum(src[0..n)): the per-iteration loss terms stay on the device
 // (a history array the host reads once per N iterations); one workgroup, double sum.
+// `iteration` (nullable) + stride: dst advances by stride * *iteration floats (the history row of a captured iteration).
 __global__ __launch_bounds__(256) void k_scalar_accumulate(float* __restrict__ dst, const float* __restrict__ src, int n,
-                                                           float scale, float bias, int accumulate) {
+                                                           float scale, float bias, int accumulate,
+                                                           const int* __restrict__ iteration, int stride) {
     __shared__ double s_red[4];
+    if (iteration) dst += (size_t)stride * (size_t)*iteration;
     double part = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) part += (double)src[i];
 #pragma unroll
@@ -134,12 +150,16 @@ void launch_deform_backward(hipStream_t st, const float* tmpl, const float* disp
                                                        grad_center, acc, ticket, nv);
 }
 void launch_adam_step(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_over_c0, float b0,
-                      float one_minus_b0, float b1, float one_minus_b1, float c1, float eps, float weight_decay) {
+                      float one_minus_b0, float b1, float one_minus_b1, float c1, float eps, float weight_decay,
+                      const int* iteration, double lr, double beta0, double beta1) {
     k_adam_step<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(p, g, m, v, n, lr_over_c0, b0, one_minus_b0, b1, one_minus_b1, c1,
-                                                            eps, weight_decay);
+                                                            eps, weight_decay, iteration, lr, beta0, beta1);
 }
-void launch_scalar_accumulate(hipStream_t st, float* dst, const float* src, int n, float scale, float bias, int accumulate) {
-    k_scalar_accumulate<<<1, 256, 0, st>>>(dst, src, n, scale, bias, accumulate);
+void launch_scalar_accumulate(hipStream_t st, float* dst, const float* src, int n, float scale, float bias, int accumulate,
+                              const int* iteration, int stride) {
+    k_scalar_accumulate<<<1, 256, 0, st>>>(dst, src, n, scale, bias, accumulate, iteration, stride);
 }
+__global__ void k_counter_add(int* __restrict__ counter, int delta) { *counter += delta; }
+void launch_counter_add(hipStream_t st, int* counter, int delta) { k_counter_add<<<1, 1, 0, st>>>(counter, delta); }
 
 }  // namespace jr

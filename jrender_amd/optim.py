@@ -23,9 +23,21 @@ class Adam:
         self.v = [p.ctx.zeros(p.shape) if isinstance(p, _ffi.DeviceArray) else np.zeros_like(p) for p in self.params]
         self.n_step = 0
 
-    def step(self, grads):
+    def step(self, grads, iteration=None):
+        """One Adam step.  ``iteration`` (a one-element int32 DeviceArray holding the number of steps already taken): the step
+        number is read on the DEVICE (jr_adam_step_counted) - what a step recorded into a graph (Context.capture) needs;
+        device parameters only, and the caller advances the counter (Context.counter_add)."""
         if len(grads) != len(self.params):
             raise ValueError("need one gradient per parameter (%d != %d)" % (len(grads), len(self.params)))
+        if iteration is not None:
+            b0, b1 = self.betas
+            for p, g, m, v in zip(self.params, grads, self.m, self.v):
+                if not (isinstance(p, _ffi.DeviceArray) and isinstance(g, _ffi.DeviceArray)) or g.size != p.size:
+                    raise TypeError("a counted step needs DeviceArray parameters and gradients of the same size")
+                _ffi._check(_ffi.load().jr_adam_step_counted(p.ctx.handle, p.ptr, g.ptr, m.ptr, v.ptr, p.size, float(self.lr),
+                                                             float(b0), float(b1), float(self.eps), float(self.weight_decay),
+                                                             iteration.ptr))
+            return
         self.n_step += 1
         b0, b1 = self.betas
         c0, c1 = 1.0 - b0 ** self.n_step, 1.0 - b1 ** self.n_step

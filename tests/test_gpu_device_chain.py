@@ -243,6 +243,47 @@ def test_demo2_front_ends_give_the_same_loss_curve():
     assert np.abs(np.asarray(dev) - np.asarray(host)).max() <= 2e-3, (dev, host)
 
 
+def test_demo2_as_one_hip_graph_retraces_the_launched_loop():
+    """--graph (round 5): the iteration number on the device (jr_adam_step_counted, jr_scalar_accumulate_at, jr_counter_add), the
+    third iteration RECORDED with jr_graph_begin / jr_graph_end - the forward launches against the pool and launch history of the
+    iteration before, nothing waits for the GPU - and replayed for the rest: the loss curve of the launched loop (float atomics
+    apart), and jr_graph_check finds every replayed forward inside the captured pool."""
+    spec = importlib.util.spec_from_file_location("demo2", os.path.join(os.path.dirname(GOLD), "..", "examples", "demo2_deform.py"))
+    demo2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo2)
+    common = ["-b", "16", "--iters", "30", "--quiet", "--front-end", "device"]
+    plain = demo2.main(common)
+    graph = demo2.main(common + ["--graph"])
+    assert len(graph) == len(plain) == 30 and graph[-1] < graph[0] - 0.05
+    assert np.abs(np.asarray(graph) - np.asarray(plain)).max() <= 2e-3, (graph, plain)
+
+
+def test_graph_capture_rules(ctx):
+    """Inside a capture an allocation must come from the cache, and a counted Adam step equals the host-numbered one."""
+    rng = np.random.default_rng(3)
+    p0 = rng.normal(size=(1, 300, 3)).astype(np.float32)
+    grads = [rng.normal(size=p0.shape).astype(np.float32) for _ in range(4)]
+    pa, pb = ctx.array(p0), ctx.array(p0)
+    oa, ob = jr.Adam([pa], 0.01, betas=(0.5, 0.99)), jr.Adam([pb], 0.01, betas=(0.5, 0.99))
+    it = ctx.array(np.zeros(1, np.int32))
+    for g in grads:
+        gd = ctx.array(g)
+        oa.step([gd])
+        ob.step([gd], iteration=it)
+        ctx.counter_add(it, 1)
+    assert int(it.numpy()[0]) == 4
+    assert np.abs(pa.numpy() - pb.numpy()).max() <= 2e-7 * np.abs(pa.numpy()).max()
+    hist = ctx.zeros((5, 3))
+    ctx.scalar_accumulate(hist, 1, ctx.array(np.arange(6, dtype=np.float32)), iteration=it, stride=3)     # row 4, column 1
+    h = hist.numpy()
+    assert h[4, 1] == 15.0 and np.count_nonzero(h) == 1
+    with pytest.raises(RuntimeError, match="capture"):
+        with ctx.capture():
+            ctx.empty((7, 1234567))                       # a size nobody has freed: the capture refuses to call hipMalloc
+    ctx.synchronize()                                     # (the aborted capture left the stream usable)
+    assert np.array_equal(hist.numpy(), h)
+
+
 @pytest.mark.parametrize("front_end", ["device", "host"])
 def test_demo2_two_ranks_follow_the_one_rank_curve(front_end, tmp_path):
     """BASELINE configs[3] shards the views over the ranks: two ranks (sharing this box's GPU, so the exchange runs over
