@@ -220,6 +220,10 @@ constexpr bool n3_face_fast = JR_TUNE_N3_FACE_FAST != 0;
 constexpr int bwd_batch = JR_TUNE_BWD_BATCH;
 constexpr int fwd_exact = JR_TUNE_FWD_EXACT, bwd_exact = JR_TUNE_BWD_EXACT;
 constexpr bool fwd_hard_exact = JR_TUNE_FWD_HARD_EXACT != 0;
+#ifndef JR_TUNE_FWD_EXACT_INSIDE_SIGMA   // forward, euclidean distance: sigma_val below this runs the instantiations with IEEE quotients for inside pixels (DIST = 3)
+#define JR_TUNE_FWD_EXACT_INSIDE_SIGMA 5e-6f
+#endif
+constexpr float fwd_exact_inside_sigma = JR_TUNE_FWD_EXACT_INSIDE_SIGMA;
 constexpr bool fwd_dis_only = JR_TUNE_FWD_DIS_ONLY != 0;
 constexpr bool fwd_prepass = JR_TUNE_FWD_PREPASS != 0;
 constexpr bool fwd_inside_rcp = JR_TUNE_FWD_INSIDE_RCP != 0;

@@ -1484,7 +1484,11 @@ void launch_softras_forward(hipStream_t st, const RasterParams& p, const float* 
     const int rgb = p.rgb == 0 ? 0 : (p.rgb == 1 ? 1 : 2);
     // DIST = 3: euclidean distance under 'hard' alpha - the inside distance keeps the reference's IEEE quotients because
     // D > 0.5 is decided from it (softras_device.h: euclidean_sign_dis); its own instantiations, so the other modes pay nothing
-    const int dist = (p.dist == 2 && p.alpha == 0 && tune::fwd_hard_exact) ? 3 : p.dist;
+    // ... and (round 5) under a sigma below tune::fwd_exact_inside_sigma: the reciprocal-multiply projection of an inside pixel is <= 2 ulp
+    // off in t, i.e. ~1e-7 of the edge length in the nearest point; at sigma = 1e-6 the coverage sigmoid's knee sits at distances of
+    // 1e-3, where that is 2e-4 of d^2 / sigma: a 7 788-face soup at 324^2 showed softmax_sum 1.03e-4 off at ONE pixel
+    // (tools/ablate/cases/fuzz_fail_89_238.npz; with IEEE quotients 3.5e-7).  The default sigma 1e-5 and anything softer keep the fast path.
+    const int dist = (p.dist == 2 && ((p.alpha == 0 && tune::fwd_hard_exact) || p.sigma < tune::fwd_exact_inside_sigma)) ? 3 : p.dist;
     switch (dist * 3 + rgb) {
         case 0: JR_FWD(0, 0); break;
         case 1: JR_FWD(0, 1); break;

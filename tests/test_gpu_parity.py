@@ -23,7 +23,7 @@ from tests.util import RGBA_ATOL, bits_equal, grad_err, grad_err_elementwise, re
 pytestmark = pytest.mark.gpu
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith(("n3mr_", "regress_", "textures_", "g1_", "host_")))
+                if not os.path.basename(p).startswith(("n3mr_", "regress_", "textures_", "g1_", "host_", "pin_")))
 GRAD_TOL = 1e-4
 
 
@@ -136,6 +136,27 @@ def test_fuzz_regressions(ctx, port, path):
     z = np.load(path)
     run_case(ctx, port, z["fv"], z["tex"], g=z["g"] if "g" in z.files else None,
              elementwise_tol=ELEMENTWISE_TOL_OUTLIERS if "regress_hard_alpha_b" in path else None, **eval(str(z["kw"])))
+
+
+def test_inside_distance_under_a_very_small_sigma(ctx, port):
+    """tests/golden/pin_inside_rcp_small_sigma.npz: the 76 faces around ONE pixel of a 7 788-face soup at 324^2 with sigma 1e-6
+    (round 5's big sweep, seed 89 case 238).  The reciprocal-multiply projection of an INSIDE pixel is <= 2 ulp off in t - 1e-7 of the
+    edge length in the nearest point, and with sigma = 1e-6 the coverage sigmoid's knee sits at distances of 1e-3: softmax_sum came
+    out 1.03e-4 off at that pixel.  Launches with sigma below 5e-6 take the instantiations with IEEE quotients now (DIST = 3, the
+    'hard'-alpha ones): the forward must sit far inside the tolerance, whatever the launch organisation."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pin_inside_rcp_small_sigma.npz"))
+    kw = eval(str(z["kw"]))
+    assert kw["sigma_val"] == 1e-6 and kw["dist_func"] == "euclidean"
+    ref = port.forward(z["fv"], z["tex"], **kw)
+    for heavy_min, bin_size in ((-1, 0), (8, 16), (8, 8)):
+        ctx.set_launch_policy(heavy_min, 0)
+        fn = SoftRasterizeFunction(ctx=ctx, bin_size=bin_size, **kw)
+        fn(z["fv"], z["tex"])
+        _, _, rgba, info, aggr, ids = [x.numpy() for x in fn.save_vars]
+        assert bits_equal(ids, ref["faces_id_buffer"]) and bits_equal(info, ref["faces_info"])
+        assert rel_err(aggr, ref["aggrs_info"], RGBA_ATOL) <= 0.1, rel_err(aggr, ref["aggrs_info"], RGBA_ATOL)
+        assert rel_err(rgba, ref["soft_colors"], RGBA_ATOL) <= 0.1
+    ctx.set_launch_policy(-1, 0)
 
 
 def test_default_sphere(ctx, port):

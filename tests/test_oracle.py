@@ -14,7 +14,7 @@ from jrender_amd import synthetic as syn
 from tests.util import bits_equal
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith(("n3mr_", "regress_", "textures_", "g1_", "host_")))
+                if not os.path.basename(p).startswith(("n3mr_", "regress_", "textures_", "g1_", "host_", "pin_")))
 
 
 @pytest.fixture(scope="module")
