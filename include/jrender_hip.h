@@ -331,7 +331,9 @@ int jr_softras_set_bin_size(jr_ctx* ctx, int bin_size);
  * double-precision quotient): RGBA within 5e-5 of the reference, gradients within 1e-4 of the largest component, but
  * 1 - 2e-4 ELEMENT-WISE (|a - b| / (|b| + 1e-3 max|b|)) - the last ulp of D amplified by (k - o) / D / gamma.  1: the
  * reference's own arithmetic for both quantities (a second set of forward kernels): RGBA 8e-6, gradients under 1e-4
- * element-wise; forward +15 % on the headline batch.  The face-index buffer and faces_info are bit-exact in both modes. */
+ * element-wise; forward +15 % on the headline batch.  The face-index buffer and faces_info are bit-exact in both modes.
+ * (Independent of this switch: with euclidean distance and sigma_val < 5e-6 the edge projections of INSIDE pixels keep the
+ * reference's IEEE quotients - their reciprocal-multiply form is 1e-7 of an edge length off, which a sigmoid that sharp shows.) */
 int jr_softras_set_precise_colour(jr_ctx* ctx, int on);
 int jr_softras_bin_size(const jr_ctx* ctx, int image_size, int batch, int num_faces);
 /* instrumented builds (-DJR_TUNE_PROFILE_SECTIONS=1, tools/ablate): shader-clock totals per kernel section since the
