@@ -199,7 +199,15 @@ int jr_scalar_accumulate(jr_ctx* ctx, float* dst, const float* src, int n, float
  *     stream) instead of executed; jr_graph_end returns an executable graph, jr_graph_launch replays it on the context's
  *     stream, jr_graph_destroy frees it, jr_graph_abort closes an open capture after an error.  Rules inside a capture:
  *       - nothing may wait for the GPU or touch host memory (no jr_memcpy_*, jr_synchronize, communicator calls);
- *       - jr_malloc must find a cached block: run the sequence once or twice before capturing it;
+ *       - jr_malloc must find a cached block: run the sequence once or twice before capturing it; every block handed out or
+ *         freed while the capture is open is PINNED to the graph - once its owner frees it, it is parked (not handed out
+ *         again, not released by jr_ctx_trim or the out-of-memory retry) until jr_graph_destroy, because the graph's nodes
+ *         address it at every replay.  Buffers allocated BEFORE the capture that the sequence uses stay the caller's to keep
+ *         alive for the graph's lifetime;
+ *       - the library's own scratch (face records, bin arrays, pair pool, reduction scratch, NMR keys / planes) must not
+ *         have to grow inside a capture (the call fails with a message saying so), and a larger call OUTSIDE the graph that
+ *         reallocates it outdates every graph captured before: jr_graph_launch then fails instead of replaying onto freed
+ *         memory.  jr_graph_launch also fails when the previous replay's forward reported more pairs than the pool holds;
  *       - jr_softras_forward launches its lists and raster kernels against the pool and the launch history of the LAST forward of
  *         the same shape (it cannot wait for the pair total); at every replay the kernels re-check the total on the device and
  *         do nothing when the pool is too small - jr_graph_check (waits for the stream, then compares the last replayed

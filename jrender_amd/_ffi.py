@@ -411,7 +411,11 @@ class Context:
         """``with ctx.capture() as g: <device calls>`` records the calls on this context into ONE HIP graph instead of running
         them (jr_graph_begin / jr_graph_end, include/jrender_hip.h: no host transfers or waits inside, every buffer from the
         allocator's cache - run the sequence once or twice first -, iteration numbers on the device); ``g.launch()``
-        replays it, ``g.check()`` waits and verifies that the replayed forwards stayed inside the captured pool."""
+        replays it, ``g.check()`` waits and verifies that the replayed forwards stayed inside the captured pool.
+        Temporaries created (or dropped) inside the ``with`` block are pinned to the graph by the allocator and only return
+        to its cache at ``g.close()``; arrays that exist BEFORE the block and are used inside it must be kept alive by the
+        caller (``g.keep(...)``).  A later, larger call outside the graph that makes the library reallocate its scratch
+        outdates the graph: ``g.launch()`` raises and the sequence has to be captured again."""
         return Graph(self)
 
     def set_bin_size(self, bin_size=0):

@@ -94,6 +94,19 @@ struct jr_ctx {
     std::unordered_map<size_t, std::vector<void*>> cache;   // rounded size -> free blocks
     std::unordered_map<void*, size_t> live;                 // block -> rounded size
     size_t cached_bytes = 0;
+    // HIP graphs (jr_graph_*) bake device addresses into their nodes.  Every block the allocator hands out or takes back
+    // WHILE a capture is open is pinned to that graph: when its owner frees it, it is parked instead of going back to the
+    // cache (so no later jr_malloc can be handed memory a replay still reads and writes, and jr_ctx_trim / the out-of-memory
+    // retry never hipFree() it) until jr_graph_destroy.  Blocks the captured sequence uses but that were allocated before
+    // the capture and are still held by the caller are the caller's to keep alive (Graph.keep()).
+    std::unordered_map<void*, int> pinned;                  // block -> 1 while some live graph may address it
+    std::unordered_map<void*, size_t> parked;               // freed pinned blocks (rounded size): not in the cache
+    std::vector<void*> capture_blocks;                      // the open capture's blocks
+    std::unordered_map<void*, std::vector<void*>> graph_blocks;   // graph exec -> its pinned blocks
+    // The library's own scratch (bin arrays, pool, reduction scratch, NMR keys / planes) is addressed by captured kernels too:
+    // every reallocation bumps this generation, a graph remembers the one it was captured under, jr_graph_launch refuses older ones.
+    uint64_t ws_generation = 0;
+    std::unordered_map<void*, uint64_t> graph_generation;
 };
 
 namespace {
@@ -121,9 +134,20 @@ struct ProfScope {
 
 namespace {
 
+// (re)allocation of library scratch: never inside a graph capture (hipMalloc / hipFree / a stream wait would invalidate the
+// capture with an opaque HIP error), and every one outdates the graphs captured before it
+int scratch_realloc_allowed(jr_ctx* ctx, const char* what) {
+    if (ctx->capturing)
+        return fail("%s has to grow during a graph capture: run the sequence once outside the graph (the scratch is sized by the "
+                    "largest call the context has seen) and capture again", what);
+    ctx->ws_generation++;
+    return 0;
+}
+
 template <typename T>
-int grow(T*& ptr, size_t& cap, size_t need, double slack) {
+int grow(jr_ctx* ctx, const char* what, T*& ptr, size_t& cap, size_t need, double slack) {
     if (need <= cap && ptr) return 0;
+    if (scratch_realloc_allowed(ctx, what)) return 1;
     if (ptr) JR_HIP(hipFree(ptr));
     ptr = nullptr;
     const size_t ncap = (size_t)(need * slack) + 1024;
@@ -135,6 +159,7 @@ int grow(T*& ptr, size_t& cap, size_t need, double slack) {
 int ensure_reduction_scratch(jr_ctx* ctx, size_t n) {
     n += 4;                                  // [0..3]: the optimiser kernels' three sums, [4..): one per mesh of a loss launch
     if (n <= ctx->red_cap) return 0;
+    if (scratch_realloc_allowed(ctx, "the reduction scratch of the loss / optimiser kernels")) return 1;
     JR_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->red_acc) JR_HIP(hipFree(ctx->red_acc));
     if (ctx->red_ticket) JR_HIP(hipFree(ctx->red_ticket));
@@ -229,19 +254,20 @@ int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, cons
     jr::BinWorkspace& ws = ctx->ws;
     if (nfaces > ws.faces_cap || !ws.geo) {
         size_t c0 = ws.faces_cap, c1 = ws.faces_cap;
-        if (grow(ws.geo, c0, nfaces, 1.0)) return 1;
-        if (grow(ws.face_rect, c1, nfaces, 1.0)) return 1;
+        if (grow(ctx, "the face-record array", ws.geo, c0, nfaces, 1.0)) return 1;
+        if (grow(ctx, "the face-rectangle array", ws.face_rect, c1, nfaces, 1.0)) return 1;
         ws.faces_cap = c0;
     }
     if (nbins > ws.bins_cap || !ws.bin_count) {
         size_t c0 = ws.bins_cap, c1 = ws.bins_cap, c2 = ws.bins_cap, c3 = ws.bins_cap, c4 = ws.bins_cap;
+        if (ctx->capturing) return fail("the bin arrays have to grow during a graph capture: run the sequence once outside the graph and capture again");
         JR_HIP(hipStreamSynchronize(ctx->stream));            // (a set-up pass in flight may still clear the old accumulator)
-        if (grow(ws.bin_acc, c4, nbins, 1.0)) return 1;
+        if (grow(ctx, "the bin arrays", ws.bin_acc, c4, nbins, 1.0)) return 1;
         JR_HIP(hipMemsetAsync(ws.bin_acc, 0, sizeof(int) * c4, ctx->stream));
-        if (grow(ws.bin_count, c0, nbins, 1.0)) return 1;
-        if (grow(ws.bin_base, c1, nbins, 1.0)) return 1;
-        if (grow(ws.bin_cursor, c2, nbins, 1.0)) return 1;
-        if (grow(ws.bin_order, c3, nbins, 1.0)) return 1;
+        if (grow(ctx, "the bin arrays", ws.bin_count, c0, nbins, 1.0)) return 1;
+        if (grow(ctx, "the bin arrays", ws.bin_base, c1, nbins, 1.0)) return 1;
+        if (grow(ctx, "the bin arrays", ws.bin_cursor, c2, nbins, 1.0)) return 1;
+        if (grow(ctx, "the bin arrays", ws.bin_order, c3, nbins, 1.0)) return 1;
         ws.bins_cap = c0;
     }
     {
@@ -357,10 +383,11 @@ int forward_pipeline(jr_ctx* ctx, const jr::RasterParams& p, const float* faces,
         return fail("%zu (bin, face) pairs exceed the 2^31 - 1 the bin lists index: render fewer views per call", pairs);
     if (!spec_lists || pairs > ws.pool_cap) {
         if (pairs > ws.pool_cap || !ws.pool) {
+            if (ctx->capturing) return fail("the pair pool has to grow during a graph capture: run the sequence once outside the graph and capture again");
             JR_HIP(hipStreamSynchronize(ctx->stream));      // nobody may still read the old pool
             size_t c0 = ws.pool_cap, c1 = ws.pool_cap;
-            if (grow(ws.pool, c0, pairs > 0 ? pairs : 1, 1.25)) return 1;
-            if (grow(ws.pool_scratch, c1, pairs > 0 ? pairs : 1, 1.25)) return 1;
+            if (grow(ctx, "the pair pool", ws.pool, c0, pairs > 0 ? pairs : 1, 1.25)) return 1;
+            if (grow(ctx, "the pair pool", ws.pool_scratch, c1, pairs > 0 ? pairs : 1, 1.25)) return 1;
             ws.pool_cap = c0;
         }
         enqueue_lists(spec_lists);
@@ -417,6 +444,7 @@ int jr_ctx_destroy(jr_ctx* ctx) {
     for (auto& kv : ctx->cache)
         for (void* p : kv.second) (void)hipFree(p);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
+    for (auto& kv : ctx->parked) (void)hipFree(kv.first);
     jr::BinWorkspace& ws = ctx->ws;
     (void)hipFree(ctx->zkey); (void)hipFree(ctx->n3_scratch); (void)hipFree(ctx->red_acc); (void)hipFree(ctx->red_ticket);
     (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_acc); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor); (void)hipFree(ws.bin_order);
@@ -453,6 +481,7 @@ int jr_malloc(jr_ctx* ctx, size_t bytes, void** dptr) {
         if (e != hipSuccess) return fail("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
     }
     ctx->live[*dptr] = sz;
+    if (ctx->capturing && !ctx->pinned.count(*dptr)) { ctx->pinned[*dptr] = 1; ctx->capture_blocks.push_back(*dptr); }
     return 0;
 }
 int jr_free(jr_ctx* ctx, void* dptr) {
@@ -460,11 +489,29 @@ int jr_free(jr_ctx* ctx, void* dptr) {
     if (!dptr) return 0;
     auto it = ctx->live.find(dptr);
     if (it == ctx->live.end()) return fail("jr_free: pointer %p was not allocated by this context", dptr);
-    ctx->cache[it->second].push_back(dptr);
-    ctx->cached_bytes += it->second;
+    if (ctx->capturing && !ctx->pinned.count(dptr)) { ctx->pinned[dptr] = 1; ctx->capture_blocks.push_back(dptr); }   // (a captured kernel may have used it)
+    if (ctx->pinned.count(dptr)) ctx->parked[dptr] = it->second;     // a graph addresses it: out of circulation until jr_graph_destroy
+    else {
+        ctx->cache[it->second].push_back(dptr);
+        ctx->cached_bytes += it->second;
+    }
     ctx->live.erase(it);
     return 0;
 }
+namespace {
+// the blocks of a destroyed / failed / aborted graph go back into circulation
+void unpin_blocks(jr_ctx* ctx, const std::vector<void*>& blocks) {
+    for (void* b : blocks) {
+        ctx->pinned.erase(b);
+        auto pk = ctx->parked.find(b);
+        if (pk != ctx->parked.end()) {
+            ctx->cache[pk->second].push_back(b);
+            ctx->cached_bytes += pk->second;
+            ctx->parked.erase(pk);
+        }
+    }
+}
+}  // namespace
 int jr_ctx_trim(jr_ctx* ctx) {
     if (!ctx) return fail("NULL context");
     if (ctx->capturing) return fail("jr_ctx_trim during graph capture");
@@ -814,18 +861,24 @@ int jr_graph_begin(jr_ctx* ctx) {
     JR_HIP(hipStreamSynchronize(ctx->stream));
     JR_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
     ctx->capturing = 1;
+    ctx->capture_blocks.clear();
     return 0;
 }
 int jr_graph_end(jr_ctx* ctx, void** graph_exec) {
     if (!ctx || !graph_exec) return fail("jr_graph_end: NULL argument");
     if (!ctx->capturing) return fail("jr_graph_end: no capture is open");
     ctx->capturing = 0;
+    std::vector<void*> blocks;
+    blocks.swap(ctx->capture_blocks);
     hipGraph_t graph = nullptr;
-    JR_HIP(hipStreamEndCapture(ctx->stream, &graph));
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (e != hipSuccess) { unpin_blocks(ctx, blocks); return fail("hipStreamEndCapture: %s", hipGetErrorString(e)); }
     hipGraphExec_t exec = nullptr;
-    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
+    if (e != hipSuccess) { unpin_blocks(ctx, blocks); return fail("hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    ctx->graph_blocks[exec] = std::move(blocks);
+    ctx->graph_generation[exec] = ctx->ws_generation;
     *graph_exec = exec;
     return 0;
 }
@@ -833,6 +886,11 @@ int jr_graph_abort(jr_ctx* ctx) {
     if (!ctx) return fail("jr_graph_abort: NULL context");
     if (!ctx->capturing) return 0;
     ctx->capturing = 0;
+    {
+        std::vector<void*> blocks;
+        blocks.swap(ctx->capture_blocks);
+        unpin_blocks(ctx, blocks);
+    }
     hipGraph_t graph = nullptr;
     (void)hipStreamEndCapture(ctx->stream, &graph);
     if (graph) (void)hipGraphDestroy(graph);
@@ -842,6 +900,19 @@ int jr_graph_abort(jr_ctx* ctx) {
 int jr_graph_launch(jr_ctx* ctx, void* graph_exec) {
     if (!ctx || !graph_exec) return fail("jr_graph_launch: NULL argument");
     if (ctx->capturing) return fail("jr_graph_launch during capture");
+    {
+        auto g = ctx->graph_generation.find(graph_exec);
+        if (g == ctx->graph_generation.end()) return fail("jr_graph_launch: not a graph of this context");
+        if (g->second != ctx->ws_generation)
+            return fail("jr_graph_launch: the context's scratch was reallocated after this graph was captured (a larger call outside the "
+                        "graph): its nodes address freed memory - destroy it and capture again");
+    }
+    // (sticky "pool too small": what the last COMPLETED schedule kernel of a replayed forward wrote to pinned memory - no wait
+    //  here, so it may lag a replay or two; jr_graph_check is the synchronous form)
+    if (ctx->h_counters && ctx->ws.pool_cap && ctx->h_counters[0] > ctx->ws.pool_cap)
+        return fail("jr_graph_launch: a replayed forward found %llu (bin, face) pairs, the captured pool holds %zu: its raster kernels did "
+                    "nothing - run the sequence outside the graph once (the pool grows) and capture again",
+                    (unsigned long long)ctx->h_counters[0], ctx->ws.pool_cap);
     JR_HIP(hipSetDevice(ctx->device));
     JR_HIP(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), ctx->stream));
     return 0;
@@ -859,7 +930,13 @@ int jr_graph_check(jr_ctx* ctx) {
 }
 int jr_graph_destroy(jr_ctx* ctx, void* graph_exec) {
     if (!ctx) return fail("jr_graph_destroy: NULL context");
-    if (graph_exec) JR_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+    if (!graph_exec) return 0;
+    JR_HIP(hipSetDevice(ctx->device));
+    JR_HIP(hipStreamSynchronize(ctx->stream));            // a replay in flight still uses the pinned blocks
+    JR_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+    auto gb = ctx->graph_blocks.find(graph_exec);
+    if (gb != ctx->graph_blocks.end()) { unpin_blocks(ctx, gb->second); ctx->graph_blocks.erase(gb); }
+    ctx->graph_generation.erase(graph_exec);
     return 0;
 }
 
@@ -882,7 +959,7 @@ int jr_n3mr_forward(jr_ctx* ctx, const float* faces, const float* textures, floa
     JR_HIP(hipSetDevice(ctx->device));
     const size_t P = (size_t)B * IS * IS;
     if (P > ctx->zkey_cap || !ctx->zkey) ctx->zkey_clean = 0;
-    if (grow(ctx->zkey, ctx->zkey_cap, P, 1.0)) return 1;
+    if (grow(ctx, "the NMR z-buffer keys", ctx->zkey, ctx->zkey_cap, P, 1.0)) return 1;
     const size_t was_clean = ctx->zkey_clean;
     const bool clean = P <= was_clean;
     ctx->zkey_clean = 0;                     // (until the launches below are known to be in the stream)
@@ -913,7 +990,7 @@ int jr_n3mr_backward(jr_ctx* ctx, const float* faces, const int32_t* face_index_
     JR_HIP(hipSetDevice(ctx->device));
     if (return_rgb || return_alpha) {
         const size_t need = jr::n3mr_backward_scratch_bytes(B, IS);
-        if (need > ctx->n3_scratch_cap && grow(ctx->n3_scratch, ctx->n3_scratch_cap, need, 1.0)) return 1;
+        if (need > ctx->n3_scratch_cap && grow(ctx, "the NMR backward's scratch planes", ctx->n3_scratch, ctx->n3_scratch_cap, need, 1.0)) return 1;
     }
     jr::launch_n3mr_backward(ctx->stream, faces, face_index_map, weight_map, depth_map, face_inv_map, rgb_map,
                              alpha_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_alpha_map,

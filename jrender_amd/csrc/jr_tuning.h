@@ -122,6 +122,9 @@
 #ifndef JR_TUNE_BWD_ROW_RANGES   // backward: a row takes a contiguous quarter of the work items and adds up consecutive items of one face before its atomic
 #define JR_TUNE_BWD_ROW_RANGES 1
 #endif
+#ifndef JR_TUNE_BWD_HASH_UNION   // backward (round 6): the faces a tile needs by hashing the pixels' buffered ids into an LDS table (0: per-lane sort + min-extraction, rounds 2 - 5)
+#define JR_TUNE_BWD_HASH_UNION 1
+#endif
 #ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
@@ -264,6 +267,7 @@ constexpr long fwd_heavy_waves8_budget_small = JR_TUNE_FWD_HEAVY_WAVES8_BUDGET_S
 constexpr int auto_bin8_max_image = JR_TUNE_AUTO_BIN8_MAX_IMAGE, auto_bin16_max_image = JR_TUNE_AUTO_BIN16_MAX_IMAGE;
 constexpr bool fwd_heavy_defer_copy = JR_TUNE_FWD_HEAVY_DEFER_COPY != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
+constexpr bool bwd_hash_union = JR_TUNE_BWD_HASH_UNION != 0;
 constexpr bool bwd_row_ranges = JR_TUNE_BWD_ROW_RANGES != 0;
 }  // namespace tune
 }  // namespace jr

@@ -226,6 +226,11 @@ constexpr int bwd_waves(int dist, int rgb, int kcap, bool texlds) {
     return spills && w > 3 ? w - 1 : w;
 }
 
+// open-addressing table of the hashed union (round 6): 256 entries x 16 B over the record slots + 64 compacted entries
+constexpr int HT_LOG2 = 8, HT_SIZE = 1 << HT_LOG2, HT_PROBES = 24;
+struct HEntry { int key; int pad; unsigned m[2]; };
+static_assert(sizeof(HEntry) == 16, "HEntry");
+
 template <int DIST, int RGB, int KCAP, bool TEXLDS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DIST, RGB, KCAP, TEXLDS)))) void k_softras_backward(
     RasterParams p, int nbins, int heavy_cap, int split_log2, const float* __restrict__ textures,
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
     // faces per batch: a tile of the headline workload needs ~40; 64 slots of 176 B cap a CU at 13 wavefronts
     constexpr int BATCH = TEXLDS ? tune::bwd_batch_for(16) : tune::bwd_batch_for(KCAP);     // (the staged texel blocks are 24 T bytes per slot: no larger batches there)
     FaceRec* s_rec = reinterpret_cast<FaceRec*>(s_dyn);                        // [BATCH]
+    static_assert(!tune::bwd_hash_union || (HT_SIZE + 64) * 16 <= BATCH * (int)sizeof(FaceRec), "the hashed union's table lies over the record slots");
     float* s_vcol = reinterpret_cast<float*>(s_rec + BATCH);                   // [BATCH*9] iff vertex colours
     // TEXLDS (round 5; its own instantiations: as a run-time flag it cost the default kernels 32 B of scratch and + 50 % time; 'surface' textures with 1 < T <= BWD_TEX_LDS_MAX texels, small launches): the batch's texture blocks
     // are staged next to the records.  A pair of a T > 1 face reads its texel colour - k0..k2 of SRK:1315 - from global
@@ -296,25 +302,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
     clk.start();
     // this pixel's buffered face ids; the reference stops at the first -1 (SRK:1236-1238)
     constexpr int BIG = 0x7fffffff;
-    int mine[KCAP];
+    constexpr bool HASHED = tune::bwd_hash_union;
+    const int32_t* ip = ids + (size_t)b * p.K * pp + pn;
+    int mine[HASHED ? 1 : KCAP];
+    int cur = BIG;
     {
-        // plane 0 decides whether the tile has anything to do; the other planes are then fetched at
-        // once (independent loads) and the reference's early stop is applied in registers
-        const int32_t* ip = ids + (size_t)b * p.K * pp + pn;
-        int raw[KCAP];
-        raw[0] = valid ? ip[0] : -1;
-        if (!ballot(raw[0] >= 0)) return;           // nothing buffered anywhere in this tile
+        // plane 0 decides whether the tile has anything to do
+        const int r0 = valid ? ip[0] : -1;
+        if (!ballot(r0 >= 0)) return;           // nothing buffered anywhere in this tile
+        if (!HASHED) {
+            // the other planes are fetched at once (independent loads) and the reference's early stop is applied in registers
+            int raw[KCAP];
+            raw[0] = r0;
 #pragma unroll
-        for (int k = 1; k < KCAP; k++) raw[k] = (valid && k < p.K) ? ip[(size_t)k * pp] : -1;
-        bool live = true;
+            for (int k = 1; k < KCAP; k++) raw[k] = (valid && k < p.K) ? ip[(size_t)k * pp] : -1;
+            bool live = true;
 #pragma unroll
-        for (int k = 0; k < KCAP; k++) {
-            live = live && raw[k] >= 0 && raw[k] < p.NF;   // -1 ends the list (ids outside [0, NF) too)
-            mine[k] = (live && (part < 0 || (raw[k] & smask) == part)) ? raw[k] : BIG;
+            for (int k = 0; k < KCAP; k++) {
+                live = live && raw[k] >= 0 && raw[k] < p.NF;   // -1 ends the list (ids outside [0, NF) too)
+                mine[HASHED ? 0 : k] = (live && (part < 0 || (raw[k] & smask) == part)) ? raw[k] : BIG;
+            }
         }
     }
-    sort_ascending(mine);
-    int cur = mine[0];
+    if (!HASHED) {
+        sort_ascending(mine);
+        cur = mine[0];
+    }
 
     PixelGrad px;
     px.g0 = px.g1 = px.g2 = px.g3 = 0.f;
@@ -343,26 +356,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
     // headline workload needs ~40): slot = extraction order = ascending id, lane j keeps slot j's id and
     // holder mask.  No list walk, no binary search, no bit-matrix transpose.
     clk.lap(0);
-    for (;;) {
-        int fill = 0, myid = 0;
-        unsigned long long has = 0ull;
-        while (fill < BATCH) {
-            const int m = wave_min(cur);
-            if (m == BIG) break;
-            const bool hit = cur == m;
-            const unsigned long long h = ballot(hit);
-            if (lane == fill) { myid = m; has = h; }
-            if (hit) {
-#pragma unroll
-                for (int k = 0; k + 1 < KCAP; k++) mine[k] = mine[k + 1];
-                mine[KCAP - 1] = BIG;
-                cur = mine[0];
-            }
-            fill++;
-        }
-        if (fill == 0) break;
-        clk.lap(1);
-
+    // ---- one batch: `fill` distinct faces, lane j < fill holds face j's id and holder mask ----
+    auto run_batch = [&](const int fill, const int myid, const unsigned long long has) {
         // ---- stage the batch's records (lane = slot) ----
         if (lane < fill) {
             const float4* src = reinterpret_cast<const float4*>(gbase + myid);
@@ -561,6 +556,147 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
             }
         }
         __syncthreads();                        // the batch's records and tables are free again
+    };
+
+    if (!HASHED) {
+        // Round 2 - 5: every lane holds its ids SORTED; the wavefront repeatedly extracts the smallest id that is still
+        // pending anywhere (DPP min), the ballot of the lanes whose head equals it IS the face's holder mask, and those lanes
+        // advance: slot = extraction order = ascending id.  ~63 VALU per distinct face + a 16-element bitonic sort per lane:
+        // 38 % of the kernel's VALU instructions on the headline batch (round 6 count) - kept as JR_TUNE_BWD_HASH_UNION=0.
+        for (;;) {
+            int fill = 0, myid = 0;
+            unsigned long long has = 0ull;
+            while (fill < BATCH) {
+                const int m = wave_min(cur);
+                if (m == BIG) break;
+                const bool hit = cur == m;
+                const unsigned long long h = ballot(hit);
+                if (lane == fill) { myid = m; has = h; }
+                if (hit) {
+#pragma unroll
+                    for (int k = 0; k + 1 < KCAP; k++) mine[HASHED ? 0 : k] = mine[HASHED ? 0 : k + 1];
+                    mine[HASHED ? 0 : KCAP - 1] = BIG;
+                    cur = mine[0];
+                }
+                fill++;
+            }
+            if (fill == 0) break;
+            clk.lap(1);
+            run_batch(fill, myid, has);
+        }
+    } else {
+        // Round 6: the union by HASHING.  Gradient sums do not care in which order the faces of a tile are visited, so the
+        // ascending extraction order bought nothing.  Every lane inserts its <= K ids into an open-addressing table in LDS
+        // (ds_cmpst on the key; the table lies over the record slots, which are free between batches) and ORs its lane bit
+        // into the entry's holder mask (ds_or); a compaction pass numbers the used entries, lane j takes entry j.  ~18 VALU
+        // per id plane instead of ~63 per distinct face, no sort.
+        // A pass holds up to 64 distinct faces (lane j <-> face j).  A tile that needs more is cut into residue CLASSES of the
+        // face id - class (level L, value v) = the ids with ((id >> split_log2) & (2^L - 1)) == v - refined only where a class
+        // overflows: a depth-first walk over that binary trie, every id in exactly one leaf.
+        HEntry* tab = reinterpret_cast<HEntry*>(s_dyn);                       // [HT_SIZE]
+        int4* comp = reinterpret_cast<int4*>(tab + HT_SIZE);                   // [64] compacted (id, -, mask lo, mask hi)
+        int cl = 0, cv = 0;
+        for (;;) {
+            // ---- build the class's table ----
+            {
+                int4 empty = make_int4(-1, 0, 0, 0);
+                asm volatile("" : "+v"(empty.x), "+v"(empty.y), "+v"(empty.z), "+v"(empty.w));      // (materialised here: kept live over the class loop it spilled)
+#pragma unroll
+                for (int e = 0; e < HT_SIZE / 64; e++) reinterpret_cast<int4*>(tab)[e * 64 + lane] = empty;
+            }
+            int raw[KCAP];
+            {                        // wave-uniform plane base + this lane's 32-bit pixel offset (sixteen 64-bit per-lane addresses kept over the class loop spilled)
+                // (opaque to the optimiser: hoisted out of the class loop, the sixteen addresses and `k < K` predicates spilled)
+                unsigned pn32 = (unsigned)pn;
+                int kk = p.K;
+                asm volatile("" : "+v"(pn32), "+s"(kk));
+                const int32_t* plane0 = ids + (size_t)b * p.K * pp;
+#pragma unroll
+                for (int k = 0; k < KCAP; k++) raw[k] = (valid && k < kk) ? (plane0 + (size_t)k * pp)[pn32] : -1;
+            }
+            __syncthreads();
+            // Every plane's first probe is issued before any result is looked at (one LDS round trip for the tile's K planes
+            // instead of K dependent ones); a lane whose first probe hit another id walks on - at most HT_PROBES entries, a
+            // table that full means "too many faces for one pass" anyway.  No short-circuit ladder: the predicates are
+            // bitwise, the plane's hash word doubles as its "this lane takes part" flag (< 0: not).
+            // (planes in groups of 16: hh / old of a K = 64 pixel would be 128 registers)
+            bool lost = false;                                        // this lane found no entry for one of its ids
+            {
+                const unsigned cmask = (1u << cl) - 1u;
+                bool live = true;
+                constexpr int PG = KCAP < 16 ? KCAP : 16;
+#pragma unroll
+                for (int g = 0; g < KCAP; g += PG) {
+                    int hh[PG], old[PG];
+#pragma unroll
+                    for (int k = 0; k < PG; k++) {
+                        const int id = raw[g + k];
+                        live = live & (id >= 0) & (id < p.NF);            // -1 ends the list (ids outside [0, NF) too)
+                        const bool take = live & ((part < 0) | ((id & smask) == part)) & ((((unsigned)id >> split_log2) & cmask) == (unsigned)cv);
+                        hh[k] = take ? (int)(((unsigned)id * 2654435761u) >> (32 - HT_LOG2)) : -1;
+                    }
+#pragma unroll
+                    for (int k = 0; k < PG; k++) {
+                        old[k] = raw[g + k];
+                        if (hh[k] >= 0) old[k] = atomicCAS(&tab[hh[k]].key, -1, raw[g + k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < PG; k++) {
+                        if (hh[k] >= 0) {
+                            int h = hh[k];
+                            if ((old[k] != -1) & (old[k] != raw[g + k])) {   // first probe hit another id (rare at <= 25 % load)
+                                bool placed = false;
+                                for (int pr = 0; pr < HT_PROBES && !placed; pr++) {
+                                    h = (h + 1) & (HT_SIZE - 1);
+                                    const int o = atomicCAS(&tab[h].key, -1, raw[g + k]);
+                                    placed = (o == -1) | (o == raw[g + k]);
+                                }
+                                lost = lost | !placed;
+                                if (!placed) h = -1;
+                            }
+                            if (h >= 0) atomicOr(&tab[h].m[lane >> 5], 1u << (lane & 31));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- compaction: used entries -> comp[0 .. ndist) -> lane j holds face j ----
+            int ndist = 0;
+#pragma unroll
+            for (int e = 0; e < HT_SIZE / 64; e++) {
+                const int4 ent = reinterpret_cast<const int4*>(tab)[e * 64 + lane];
+                const bool used = ent.x != -1;
+                const unsigned long long um = ballot(used);
+                const int at = ndist + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                if (used & (at < 64)) comp[at] = ent;
+                ndist += __builtin_popcountll(um);
+            }
+            const bool overflow = ndist > 64 || ballot(lost) != 0ull;
+            __syncthreads();
+            if (overflow) { cl++; continue; }                     // refine: (L + 1, v) is the left child; every id in exactly one leaf
+            int eid = 0;
+            unsigned long long ehas = 0ull;
+            if (lane < ndist) { const int4 ent = comp[lane]; eid = ent.x; ehas = ((unsigned long long)(unsigned)ent.w << 32) | (unsigned)ent.z; }
+            __syncthreads();                                      // the table's LDS becomes record slots again
+            clk.lap(1);
+            for (int b0 = 0; b0 < ndist; b0 += BATCH) {
+                const int fill = min(BATCH, ndist - b0);
+                int myid = eid;
+                unsigned long long has = ehas;
+                if (b0 > 0) {                                     // faces b0 .. of the pass move down to lanes 0 ..
+                    const int from = ((lane + b0) & 63) << 2;
+                    myid = __builtin_amdgcn_ds_bpermute(from, eid);
+                    has = ((unsigned long long)(unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(ehas >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)ehas);
+                }
+                if (lane >= fill) has = 0ull;
+                run_batch(fill, myid, has);
+            }
+            // ---- next class: right sibling, or up ----
+            while (cl > 0 && ((cv >> (cl - 1)) & 1)) { cv &= ~(1 << (cl - 1)); cl--; }
+            if (cl == 0) break;
+            cv |= 1 << (cl - 1);
+        }
     }
     clk.lap(1);
     if (JR_TUNE_PROFILE_SECTIONS == 1) clk.flush(counters, 12);

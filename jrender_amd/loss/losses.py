@@ -120,16 +120,31 @@ class LaplacianLoss:
                                 faces[:, [2, 0]], faces[:, [0, 2]]])
             adj = coo_matrix((np.ones(len(e), F32), (e[:, 0], e[:, 1])), shape=(self.nv, self.nv)).tocsr()
             adj.data[:] = -1.0                                     # duplicates were summed: an edge is -1 however many faces share it
-            deg = -np.asarray(adj.sum(1)).reshape(-1).astype(F32)   # lap[r, r] = -sum of the row
-            with np.errstate(divide="ignore", invalid="ignore"):
-                inv = (F32(1) / deg).astype(F32)
-            lap = (adj + diags(deg.astype(F32), format="csr")).tocsr().astype(F32)
+            # lap[r, r] = -(sum of the row) OVERWRITES the diagonal.  A face that repeats a vertex has put a -1 there first
+            # (laplacian_loss.py:14-19), and that -1 is part of the sum: the diagonal is then degree + 1 ...
+            diag = -np.asarray(adj.sum(1)).reshape(-1).astype(F32)
+            off = adj.tolil()
+            off.setdiag(0)
+            off = off.tocsr()
+            off.eliminate_zeros()
+            lap = (off + diags(diag, format="csr")).tocsr().astype(F32)
             lap.sort_indices()
-            # row / diagonal, element by element like the reference's `lap /= lap[r, c][:, None]` (a float division each)
+            # row / diagonal, element by element like the reference's `laplacian[i, :] /= laplacian[i, i]` (a float division each)
             rows = np.repeat(np.arange(self.nv), np.diff(lap.indptr))
             with np.errstate(divide="ignore", invalid="ignore"):
-                lap.data = (lap.data / deg[rows]).astype(F32)
-            del inv
+                lap.data = (lap.data / diag[rows]).astype(F32)
+            # ... and a vertex no face refers to has an all-zero row divided by its zero diagonal: 0 / 0 = NaN in EVERY column
+            # (the loss of such a mesh is NaN in the reference; a sparse row of explicit NaNs keeps that)
+            lonely = np.flatnonzero(diag == 0)
+            if lonely.size:
+                keep = np.ones(self.nv, bool)
+                keep[lonely] = False
+                lap = diags(keep.astype(F32), format="csr") @ lap
+                nan_rows = coo_matrix((np.full(lonely.size * self.nv, np.nan, F32),
+                                       (np.repeat(lonely, self.nv), np.tile(np.arange(self.nv), lonely.size))),
+                                      shape=(self.nv, self.nv)).tocsr()
+                lap = (lap + nan_rows).tocsr().astype(F32)
+                lap.sort_indices()
             self._csr = csr_matrix(lap)
             self._csr_t = csr_matrix(lap.T.tocsr())
             self._csr_t.sort_indices()

@@ -177,8 +177,21 @@ def launch_ranks(script, n, argv, timeout_s=1500.0, name=None, relay_stdout=True
             except Exception:
                 pass
 
+    # rank 0's stdout is relayed WHILE the ranks run (a progress line every 20 iterations of an optimisation loop must not
+    # wait for the end of the launch): a second handle on its log file is drained in the poll loop
+    relay = open(os.path.join(rdzv, "rank0.out"), "rb") if relay_stdout else None
+
+    def drain():
+        if relay is None:
+            return
+        chunk = relay.read()
+        if chunk:
+            sys.stdout.write(chunk.decode(errors="replace"))
+            sys.stdout.flush()
+
     failure, t0 = None, time.time()
     while failure is None and any(q.poll() is None for q in procs):
+        drain()
         for r, q in enumerate(procs):
             rc = q.poll()
             if rc not in (None, 0):
@@ -195,21 +208,27 @@ def launch_ranks(script, n, argv, timeout_s=1500.0, name=None, relay_stdout=True
             failure = "rank %d exited with code %d" % bad[0]
     if failure is not None:
         kill_all()
+        drain()
         sys.stderr.write("%s: %s; exit codes %s\n" % (name, failure, [q.returncode for q in procs]))
         for r, (_o, e) in enumerate(logs):
             t = tail(e).strip()
             if t:
                 sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, t))
+        sys.stderr.write("%s: the ranks' complete logs are kept in %s (rank<i>.out / rank<i>.err)\n" % (name, rdzv))
     else:
-        if relay_stdout:
-            sys.stdout.write(tail(logs[0][0], 1 << 20))
-            sys.stdout.flush()
+        for o, _e in logs:
+            o.flush()
+        drain()
         for r, (_o, e) in enumerate(logs):                 # warnings of healthy ranks stay visible
             t = tail(e).strip()
             if t:
                 sys.stderr.write("---- rank %d stderr ----\n%s\n" % (r, t))
     for o, e in logs:
         o.close(); e.close()
+    if relay is not None:
+        relay.close()
+    if failure is not None:                                # the logs stay for the post-mortem (their directory is private: 0700)
+        return 1
     try:
         for f in os.listdir(rdzv):
             os.unlink(os.path.join(rdzv, f))

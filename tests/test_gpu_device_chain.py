@@ -284,6 +284,47 @@ def test_graph_capture_rules(ctx):
     assert np.array_equal(hist.numpy(), h)
 
 
+def test_graph_pins_the_blocks_its_capture_touched(ctx):
+    """a graph bakes device addresses into its nodes.  Blocks the allocator handed out (or took back) while the
+    capture was open must stay out of circulation - not handed to later jr_malloc calls, not hipFree()d by jr_ctx_trim - until
+    the graph is destroyed, even after their Python owners died; a replay then still lands in them."""
+    n = 54321                                            # a size class of its own
+    src = ctx.array(np.arange(n, dtype=np.float32))
+    warm = ctx.empty((n,)); warm_ptr = warm.ptr; del warm          # one cached block of the class for the capture to find
+    with ctx.capture() as g:
+        tmp = src.clone()                                # library-internal style temporary: allocated inside the capture ...
+        out_ptr = tmp.ptr
+        del tmp                                          # ... and dropped inside it
+    g.keep(src)
+    assert out_ptr == warm_ptr
+    # the freed temporary is parked: allocations of its size class get other memory, trim does not free it
+    others = [ctx.empty((n,)).zero_() for _ in range(3)]
+    assert all(o.ptr != out_ptr for o in others)
+    del others
+    ctx.trim()
+    src.copy_from_host(np.arange(n, dtype=np.float32)[::-1].copy())
+    g.launch(); g.check()
+    look = _ffi.DeviceArray(ctx, out_ptr, (n,), np.float32, owner=g)       # (a non-owning look at the parked block)
+    assert np.array_equal(look.numpy(), np.arange(n, dtype=np.float32)[::-1])
+    del look
+    g.close()
+    again = ctx.empty((n,))                              # back in circulation once the graph is gone
+    assert again.ptr == out_ptr
+    # a graph captured before the context's scratch was reallocated refuses to replay
+    it = ctx.array(np.zeros(1, np.int32))
+    with ctx.capture() as g2:
+        ctx.counter_add(it, 1)
+    g2.keep(it)
+    g2.launch(); g2.check()
+    fv, tex = jr.synthetic.sphere_views(280, 1)
+    from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
+    SoftRasterizeFunction(image_size=2440, ctx=ctx).execute(ctx.array(fv), ctx.array(tex))   # more bins than any earlier test of this context: the bin arrays grow
+    with pytest.raises(RuntimeError, match="reallocated"):
+        g2.launch()
+    g2.close()
+    assert int(it.numpy()[0]) == 1
+
+
 @pytest.mark.parametrize("front_end", ["device", "host"])
 def test_demo2_two_ranks_follow_the_one_rank_curve(front_end, tmp_path):
     """BASELINE configs[3] shards the views over the ranks: two ranks (sharing this box's GPU, so the exchange runs over

@@ -323,6 +323,29 @@ def test_csr_arrays_of_the_laplacian_match_scipy():
     assert np.array_equal(rp, [0, 0, 0, 0]) and c.size == 0 and vl.size == 0
 
 
+def test_sparse_laplacian_is_the_dense_construction_on_unclean_meshes():
+    """the CSR construction of LaplacianLoss against the reference's dense one (laplacian_loss.py:14-26) on a mesh
+    with faces that repeat a vertex (the self -1 is part of the row sum: diagonal = degree + 1) and vertices no face uses
+    (zero row / zero diagonal = NaN in every column, so the loss is NaN as in the reference)."""
+    import jrender_amd as jr
+    v = np.random.default_rng(0).normal(size=(9, 3)).astype(np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3], [0, 0, 1], [3, 4, 5], [5, 5, 5], [4, 6, 4]], np.int64)     # vertices 7, 8 unused
+    L = jr.LaplacianLoss(v, f)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dense = L._dense_matrix(f)
+    assert np.isnan(dense[7]).all() and np.isnan(dense[8]).all() and not np.isnan(dense[:7]).any()
+    assert dense[0, 0] == 1.0 and dense[0, 1] == np.float32(-1) / np.float32(4)          # degree 3 + the self edge
+    assert np.array_equal(np.isnan(L.laplacian), np.isnan(dense))
+    assert np.array_equal(np.nan_to_num(L.laplacian), np.nan_to_num(dense))
+    x = np.random.default_rng(1).normal(size=(2, 9, 3)).astype(np.float32)
+    assert np.isnan(L(x)).all()
+    clean = jr.LaplacianLoss(v[:7], f[[0, 1, 2, 3, 5]])              # no unused vertex: finite, equal to the dense product
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d2 = clean._dense_matrix(f[[0, 1, 2, 3, 5]])
+    assert np.array_equal(clean.laplacian, d2)
+    assert np.allclose(clean(x[:, :7]), ((d2 @ x[:, :7]) ** 2).sum((1, 2)), rtol=1e-5)
+
+
 def test_single_rounding_sigmoid_of_the_backward_is_the_references_float():
     """softras_device.h: coverage_backward.  For e < 2^-10 the backward takes D = fma(-e, 1 - e, 1); the claim is that this ONE
     rounding of 1 - e + e^2 is the reference's D = (float)(1. / (1. + e)) (SRK:338 / :344 evaluate in double), while the plain

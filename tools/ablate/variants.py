@@ -57,6 +57,9 @@ VARIANTS = {
     "bwd_split2": ["JR_TUNE_BWD_SPLIT=2"], "bwd_split8": ["JR_TUNE_BWD_SPLIT=8"],
     "no_heavy_overlap": ["JR_TUNE_FWD_HEAVY_OVERLAP=0"],     # round 3: heavy tiles stage / list between the passes (wavefront 0) instead of during the apply (wavefronts 3 / 2)
     "bwd_k64w4": ["JR_TUNE_BWD_WAVES64=4"],                  # round 3: backward at K = 64 with 4 wavefronts per SIMD (52 B of scratch)
+    "sections_sorted": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0", "JR_TUNE_BWD_HASH_UNION=0"],
+    "hashv1": [],                                           # (round 6 call 2: a saved build of the first hashed union - one dependent LDS round trip per id plane; not reproducible from a define)
+    "bwd_sorted": ["JR_TUNE_BWD_HASH_UNION=0"],             # round 6: the backward's face union by per-lane sort + min-extraction (rounds 2 - 5) instead of the LDS hash table
     "no_heavy_pipe": ["JR_TUNE_FWD_HEAVY_PIPE=0"],           # round 3: heavy tiles with the passes in sequence (tile_heavy) instead of the pipeline
     "pipe_ct2": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=2"], "pipe_ct0": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=0"],   # round 3: the K-buffer wavefront / both applying wavefronts take no evaluate tasks
     "pipe_nw4": ["JR_TUNE_FWD_HEAVY_WAVES=4"],               # round 3: the pipelined heavy tile with four wavefronts per workgroup instead of eight
