@@ -12,11 +12,11 @@ with a device-resident upstream gradient.  Workload = BASELINE.json's metric con
 (configs[2]): UV-sphere with 39 000 faces seen from 8 turntable cameras, 1024x1024, batch 8 per
 GPU, jrender Renderer defaults (sigma 1e-5, gamma 1e-4, euclidean / softmax / prod, K=16).
 Every rank renders its own 8 views (batch sharding, no collective inside the op) => weak scaling.
-With N > 1 the step ends with the exchange a data-parallel mesh optimisation needs
-(--exchange allreduce_vertex_grads, the default for N > 1: face->vertex scatter of the rank's
-gradients + ONE ncclAllReduce of the shared-vertex gradient, demo2-deform.py:45); --exchange
-allgather_images puts the RCCL all-gather of the rendered image shards into the step instead,
---exchange none times independent replicas.
+With N > 1 the step ends with the exchange north_star names ("RCCL all-gather of images/gradients"):
+--exchange both, the default for N > 1 = face->vertex scatter of the rank's gradients + ONE
+ncclAllReduce of the shared-vertex gradient (what a data-parallel mesh optimisation needs,
+demo2-deform.py:45) AND the ncclAllGather of the rendered image shards; --exchange
+allreduce_vertex_grads / allgather_images time one of the two, --exchange none independent replicas.
 
 Rank 0 prints ONE JSON line.  `value` comes from the wall clock around exactly K steps between
 barriers (max over ranks); per-step HIP events give median / p10 / p90.  `roofline` prices the
@@ -169,12 +169,13 @@ def reference_platform_envelope(NF, K, IS=256):
             "rgba": err_metrics(rb["soft_colors"], ra["soft_colors"]), "grad_faces": err_metrics(gb, ga)}
 
 
-def parity_vs_sample(ctx, sample, K, mesh_faces, NV):
-    """The GPU path on the oracle's view: same inputs, same size, same upstream gradient."""
+def parity_vs_sample(ctx, sample, K, mesh_faces, NV, precise_colour=False):
+    """The GPU path on the oracle's view: same inputs, same size, same upstream gradient.  precise_colour: through the
+    conformant kernel set (the forward's colour path in the reference's own arithmetic, jr_softras_set_precise_colour)."""
     from jrender_amd.renderer.dr.softras.soft_rasterize import SoftRasterizeFunction
     from jrender_amd.structures.mesh import face_vertices_backward
     IS, a = sample["IS"], sample["saved"]
-    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
+    fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx, precise_colour=precise_colour)
     img = fn.execute(ctx.array(sample["fv"]), ctx.array(sample["tex"]))
     gf, gt = fn.grad(ctx.array(sample["g"]))
     ids = fn.save_vars[5].numpy()
@@ -443,7 +444,9 @@ def bench_softras(args, ctx, comm, rank, world):
     faces_d = ctx.array(np.ascontiguousarray(mesh_faces, np.int32))
     grad = ctx.array(np.random.default_rng(7 + rank).uniform(-1, 1, (B, 4, IS, IS)).astype(np.float32))
     fn = SoftRasterizeFunction(image_size=IS, max_faces_per_pixel_for_grad=K, ctx=ctx)
-    exchange = args.exchange or ("allreduce_vertex_grads" if world > 1 else "none")
+    # north_star: "RCCL all-gather of images/gradients": with more than one rank a step ends with BOTH collectives - the
+    # all-reduce of the shared-vertex gradient and the all-gather of the rendered images (--exchange both), timed in the line
+    exchange = args.exchange or ("both" if world > 1 else "none")
 
     def render():
         img = fn.execute(fv, tex)
@@ -451,9 +454,9 @@ def bench_softras(args, ctx, comm, rank, world):
         return img, gf
 
     def do_exchange(img, gf):
-        if exchange == "allreduce_vertex_grads":
+        if exchange in ("allreduce_vertex_grads", "both"):
             shared_vertex_gradient(gf, faces_d, NV, comm)
-        elif exchange == "allgather_images":
+        if exchange in ("allgather_images", "both"):
             comm.all_gather(img, B * world)
 
     def step():
@@ -520,6 +523,29 @@ def bench_softras(args, ctx, comm, rank, world):
             valu["model_over_measured_valu"] = mv["model_over_measured"]
             valu["split_ms_of_the_profiled_launch"] = mv["split_ms"]
             valu["gap_owner"] = mv["gap_owner"]
+    # ... and the same for the OTHER raster kernel (VERDICT r5 next #1a / #3: the line carries both kernels' floors): PMC counters of
+    # the backward + tools/sim/min_valu_bwd.py's model (ISA by loop nest x counts of the instrumented build)
+    valu_bwd = None
+    if profiled and vj.get("bwd_raster") and per_launch["bwd_raster"] > 0:
+        valu_bwd = dict(vj["bwd_raster"])
+        cyc = per_launch["bwd_raster"] * 1e-3 * valu_bwd.get("clock_ghz", 2.4) * 1e9 * valu_bwd.get("simds", 1024)
+        valu_bwd["busy_raw"] = valu_bwd["valu_insts_per_launch"] * valu_bwd.get("mean_issue_cycles", 4.0) / cyc
+        valu_bwd["busy"] = min(1.0, valu_bwd["busy_raw"])
+        mb = load_json("min_valu_bwd_latest.json")
+        if mb:
+            valu_bwd.update(attainable_ms=mb["attainable_ms"], frac_of_attainable=mb["attainable_ms"] / per_launch["bwd_raster"],
+                            pair_arithmetic_only_ms=mb["pair_arithmetic_only_ms"], model_over_measured_valu=mb["model_over_measured"],
+                            split_ms_of_the_profiled_launch=mb["split_ms"], lanes_per_trip=mb["lanes_per_trip"])
+        valu_bwd["avg_launch_ms"] = per_launch["bwd_raster"]
+        valu_bwd["hbm_frac"] = ab["bwd_raster"] / (per_launch["bwd_raster"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    valu_fwd = None
+    if profiled and vj.get("fwd_raster") and per_launch["fwd_raster"] > 0:
+        mv = load_json("min_valu_latest.json")
+        valu_fwd = {"avg_launch_ms": per_launch["fwd_raster"], "hbm_frac": ab["fwd_raster"] / (per_launch["fwd_raster"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if mv:
+            valu_fwd.update(attainable_ms=mv["attainable_ms"], frac_of_attainable=mv["attainable_ms"] / per_launch["fwd_raster"])
+    if dom == "bwd_raster" and valu_bwd:
+        valu = valu_bwd
     out = {
         "metric": "SoftRas fwd+bwd images/s @1024x1024, 39k faces",
         "value": world * B / (elapsed / args.steps),
@@ -546,13 +572,15 @@ def bench_softras(args, ctx, comm, rank, world):
                                % (args.steps, bracketed_ms),
                      "step_frac": ab["step"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "hbm_read_frac": ab["read"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "valu": valu, "profile_stale": profile_stale, "csrc_hash": here,
+                     "valu": valu, "valu_bwd": valu_bwd, "valu_fwd_floor": valu_fwd, "profile_stale": profile_stale, "csrc_hash": here,
                      "profile_csrc_hash": tj.get("csrc_hash") if profiled else None},
         "phase_ms_per_step": {k: v[0] / args.steps for k, v in phases.items()},
         "exchange": {"kind": exchange, "backend": backend, "ms_per_step": percentiles(ex_ms)["median"] if ex_ms else 0.0},
         "tile_stats": ctx.last_stats(),
     }
     out["rccl_ranks"] = rccl_ranks
+    out["comm_init"] = {"attempts": 2 if os.environ.get("JRENDER_IPC_RETRY") else 1,
+                        "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
     if backend == "rccl" and rccl_ranks != world:
         sys.exit("bench.py: RCCL reports %s ranks for a launch of %d" % (rccl_ranks, world))
     # Everything below is measured by rank 0 on its own GPU AFTER the timed region, at any world size (north_star: latency
@@ -572,6 +600,7 @@ def bench_softras(args, ctx, comm, rank, world):
                 out["secondary"] = {"b1": {"workload": "ONE %d-face view %dx%d fwd+bwd, K=%d, on rank 0's GPU" % (NF, IS, IS, K), "ms": st, "phase_ms": ph}}
         except Exception as e:                      # never break the headline line
             out["secondary"] = {"error": repr(e)}
+    sample = None
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"], sample = cpu_baseline(NF, K)
@@ -585,6 +614,25 @@ def bench_softras(args, ctx, comm, rank, world):
         except Exception as e:                      # the baseline must never break the bench line
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
+    # a CONFORMANT number beside the fast one - the same batch through the precise-colour kernel set
+    # (SoftRasterizeFunction(precise_colour=True): libm expf, IEEE quotients, the double-precision sigmoid of SRK:344, :401-411 in
+    # the forward; the backward is the same kernel), with its own parity block on the same oracle view
+    if not args.no_secondary and world == 1:
+        try:
+            fvp, texp = syn.sphere_views(NF, B) if args.scene == "sphere" else syn.triangle_soup(NF, B, seed=100)
+            st, ph = fwd_bwd_ms(ctx, solo, fvp, texp, IS, K, steps=20, warmup=3, precise_colour=True)
+            hp = {"workload": "the headline batch through the precise-colour kernel set (jr_softras_set_precise_colour)",
+                  "ms": st, "phase_ms": ph, "images_per_s": B / (st["median"] * 1e-3),
+                  "step_frac": ab["step"] / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "vs_default_step": st["median"] / out["step_ms"]["median"]}
+            if sample is not None and args.scene == "sphere":
+                pp = parity_vs_sample(ctx, sample, K, mesh_faces, NV, precise_colour=True)
+                hp["parity"] = {k: pp[k] for k in ("ids_match_frac", "rgba_err", "aggrs_err", "grad_faces_err", "vertex_grad_err", "view")}
+                if pp.get("gradient_references"):
+                    hp["parity"]["vs_exact_sum"] = pp["gradient_references"]["vs_exact_sum"]
+            out.setdefault("secondary", {})["headline_precise"] = hp
+        except Exception as e:
+            out.setdefault("secondary", {})["headline_precise"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
 
 
@@ -632,8 +680,9 @@ def main():
     ap.add_argument("--image-size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8, help="views per GPU")
     ap.add_argument("--K", type=int, default=16)
-    ap.add_argument("--exchange", default=None, choices=["none", "allreduce_vertex_grads", "allgather_images"],
-                    help="exchange step at the end of every step (default: allreduce_vertex_grads when N > 1)")
+    ap.add_argument("--exchange", default=None, choices=["none", "allreduce_vertex_grads", "allgather_images", "both"],
+                    help="exchange step at the end of every step (default when N > 1: both - the all-reduce of the shared-vertex "
+                         "gradient AND the all-gather of the images, as north_star words it)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline + parity)")
     ap.add_argument("--no-secondary", action="store_true", help="skip latency_ms_b1 / secondary (K=32, K=64, soup, NMR)")
     ap.add_argument("--dry-run-ranks", type=int, default=0, metavar="N",

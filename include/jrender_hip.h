@@ -202,7 +202,8 @@ int jr_scalar_accumulate(jr_ctx* ctx, float* dst, const float* src, int n, float
  *       - jr_malloc must find a cached block: run the sequence once or twice before capturing it; every block handed out or
  *         freed while the capture is open is PINNED to the graph - once its owner frees it, it is parked (not handed out
  *         again, not released by jr_ctx_trim or the out-of-memory retry) until jr_graph_destroy, because the graph's nodes
- *         address it at every replay.  Buffers allocated BEFORE the capture that the sequence uses stay the caller's to keep
+ *         address it at every replay; only the rest of the SAME capture may get it again (a graph replays its nodes in the
+ *         captured order, so reuse inside one sequence is as safe as it is on the stream).  Buffers allocated BEFORE the capture that the sequence uses stay the caller's to keep
  *         alive for the graph's lifetime;
  *       - the library's own scratch (face records, bin arrays, pair pool, reduction scratch, NMR keys / planes) must not
  *         have to grow inside a capture (the call fails with a message saying so), and a larger call OUTSIDE the graph that

@@ -40,9 +40,10 @@ def rendezvous_path():
     and no other attempt does: the agent's pid (their parent), MASTER_PORT, TORCHELASTIC_RUN_ID and
     TORCHELASTIC_RESTART_COUNT - a restarted worker group gets a fresh name, so a file left by the crashed attempt is
     never read - inside a per-user 0700 directory."""
+    retry = ".retry" if os.environ.get("JRENDER_IPC_RETRY") else ""     # the second attempt of init_from_env never reads the first one's files
     p = os.environ.get("JRENDER_RDZV")
     if p:
-        return p
+        return p + retry
     d = os.path.join(tempfile.gettempdir(), "jrender_rdzv_u%d" % os.getuid())
     os.makedirs(d, mode=0o700, exist_ok=True)
     st = os.stat(d)
@@ -50,8 +51,8 @@ def rendezvous_path():
         raise RuntimeError("rendezvous directory %s is not private to this user" % d)
     import hashlib
     run = hashlib.sha1(os.fsencode(os.environ.get("TORCHELASTIC_RUN_ID", "none"))).hexdigest()[:12]   # (short: AF_UNIX paths end at 108 bytes)
-    return os.path.join(d, "%s_%s_r%s_%d" % (os.environ.get("MASTER_PORT", "0"), run,
-                                             os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid()))
+    return os.path.join(d, "%s_%s_r%s_%d%s" % (os.environ.get("MASTER_PORT", "0"), run,
+                                               os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid(), retry))
 
 
 def _require_private_parent(path):
@@ -396,6 +397,36 @@ def rccl_dry_run(ctx, rank, world, payload_bytes, path=None, timeout=120.0):
     return dict(rep, ranks=reports, problems=problems, ok=not problems, one_gpu_per_rank=one_gpu_each)
 
 
+def _rccl_with_one_retry(ctx, rank, world):
+    """RcclCommunicator, and when ncclCommInitRank fails: say what the rank saw, then ONE more attempt of the whole process with
+    the HSA IPC mode toggled.  On this pool's hosts RCCL's cross-process buffer registration needs
+    HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; with the legacy mode it fails with `hipIpcGetMemHandle: invalid argument`); a node
+    whose driver wants the other mode fails the same way with the value this launch exported.  The HSA runtime reads the
+    variable once, at start-up, so the retry is a re-exec of this rank (same argv, JRENDER_IPC_RETRY=1, its own rendezvous
+    files).  ncclCommInitRank is collective: when it fails, it fails on every rank, and every rank takes this path."""
+    import sys
+    try:
+        if os.environ.get("JRENDER_FAIL_COMM_INIT_ONCE") and not os.environ.get("JRENDER_IPC_RETRY"):     # (tests: the retry path on one GPU)
+            raise RuntimeError("ncclCommInitRank(rank %d of %d) failed: injected by JRENDER_FAIL_COMM_INIT_ONCE" % (rank, world))
+        return RcclCommunicator(ctx, rank, world)
+    except RuntimeError as e:
+        if "ncclCommInitRank" not in str(e):
+            raise
+        mode = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+        sys.stderr.write(
+            "jrender_amd.comm: rank %d of %d (GPU %d of %d visible, pid %d): %s\n"
+            "    HSA_ENABLE_IPC_MODE_LEGACY=%s  NCCL_DEBUG=%s  (export NCCL_DEBUG=INFO for RCCL's own account; xGMI peers need one "
+            "process per GPU and dmabuf or legacy IPC as the host driver supports)\n"
+            % (rank, world, ctx.device, _ffi.device_count(), os.getpid(), e, mode, os.environ.get("NCCL_DEBUG")))
+        if os.environ.get("JRENDER_IPC_RETRY"):
+            sys.stderr.write("jrender_amd.comm: this was the second attempt (IPC mode toggled): giving up\n")
+            raise
+        env = dict(os.environ, JRENDER_IPC_RETRY="1", HSA_ENABLE_IPC_MODE_LEGACY="1" if mode == "0" else "0")
+        sys.stderr.write("jrender_amd.comm: retrying ONCE with HSA_ENABLE_IPC_MODE_LEGACY=%s (re-exec of this rank)\n" % env["HSA_ENABLE_IPC_MODE_LEGACY"])
+        sys.stderr.flush(); sys.stdout.flush()
+        os.execve(sys.executable, list(getattr(sys, "orig_argv", [sys.executable] + sys.argv)), env)
+
+
 def init_from_env(ctx=None, backend=None):
     """Communicator of this process from RANK / WORLD_SIZE / LOCAL_RANK.
 
@@ -415,7 +446,7 @@ def init_from_env(ctx=None, backend=None):
             if world == 1:
                 return SingleCommunicator()
             raise ValueError("the RCCL communicator needs a Context")
-        return RcclCommunicator(ctx, rank, world)
+        return _rccl_with_one_retry(ctx, rank, world)
     if backend == "host":
         return HostCommunicator(rank, world, ctx=ctx)
     raise ValueError("unknown communicator backend %r" % (backend,))

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256) void k_bin_order(int NF, const int* __restrict
 // counters: [0] = total pairs, [1] = non-empty bins, [2] = max bin count, [3] = heavy bins - WRITTEN here (nothing to
 // clear beforehand), and copied to `host_counters` (pinned, device-visible) so that the host's read-back of the pair
 // total is a wait on an event, not a copy engine's turn in the stream.
+constexpr int SCHED_ITEMS = 8;      // bins per thread and chunk of k_bin_alloc_schedule (8 192 bins = the headline batch in one chunk)
 __global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, int* __restrict__ bin_acc, int* __restrict__ bin_count,
                                                              int* __restrict__ bin_base, int* __restrict__ bin_cursor,
                                                              int* __restrict__ bin_order,
@@ -304,34 +305,61 @@ __global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, in
     if (threadIdx.x == 0) { s_total = 0ull; s_nonempty = 0; s_max = 0; s_heavy = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int t0 = 0; t0 < nbins_total; t0 += 1024) {         // (uniform trip count: the wavefront scans need every lane)
-        const int t = t0 + (int)threadIdx.x;
-        const int n = t < nbins_total ? bin_acc[t] : 0;
-        // (empty bins are the most frequent bucket by far: one LDS atomic per wavefront for them instead of one per lane)
-        const unsigned long long zb = ballot(t < nbins_total && n <= 0);
-        if (t < nbins_total && n > 0) atomicAdd(&s_hist[bucket(n)], 1);
-        if (zb != 0ull && lane == (int)__builtin_ctzll(zb)) atomicAdd(&s_hist[0], (int)__builtin_popcountll(zb));
-        int incl = n, mx = n;
+    // Round 6: a thread owns SCHED_ITEMS bins of a chunk of 1024 x SCHED_ITEMS and loads their counts in ONE go (the loop over
+    // 1024-bin slices paid one exposed global-load latency per slice and pass: 16 of them for the headline batch's 8 192 bins),
+    // and a launch of up to one chunk - every shape of BASELINE.json - keeps them in registers for the second pass.
+    constexpr int CH = 1024 * SCHED_ITEMS;
+    const bool one_chunk = nbins_total <= CH;
+    int nreg[SCHED_ITEMS];
+    for (int c0 = 0; c0 < nbins_total; c0 += CH) {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-            mx = max(mx, __shfl_xor(mx, d));
+        for (int i = 0; i < SCHED_ITEMS; i++) {
+            const int t = c0 + i * 1024 + (int)threadIdx.x;
+            nreg[i] = t < nbins_total ? bin_acc[t] : 0;
         }
-        const int wtotal = __builtin_amdgcn_readlane(incl, 63);
-        const int wnz = __builtin_popcountll(ballot(n > 0));
-        unsigned long long wbase = 0ull;
-        if (wtotal > 0) {                                    // wave-uniform
-            if (lane == 63) {
-                wbase = atomicAdd(&s_total, (unsigned long long)wtotal);
-                atomicAdd(&s_nonempty, wnz);
-                atomicMax(&s_max, mx);
+#pragma unroll
+        for (int i = 0; i < SCHED_ITEMS; i++) {
+            const int t = c0 + i * 1024 + (int)threadIdx.x;
+            if (c0 + i * 1024 >= nbins_total) break;             // (block-uniform)
+            const int n = nreg[i];
+            // (empty bins are the most frequent bucket by far: one LDS atomic per wavefront for them instead of one per lane)
+            const unsigned long long zb = ballot(t < nbins_total && n <= 0);
+            if (t < nbins_total && n > 0) atomicAdd(&s_hist[bucket(n)], 1);
+            if (zb != 0ull && lane == (int)__builtin_ctzll(zb)) atomicAdd(&s_hist[0], (int)__builtin_popcountll(zb));
+            // segment bases: inclusive prefix of the wavefront's counts by DPP (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: six adds, no LDS
+            // round trip - the __shfl_up ladder of rounds 3 - 5 was six dependent ds_bpermute per slice on the launch's ONE CU) + one LDS
+            // atomic per wavefront; the largest count by DPP too.  (One same-address LDS atomic per BIN instead of the scan: 15.8 -> 27.9 us.)
+            int incl = n;
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+            const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+            const unsigned long long nzb = ballot(n > 0);
+            unsigned long long wbase = 0ull;
+            if (wtotal > 0) {                                    // wave-uniform
+                int mx = n;
+                mx = max(mx, __builtin_amdgcn_update_dpp(mx, mx, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+                mx = max(mx, __builtin_amdgcn_update_dpp(mx, mx, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+                mx = max(mx, __builtin_amdgcn_update_dpp(mx, mx, 0x141, 0xf, 0xf, false));   // row_half_mirror
+                mx = max(mx, __builtin_amdgcn_update_dpp(mx, mx, 0x140, 0xf, 0xf, false));   // row_mirror
+                mx = max(max(__builtin_amdgcn_readlane(mx, 0), __builtin_amdgcn_readlane(mx, 16)),
+                         max(__builtin_amdgcn_readlane(mx, 32), __builtin_amdgcn_readlane(mx, 48)));
+                if (lane == 0) {
+                    wbase = atomicAdd(&s_total, (unsigned long long)wtotal);
+                    atomicAdd(&s_nonempty, (int)__builtin_popcountll(nzb));
+                    atomicMax(&s_max, mx);
+                }
+                wbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wbase >> 32), 0) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wbase, 0);
             }
-            wbase = __shfl(wbase, 63);
-        }
-        if (t < nbins_total) {
-            bin_base[t] = n > 0 ? (int)(wbase + (unsigned long long)(incl - n)) : 0;
-            bin_cursor[t] = 0;
+            const int base = n > 0 ? (int)(wbase + (unsigned long long)(incl - n)) : 0;
+            if (t < nbins_total) {
+                bin_base[t] = base;
+                bin_cursor[t] = 0;
+            }
         }
     }
     __syncthreads();
@@ -349,20 +377,31 @@ __global__ __launch_bounds__(1024) void k_bin_alloc_schedule(int nbins_total, in
         for (int k = 0; k < 4; k++) { counters[k] = c[k]; host_counters[k] = c[k]; }
         __threadfence_system();
     }
-    for (int t0 = 0; t0 < nbins_total; t0 += 1024) {
-        const int t = t0 + (int)threadIdx.x;
-        const int n = t < nbins_total ? bin_acc[t] : 1;
-        if (t < nbins_total) { bin_count[t] = n; bin_acc[t] = 0; }     // what the other kernels read / the accumulator left clear for the next set-up pass (no memset in the stream)
-        const bool empty = t < nbins_total && n <= 0;
-        const unsigned long long zb = ballot(empty);
-        int zbase = 0;
-        if (zb != 0ull) {
-            const int leader = (int)__builtin_ctzll(zb);
-            if (lane == leader) zbase = atomicAdd(&s_start[0], (int)__builtin_popcountll(zb));
-            zbase = __shfl(zbase, leader);
+    for (int c0 = 0; c0 < nbins_total; c0 += CH) {
+        if (!one_chunk) {
+#pragma unroll
+            for (int i = 0; i < SCHED_ITEMS; i++) {
+                const int t = c0 + i * 1024 + (int)threadIdx.x;
+                nreg[i] = t < nbins_total ? bin_acc[t] : 1;
+            }
         }
-        if (empty) bin_order[zbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(zb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)zb, 0u))] = t;
-        else if (t < nbins_total) bin_order[atomicAdd(&s_start[bucket(n)], 1)] = t;
+#pragma unroll
+        for (int i = 0; i < SCHED_ITEMS; i++) {
+            const int t = c0 + i * 1024 + (int)threadIdx.x;
+            if (c0 + i * 1024 >= nbins_total) break;
+            const int n = t < nbins_total ? nreg[i] : 1;
+            if (t < nbins_total) { bin_count[t] = n; bin_acc[t] = 0; }     // what the other kernels read / the accumulator left clear for the next set-up pass (no memset in the stream)
+            const bool empty = t < nbins_total && n <= 0;
+            const unsigned long long zb = ballot(empty);
+            int zbase = 0;
+            if (zb != 0ull) {
+                const int leader = (int)__builtin_ctzll(zb);
+                if (lane == leader) zbase = atomicAdd(&s_start[0], (int)__builtin_popcountll(zb));
+                zbase = __builtin_amdgcn_readlane(zbase, leader);
+            }
+            if (empty) bin_order[zbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(zb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)zb, 0u))] = t;
+            else if (t < nbins_total) bin_order[atomicAdd(&s_start[bucket(n)], 1)] = t;
+        }
     }
 }
 

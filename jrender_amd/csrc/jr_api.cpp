@@ -102,6 +102,8 @@ struct jr_ctx {
     std::unordered_map<void*, int> pinned;                  // block -> 1 while some live graph may address it
     std::unordered_map<void*, size_t> parked;               // freed pinned blocks (rounded size): not in the cache
     std::vector<void*> capture_blocks;                      // the open capture's blocks
+    std::unordered_map<size_t, std::vector<void*>> capture_free;   // ... those its sequence has freed again: reusable INSIDE the same capture
+                                                            // (a graph replays its nodes in the captured order, as the stream would), parked when it ends
     std::unordered_map<void*, std::vector<void*>> graph_blocks;   // graph exec -> its pinned blocks
     // The library's own scratch (bin arrays, pool, reduction scratch, NMR keys / planes) is addressed by captured kernels too:
     // every reallocation bumps this generation, a graph remembers the one it was captured under, jr_graph_launch refuses older ones.
@@ -445,6 +447,8 @@ int jr_ctx_destroy(jr_ctx* ctx) {
         for (void* p : kv.second) (void)hipFree(p);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     for (auto& kv : ctx->parked) (void)hipFree(kv.first);
+    for (auto& kv : ctx->capture_free)
+        for (void* p : kv.second) (void)hipFree(p);
     jr::BinWorkspace& ws = ctx->ws;
     (void)hipFree(ctx->zkey); (void)hipFree(ctx->n3_scratch); (void)hipFree(ctx->red_acc); (void)hipFree(ctx->red_ticket);
     (void)hipFree(ws.geo); (void)hipFree(ws.face_rect); (void)hipFree(ws.bin_acc); (void)hipFree(ws.bin_count); (void)hipFree(ws.bin_base); (void)hipFree(ws.bin_cursor); (void)hipFree(ws.bin_order);
@@ -465,7 +469,11 @@ int jr_malloc(jr_ctx* ctx, size_t bytes, void** dptr) {
     JR_HIP(hipSetDevice(ctx->device));
     const size_t sz = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
     auto it = ctx->cache.find(sz);
-    if (it != ctx->cache.end() && !it->second.empty()) {
+    auto cf = ctx->capturing ? ctx->capture_free.find(sz) : ctx->capture_free.end();
+    if (cf != ctx->capture_free.end() && !cf->second.empty()) {          // a block this capture's own sequence has freed
+        *dptr = cf->second.back();
+        cf->second.pop_back();
+    } else if (it != ctx->cache.end() && !it->second.empty()) {
         *dptr = it->second.back();
         it->second.pop_back();
         ctx->cached_bytes -= sz;
@@ -490,7 +498,8 @@ int jr_free(jr_ctx* ctx, void* dptr) {
     auto it = ctx->live.find(dptr);
     if (it == ctx->live.end()) return fail("jr_free: pointer %p was not allocated by this context", dptr);
     if (ctx->capturing && !ctx->pinned.count(dptr)) { ctx->pinned[dptr] = 1; ctx->capture_blocks.push_back(dptr); }   // (a captured kernel may have used it)
-    if (ctx->pinned.count(dptr)) ctx->parked[dptr] = it->second;     // a graph addresses it: out of circulation until jr_graph_destroy
+    if (ctx->capturing) ctx->capture_free[it->second].push_back(dptr);       // reusable by the rest of THIS capture only
+    else if (ctx->pinned.count(dptr)) ctx->parked[dptr] = it->second;        // a graph addresses it: out of circulation until jr_graph_destroy
     else {
         ctx->cache[it->second].push_back(dptr);
         ctx->cached_bytes += it->second;
@@ -868,6 +877,9 @@ int jr_graph_end(jr_ctx* ctx, void** graph_exec) {
     if (!ctx || !graph_exec) return fail("jr_graph_end: NULL argument");
     if (!ctx->capturing) return fail("jr_graph_end: no capture is open");
     ctx->capturing = 0;
+    for (auto& kv : ctx->capture_free)
+        for (void* b : kv.second) ctx->parked[b] = kv.first;
+    ctx->capture_free.clear();
     std::vector<void*> blocks;
     blocks.swap(ctx->capture_blocks);
     hipGraph_t graph = nullptr;
@@ -887,6 +899,9 @@ int jr_graph_abort(jr_ctx* ctx) {
     if (!ctx->capturing) return 0;
     ctx->capturing = 0;
     {
+        for (auto& kv : ctx->capture_free)
+            for (void* b : kv.second) ctx->parked[b] = kv.first;
+        ctx->capture_free.clear();
         std::vector<void*> blocks;
         blocks.swap(ctx->capture_blocks);
         unpin_blocks(ctx, blocks);

@@ -125,6 +125,10 @@
 #ifndef JR_TUNE_BWD_HASH_UNION   // backward (round 6): the faces a tile needs by hashing the pixels' buffered ids into an LDS table (0: per-lane sort + min-extraction, rounds 2 - 5)
 #define JR_TUNE_BWD_HASH_UNION 1
 #endif
+#ifndef JR_TUNE_LIGHT_SYNC       // one-wavefront raster kernels (round 6): LDS hand-overs inside the wavefront by a compiler fence (LDS instructions of a wavefront
+                                 // execute in order) instead of __syncthreads(), whose workgroup-scope fence waits for every outstanding store / atomic (vmcnt(0))
+#define JR_TUNE_LIGHT_SYNC 1
+#endif
 #ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
@@ -200,7 +204,7 @@
 #define JR_TUNE_PROFILE_SECTIONS 0
 #endif
 
-#ifndef JR_TUNE_COUNT_PATHS       // instrumented build: trips and lanes per region of the forward's raster loop (tools/sim/min_valu.py --measure)
+#ifndef JR_TUNE_COUNT_PATHS       // instrumented builds: 1 = trips and lanes per region of the forward's raster loop (tools/sim/min_valu.py --measure), 2 = the backward's (min_valu_bwd.py)
 #define JR_TUNE_COUNT_PATHS 0
 #endif
 #ifndef JR_TUNE_SECTIONS_WAVE     // instrumented build 2: which wavefront of the pipelined heavy tile's workgroup keeps the section clocks (0 K-buffer, 1 colour, 2 tasks, 3 stager)
@@ -211,7 +215,8 @@ namespace jr {
 namespace tune {
 constexpr int sections_wave = JR_TUNE_SECTIONS_WAVE;
 constexpr bool profile_sections = JR_TUNE_PROFILE_SECTIONS != 0;
-constexpr bool count_paths = JR_TUNE_COUNT_PATHS != 0;
+constexpr bool count_paths = JR_TUNE_COUNT_PATHS == 1;        // the forward's raster loop
+constexpr bool count_paths_bwd = JR_TUNE_COUNT_PATHS == 2;    // the backward: tiles, passes, batches, trips, lanes, inside / slow trips (tools/sim/min_valu_bwd.py --measure)
 constexpr bool n3_pixmap_all = JR_TUNE_N3_PIXMAP_ALL != 0;
 constexpr int n3_xcd_group = JR_TUNE_N3_XCD_GROUP;
 constexpr int n3_walks = JR_TUNE_N3_WALKS;
@@ -235,7 +240,10 @@ constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
 // slots (11.3 KB) cost no occupancy and save batch turn-arounds: forward 1.444 -> 1.393 ms, backward 1.548 -> 1.529 (round 5 call 17);
 // at K <= 32 (4 per SIMD) 56 / 64 slots measured slower in both kernels
 constexpr int fwd_batch_for(int kcap) { return kcap > 32 ? 64 : JR_TUNE_FWD_BATCH; }
-constexpr int bwd_batch_for(int kcap) { return kcap > 32 ? 64 : JR_TUNE_BWD_BATCH; }
+#ifndef JR_TUNE_BWD_BATCH64      // backward at K > 32: record slots per wavefront (64 x 176 B = 11.3 KB: 13 wavefronts per CU; 52 -> 16)
+#define JR_TUNE_BWD_BATCH64 64
+#endif
+constexpr int bwd_batch_for(int kcap) { return kcap > 32 ? JR_TUNE_BWD_BATCH64 : JR_TUNE_BWD_BATCH; }
 constexpr int fwd_batch_mixed = JR_TUNE_FWD_BATCH_MIXED;
 constexpr int fwd_waves16 = JR_TUNE_FWD_WAVES16;
 constexpr bool fwd_heavy_overlap = JR_TUNE_FWD_HEAVY_OVERLAP != 0;
@@ -268,6 +276,7 @@ constexpr int auto_bin8_max_image = JR_TUNE_AUTO_BIN8_MAX_IMAGE, auto_bin16_max_
 constexpr bool fwd_heavy_defer_copy = JR_TUNE_FWD_HEAVY_DEFER_COPY != 0;
 constexpr bool bwd_tv_rcp = JR_TUNE_BWD_TV_RCP != 0;
 constexpr bool bwd_hash_union = JR_TUNE_BWD_HASH_UNION != 0;
+constexpr bool light_sync = JR_TUNE_LIGHT_SYNC != 0;
 constexpr bool bwd_row_ranges = JR_TUNE_BWD_ROW_RANGES != 0;
 }  // namespace tune
 }  // namespace jr

@@ -168,6 +168,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
             else {
                 const float* tx_ = (tex_block ? tex_block : tbase + (size_t)fn * p.T * 3) + texel * 3;      // (the staged LDS copy of the face's texels, or global)
                 k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
+                if (!tex_block) asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2));     // (a global load: its wait stays in this branch, not at the join with the T = 1 path - softras_forward.hip: sample_colour)
             }
         } else {                                                           // SRK:1147-1149 (affine)
             k0 = (wc.w0 * vc[0] + wc.w1 * vc[3]) + wc.w2 * vc[6];
@@ -224,6 +225,18 @@ constexpr int bwd_waves(int dist, int rgb, int kcap, bool texlds) {
     const int w = texlds ? (kcap <= 32 ? 4 : 3) : (kcap <= 16 ? JR_TUNE_BWD_WAVES : (kcap <= 32 ? 4 : JR_TUNE_BWD_WAVES64));
     const bool spills = dist == 1 && rgb != 2 && ((kcap <= 16 && !texlds) || (kcap == 32 && texlds));
     return spills && w > 3 ? w - 1 : w;
+}
+
+// LDS hand-over inside the kernel's ONE wavefront (writes by some lanes, reads by others).  LDS instructions of a wavefront execute in
+// order, so only the compiler has to be kept from moving accesses across this point; __syncthreads() also is a workgroup-scope fence,
+// which on gfx950 waits for every outstanding global store and atomic (s_waitcnt vmcnt(0)): the gradient atomics of a whole batch.
+__device__ inline void bsync() {
+    if (tune::light_sync) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);           // (nothing is scheduled across: with the freedom the lighter fence gives, the allocator spilled 8 - 12 B)
+    } else __syncthreads();
 }
 
 // open-addressing table of the hashed union (round 6): 256 entries x 16 B over the record slots + 64 compacted entries
@@ -300,6 +313,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
 
     SectionClock clk;            // instrumented builds only: 0 tile state, 1 extraction, 2 staging + items, 3 gather, 4 pair, 5 reduce + atomics
     clk.start();
+    // instrumented build JR_TUNE_COUNT_PATHS = 2 (tools/sim/min_valu_bwd.py --measure): the dynamic half of the backward's VALU model -
+    // 0 tiles, 1 union passes, 2 batches, 3 trips, 4 lanes with a pair, 5 trips with an inside pair, 6 inside lanes, 7 trips with a
+    // non-FAST face, 8 their lanes, 9 distinct faces, 10 work items.  Wave-uniform scalars, flushed by lane 0; dead code otherwise.
+    unsigned pcnt[11] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // this pixel's buffered face ids; the reference stops at the first -1 (SRK:1236-1238)
     constexpr int BIG = 0x7fffffff;
     constexpr bool HASHED = tune::bwd_hash_union;
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
         px.ssum = aggrs[(size_t)b * 2 * pp + pn];
         px.smax = aggrs[(size_t)b * 2 * pp + pp + pn];
     }
-    px.r_ssum = __builtin_amdgcn_rcpf(px.ssum);
+    px.r_ssum = 0.f;                                 // (formed after the gather)
 
     const FaceGeo* gbase = geo + (size_t)b * p.NF;
     const float* tbase = textures + (size_t)b * p.NF * p.T * 3;
@@ -393,10 +410,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
             if (lane >= d) incl += o;
         }
         const int nitems = __builtin_amdgcn_readlane(incl, 63);
+        if (tune::count_paths_bwd) { pcnt[2]++; pcnt[9] += (unsigned)fill; pcnt[10] += (unsigned)nitems; }
         if (lane < BATCH) s_has[lane] = has;
         s_ioff[lane] = incl - items;
         if (lane == 0) s_ioff[64] = nitems;
-        __syncthreads();
+        bsync();
 
         // ---- each 16-lane DPP row takes one item per trip (four faces in flight per wavefront): gather
         //      the pixels' state, pair arithmetic, row-local transpose-reduction -> lane k of the row
@@ -459,7 +477,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
             else {
             q.g0 = gather(px.g0, src); q.g1 = gather(px.g1, src); q.g2 = gather(px.g2, src); q.g3 = gather(px.g3, src);
             q.o0 = gather(px.o0, src); q.o1 = gather(px.o1, src); q.o2 = gather(px.o2, src); q.o3 = gather(px.o3, src);
-            q.ssum = gather(px.ssum, src); q.smax = gather(px.smax, src); q.r_ssum = gather(px.r_ssum, src);
+            q.ssum = gather(px.ssum, src); q.smax = gather(px.smax, src);
+            q.r_ssum = __builtin_amdgcn_rcpf(q.ssum);       // (the same bits as gathering the pixel's own reciprocal: one v_rcp per trip instead of a register held through the kernel + a 13th ds_bpermute)
             }
             const float qx = (JR_TUNE_DIAG & 256) ? xp : gather(xp, src), qy = (JR_TUNE_DIAG & 256) ? yp : gather(yp, src);
             if (tune::profile_sections) { __builtin_amdgcn_s_waitcnt(0); clk.lap(3); }
@@ -470,6 +489,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
             // short-circuit ladder (every rung would re-materialise the zeroed outputs)
             const float4 box = *reinterpret_cast<const float4*>(&fr);       // xlo xhi ylo yhi
             const bool inb = !(qx > box.y) & !(qx < box.x) & !(qy > box.w) & !(qy < box.z);
+            if (tune::count_paths_bwd) {
+                const bool on = act & inb, fast = face_safe(fr.meta) && p.consts_safe;
+                const bool ins = on && DIST == 2 && strictly_inside(barycentric(fr, qx, qy));
+                pcnt[3]++; pcnt[4] += (unsigned)__builtin_popcountll(ballot(on));
+                const unsigned long long bi = ballot(ins), bs = ballot(on && !fast);
+                pcnt[5] += bi != 0ull; pcnt[6] += (unsigned)__builtin_popcountll(bi);
+                pcnt[7] += bs != 0ull; pcnt[8] += (unsigned)__builtin_popcountll(bs);
+            }
             if (act & inb) {
                 float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // x0 y0 z0 x1 y1 z1 x2 y2 z2
                 float tgs;
@@ -540,7 +567,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
         }
         if (RANGES && !(JR_TUNE_DIAG & 32)) flush();
         if (TEXLDS) {            // the batch's texel sums leave: one global atomic per touched component, 16 lanes per slot as in the staging
-            __syncthreads();
+            bsync();
             const int t3 = p.T * 3, sub = lane >> 4, l16 = lane & 15;
             for (int s0 = 0; s0 < fill; s0 += 4) {
                 const int slot = s0 + sub;
@@ -555,7 +582,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
                 }
             }
         }
-        __syncthreads();                        // the batch's records and tables are free again
+        bsync();                        // the batch's records and tables are free again
     };
 
     if (!HASHED) {
@@ -614,7 +641,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
 #pragma unroll
                 for (int k = 0; k < KCAP; k++) raw[k] = (valid && k < kk) ? (plane0 + (size_t)k * pp)[pn32] : -1;
             }
-            __syncthreads();
+            bsync();
             // Every plane's first probe is issued before any result is looked at (one LDS round trip for the tile's K planes
             // instead of K dependent ones); a lane whose first probe hit another id walks on - at most HT_PROBES entries, a
             // table that full means "too many faces for one pass" anyway.  No short-circuit ladder: the predicates are
@@ -659,7 +686,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
                     }
                 }
             }
-            __syncthreads();
+            bsync();
             // ---- compaction: used entries -> comp[0 .. ndist) -> lane j holds face j ----
             int ndist = 0;
 #pragma unroll
@@ -672,12 +699,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
                 ndist += __builtin_popcountll(um);
             }
             const bool overflow = ndist > 64 || ballot(lost) != 0ull;
-            __syncthreads();
+            bsync();
+            if (tune::count_paths_bwd) pcnt[1]++;
             if (overflow) { cl++; continue; }                     // refine: (L + 1, v) is the left child; every id in exactly one leaf
             int eid = 0;
             unsigned long long ehas = 0ull;
             if (lane < ndist) { const int4 ent = comp[lane]; eid = ent.x; ehas = ((unsigned long long)(unsigned)ent.w << 32) | (unsigned)ent.z; }
-            __syncthreads();                                      // the table's LDS becomes record slots again
+            bsync();                                      // the table's LDS becomes record slots again
             clk.lap(1);
             for (int b0 = 0; b0 < ndist; b0 += BATCH) {
                 const int fill = min(BATCH, ndist - b0);
@@ -700,6 +728,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(bwd_waves(DI
     }
     clk.lap(1);
     if (JR_TUNE_PROFILE_SECTIONS == 1) clk.flush(counters, 12);
+    if (tune::count_paths_bwd && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; i++) atomicAdd(counters + 4 + i, (unsigned long long)pcnt[i]);
+    }
 }
 
 template <int DIST, int RGB>

@@ -168,6 +168,11 @@ __device__ inline void sample_colour(const RasterParams& p, const FaceRec& r, co
         else {
             const float* tx_ = tbase + ((size_t)face_id(r.meta) * p.T + surface_texel(wc, p.R)) * 3;
             k0 = tx_[0]; k1 = tx_[1]; k2 = tx_[2];
+        asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2));          // (the load's wait stays in this branch: see sample_colour)
+            // Round 6: consume the load HERE.  Left to the compiler, the wait for it lands at the join with the single-texel path as
+            // `s_waitcnt vmcnt(0)` - and on gfx950 stores and atomics count on the same in-order counter, so EVERY trip of the raster loop,
+            // T = 1 launches included, waited there for the id store it had just issued (the backward: for its gradient atomics).
+            asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2));
         }
     } else {                                                                   // SRK:168-171
         k0 = ((wc.w0 * vc[0] / r.z[0] + wc.w1 * vc[3] / r.z[1]) + wc.w2 * vc[6] / r.z[2]) * zp;
@@ -1352,7 +1357,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     }
     TileGeom t;
     if (!tile_geom(p, bin, k & tmask, n, threadIdx.x, t, bl)) return;
-    tile_single<DIST, RGB, KCAP, tune::fwd_batch_for(KCAP), true>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
+    tile_single<DIST, RGB, KCAP, tune::fwd_batch_for(KCAP), !tune::light_sync>(p, t, threadIdx.x, s_dyn, textures, geo, pool + bin_base[bin], counters, aggrs, rgba, ids);
 }
 
 // NW = four or eight wavefronts per workgroup (round 3).  The launch order of the bins is heaviest first

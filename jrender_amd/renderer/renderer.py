@@ -131,6 +131,15 @@ class Renderer:
         gt = self._fold_back(gt.numpy(), transpose_cube=self.dr_type == 'n3mr')
         return (gt * lit["dlit"]).astype(np.float32)
 
+    def grad_material(self, grad_rgb):
+        """d(loss)/d(metallic_textures), d(loss)/d(roughness_textures) of the last ``render_mesh(mode='rgb')`` of a mesh with
+        specular material ('surface' textures): rasteriser backward -> fold of the fill_back half -> VJP of the Cook-Torrance
+        lighting step (lighting.py:177-204, directional_lighting.py:86-130).  What demo5-optim_metallic_textures.py:38-44 and
+        demo6-optim_roughness_textures.py differentiate through."""
+        _, gt = self._rasterizer_backward(None, grad_rgb, None)
+        gt = self._fold_back(gt.numpy(), transpose_cube=self.dr_type == 'n3mr')
+        return self.lighting.backward_material(gt)
+
     def execute(self, vertices, faces, textures=None, mode='rgb', texture_type='surface',
                 metallic_textures=None, roughness_textures=None):
         mesh = Mesh(vertices, faces, textures=textures, texture_type=texture_type,

@@ -261,7 +261,10 @@ def test_whole_view_end_to_end_gradient_vs_the_references_own_forward(scene):
     print("precise colour: grad_faces %.3g (fast path %.3g) vertex gradient %.3g (%.3g) | RGBA error / tolerance %.3g (%.3g)"
           % (p_f, e_f, p_v, e_v, rgba_precise, rgba_fast))
     assert rgba_precise <= 0.5 * max(rgba_fast, 0.2) and rgba_precise <= 0.3
-    assert p_f <= max(1.3e-4, 2.5 * noise_f) and p_v <= max(2.0e-4, 3 * noise_v)
+    # the conformant mode is gated at the contract's 1e-4 ELEMENT-WISE (1e-3 floor) for grad_faces - or twice the
+    # reference's own atomic-order noise on this input where that is larger (3 - 5e-5 measured, so the bar is 1e-4 in practice);
+    # the vertex gradient sums ~6 face gradients per vertex and is held to 1.5e-4 / 2.5 x its noise
+    assert p_f <= max(1.0e-4, 2.0 * noise_f) and p_v <= max(1.5e-4, 2.5 * noise_v)
 
 
 def test_heavy_tile_path_whole_view_forward_and_dense_backward():

@@ -323,6 +323,70 @@ def test_csr_arrays_of_the_laplacian_match_scipy():
     assert np.array_equal(rp, [0, 0, 0, 0]) and c.size == 0 and vl.size == 0
 
 
+def test_cook_torrance_vjp_with_respect_to_metallic_and_roughness(monkeypatch):
+    """VERDICT r5 next #8 (directional_lighting.py:86-130; demo5 / demo6 differentiate it with Jittor's autograd): the hand-written
+    VJP of the Cook-Torrance branch against central differences of the forward, both evaluated in float64 (the module's float32
+    casts are switched to float64 for the duration of the test) on the fixture inputs the reference's own forward was pinned on."""
+    import importlib
+    L = importlib.import_module("jrender_amd.renderer.lighting")
+    monkeypatch.setattr(L, "F32", np.float64)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_ref.npz"))
+    N, P, E, M, R = [z[k].astype(np.float64) for k in ("in_normals", "in_positions", "in_eye", "in_metallic", "in_roughness")]
+    rng = np.random.default_rng(0)
+    gd, gs = rng.normal(size=N.shape), rng.normal(size=N.shape)
+    kw = dict(light_intensity=0.7, light_color=(1, 0.9, 0.8), light_direction=(0.3, 1, 0.2))
+
+    def f(m, r):
+        d, s = L.directional_lighting(np.zeros_like(N), np.zeros_like(N), N, positions=P, eye=E, with_specular=True,
+                                      metallic_textures=m, roughness_textures=r, **kw)
+        return float((d * gd).sum() + (s * gs).sum())
+    gm, gr = L.directional_lighting_backward(gd, gs, N, positions=P, eye=E, metallic_textures=M, roughness_textures=R, **kw)
+    assert gm.shape == M.shape and gr.shape == R.shape
+    h = 1e-6
+    for which, g in (("m", gm), ("r", gr)):
+        for _ in range(25):
+            i = tuple(int(rng.integers(0, n)) for n in M.shape)
+            a, b = (M if which == "m" else R).copy(), (M if which == "m" else R).copy()
+            a[i] += h; b[i] -= h
+            fd = (f(a, R) - f(b, R)) / (2 * h) if which == "m" else (f(M, a) - f(M, b)) / (2 * h)
+            assert abs(fd - g[i]) <= 1e-6 * max(1.0, abs(fd)), (which, i, fd, g[i])
+
+
+def test_lighting_backward_material_goes_through_the_clip(monkeypatch):
+    """Lighting.backward_material = VJP of lit = clip(textures * diffuse + specular, 0, 1) (lighting.py:203-204) with respect to the
+    mesh's metallic / roughness textures: against central differences of Lighting.__call__ in float64, on a mesh whose bright
+    texels saturate (the clip's mask must cut their gradient)."""
+    import importlib
+    import jrender_amd as jr
+    L = importlib.import_module("jrender_amd.renderer.lighting")
+    monkeypatch.setattr(L, "F32", np.float64)
+    monkeypatch.setattr(importlib.import_module("jrender_amd.structures.mesh"), "F32", np.float64)
+    v, f = jr.synthetic.uv_sphere(8, 5)
+    rng = np.random.default_rng(4)
+    nf, T = f.shape[0], 4
+    tex = rng.uniform(0.1, 3.0, (1, nf, T, 3))                       # some texels end above 1 after lighting
+    M, R = rng.uniform(0.05, 0.9, (1, nf, T, 1)), rng.uniform(0.2, 0.95, (1, nf, T, 1))
+    eyes = np.array([[0.3, 1.1, -2.5]])
+    G = rng.normal(size=tex.shape)
+    light = L.Lighting('surface', 0.3, [1, 1, 1], 0.9, [1, 0.8, 0.9], [0.2, 1, -0.4])
+
+    def lit(m, r):
+        mesh = jr.Mesh(v, f, textures=tex.copy(), metallic_textures=m, roughness_textures=r)
+        mesh._textures = tex.copy(); mesh._metallic_textures = m; mesh._roughness_textures = r      # (keep float64 past the constructor's float32 casts)
+        return np.asarray(light(mesh, eyes).textures)
+    out = lit(M, R)
+    assert (out == 1.0).any() and ((out > 0) & (out < 1)).any()
+    gm, gr = light.backward_material(G)
+    h = 1e-6
+    for which, g in (("m", gm), ("r", gr)):
+        for _ in range(12):
+            i = tuple(int(rng.integers(0, n)) for n in M.shape)
+            a, b = (M if which == "m" else R).copy(), (M if which == "m" else R).copy()
+            a[i] += h; b[i] -= h
+            fd = ((lit(a, R) - lit(b, R)) * G).sum() / (2 * h) if which == "m" else ((lit(M, a) - lit(M, b)) * G).sum() / (2 * h)
+            assert abs(fd - g[i]) <= 2e-5 * max(1.0, abs(fd)), (which, i, fd, g[i])
+
+
 def test_sparse_laplacian_is_the_dense_construction_on_unclean_meshes():
     """the CSR construction of LaplacianLoss against the reference's dense one (laplacian_loss.py:14-26) on a mesh
     with faces that repeat a vertex (the self -1 is part of the row sum: diagonal = degree + 1) and vertices no face uses

@@ -59,6 +59,10 @@ VARIANTS = {
     "bwd_k64w4": ["JR_TUNE_BWD_WAVES64=4"],                  # round 3: backward at K = 64 with 4 wavefronts per SIMD (52 B of scratch)
     "sections_sorted": ["JR_TUNE_PROFILE_SECTIONS=1", "JR_TUNE_FWD_HEAVY=0", "JR_TUNE_BWD_HASH_UNION=0"],
     "hashv1": [],                                           # (round 6 call 2: a saved build of the first hashed union - one dependent LDS round trip per id plane; not reproducible from a define)
+    "count_paths_bwd": ["JR_TUNE_COUNT_PATHS=2"],           # instrumented: tools/sim/min_valu_bwd.py --measure
+    "bwd_k64w4b52": ["JR_TUNE_BWD_WAVES64=4", "JR_TUNE_BWD_BATCH64=52"],   # round 6: K = 64 backward fits 128 VGPRs with the hashed union: 4 wavefronts per SIMD need <= 10 KB of LDS
+    "prev": [],                                             # (round 6 call 6: a saved build from before the texel-load wait fix / light sync)
+    "heavy_sync": ["JR_TUNE_LIGHT_SYNC=0"],                 # round 6: __syncthreads() (workgroup-scope fence: vmcnt(0)) for the LDS hand-overs of the one-wavefront raster kernels
     "bwd_sorted": ["JR_TUNE_BWD_HASH_UNION=0"],             # round 6: the backward's face union by per-lane sort + min-extraction (rounds 2 - 5) instead of the LDS hash table
     "no_heavy_pipe": ["JR_TUNE_FWD_HEAVY_PIPE=0"],           # round 3: heavy tiles with the passes in sequence (tile_heavy) instead of the pipeline
     "pipe_ct2": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=2"], "pipe_ct0": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=0"],   # round 3: the K-buffer wavefront / both applying wavefronts take no evaluate tasks

@@ -16,7 +16,17 @@ cp gpurun_out/profiles_${tag}_b1/${tag}_b1_* $out/ 2>/dev/null
 rm -rf gpurun_out/n3mr_prof; tools/collect_profiles_n3mr.sh
 for f in gpurun_out/n3mr_prof/n3mr_*; do cp $f $out/${tag}_$(basename $f); done
 python tools/pmc_n3mr_to_json.py gpurun_out/n3mr_prof $tag > $out/${tag}_pmc_n3mr_to_json.log 2>&1
-cp profiles/traffic_latest.json profiles/valu_latest.json profiles/traffic_n3mr_latest.json $out/
+# round 6: both raster kernels' VALU floors from THIS run's counters (instrumented builds count_paths / count_paths_bwd must exist:
+# python tools/ablate/build.py count_paths count_paths_bwd) - profiles/min_valu_latest.json, min_valu_bwd_latest.json
+if [ -f jrender_amd/csrc/libjrender_hip_count_paths.so ]; then
+  (timeout 200 python tools/sim/min_valu.py --measure > /dev/null 2>&1; timeout 200 python tools/sim/min_valu.py > $out/${tag}_min_valu.txt 2>&1)
+  cp profiles/r05_path_counts.json $out/${tag}_path_counts_fwd.json 2>/dev/null
+fi
+if [ -f jrender_amd/csrc/libjrender_hip_count_paths_bwd.so ]; then
+  (timeout 200 python tools/sim/min_valu_bwd.py --measure > /dev/null 2>&1; timeout 200 python tools/sim/min_valu_bwd.py > $out/${tag}_min_valu_bwd.txt 2>&1)
+  cp profiles/r06_path_counts_bwd.json $out/ 2>/dev/null
+fi
+cp profiles/traffic_latest.json profiles/valu_latest.json profiles/traffic_n3mr_latest.json profiles/min_valu_latest.json profiles/min_valu_bwd_latest.json $out/ 2>/dev/null
 (timeout 300 python __graft_entry__.py --smoke > $out/${tag}_smoke.log 2>&1; echo "smoke rc=$?" >> $out/${tag}_smoke.log)
 timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --scene soup --no-secondary > $out/${tag}_bench_soup.json 2>> $out/${tag}_bench.err
