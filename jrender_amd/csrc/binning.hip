@@ -84,7 +84,18 @@ __device__ inline int wave_bin_add(int* __restrict__ arr, int tb) {
     return __shfl(base, leader) + rank;
 }
 
-constexpr int SETUP_WG = 128;      // faces per workgroup of k_face_setup (22 KB of LDS: 7 workgroups per CU in flight)
+// Faces per workgroup of k_face_setup.  Round 6: ONE wavefront (11 KB of LDS: 14 per CU, as many wavefronts as before) - the two LDS
+// transposes then need no workgroup barrier, and above all no __syncthreads(): its workgroup-scope fence waits for every outstanding global
+// store (s_waitcnt vmcnt(0)), i.e. the kernel - 328 B of stores per face, 3 x off the memset rate - stalled at each of its three barriers
+// until the stores it had just issued were acknowledged.  LDS instructions of a wavefront execute in order: a compiler fence is enough.
+constexpr int SETUP_WG = JR_TUNE_SETUP_WG;
+__device__ inline void setup_sync() {
+    if (SETUP_WG == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else __syncthreads();
+}
 __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const float* __restrict__ faces,
                                                     const float* __restrict__ textures,
                                                     float* __restrict__ faces_info,
@@ -109,13 +120,13 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     if (faces_info) {   // nullptr when the backward only rebuilds the lists
 #pragma unroll
         for (int k = 0; k < 27; k++) s_out[threadIdx.x * 27 + k] = info[k];
-        __syncthreads();
+        setup_sync();
         float* out = faces_info + (size_t)i0 * 27;                  // SETUP_WG*108 B per block: 16 B aligned
         const int nfl = nvalid * 27;
         for (int q = threadIdx.x; q < (nfl >> 2); q += SETUP_WG)
             reinterpret_cast<float4*>(out)[q] = reinterpret_cast<const float4*>(s_out)[q];
         if (threadIdx.x < (nfl & 3)) out[(nfl & ~3) + threadIdx.x] = s_out[(nfl & ~3) + threadIdx.x];
-        __syncthreads();
+        setup_sync();
     }
     clk.lap(1);
     FaceGeo g;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
         g.col[0] = tx[0]; g.col[1] = tx[1]; g.col[2] = tx[2];
     }
     *reinterpret_cast<FaceGeo*>(&s_out[threadIdx.x * 44]) = g;
-    __syncthreads();
+    setup_sync();
     {
         float4* out = reinterpret_cast<float4*>(geo + i0);
         for (int q = threadIdx.x; q < nvalid * 11; q += SETUP_WG) out[q] = reinterpret_cast<const float4*>(s_out)[q];

@@ -129,6 +129,9 @@
                                  // execute in order) instead of __syncthreads(), whose workgroup-scope fence waits for every outstanding store / atomic (vmcnt(0))
 #define JR_TUNE_LIGHT_SYNC 1
 #endif
+#ifndef JR_TUNE_SETUP_WG         // k_face_setup: faces per workgroup (64 = one wavefront, LDS hand-overs without __syncthreads(); 128 = rounds 1 - 5)
+#define JR_TUNE_SETUP_WG 64
+#endif
 #ifndef JR_TUNE_BWD_TV_RCP       // backward: edge-projection parameter by reciprocal multiply (gradient-only use)
 #define JR_TUNE_BWD_TV_RCP 0
 #endif
@@ -148,8 +151,8 @@
 #ifndef JR_TUNE_BWD_ONE_ATOMIC    // backward: grad_faces and grad_textures components of a flush in one atomic instruction (per-lane selected address)
 #define JR_TUNE_BWD_ONE_ATOMIC 1
 #endif
-#ifndef JR_TUNE_BWD_WAVES64       // backward at 32 < K <= 64: wavefronts per SIMD (3 -> 158 VGPRs; 4 -> 128 with 52 B of scratch)
-#define JR_TUNE_BWD_WAVES64 3
+#ifndef JR_TUNE_BWD_WAVES64       // backward at 32 < K <= 64: wavefronts per SIMD (rounds 3 - 5: 3 -> 158 VGPRs, 4 spilled 52 B; round 6: 4 -> 128 VGPRs, euclidean 'softmax' keeps 36 B outside the pair loop)
+#define JR_TUNE_BWD_WAVES64 4
 #endif
 #ifndef JR_TUNE_BWD_SPLIT         // backward: wavefronts per tile of a HEAVY bin in launches of up to BWD_SPLIT_PIXELS pixels (each keeps the ids with id % SPLIT == its part); 0 / 1 = off
 #define JR_TUNE_BWD_SPLIT 4
@@ -240,8 +243,9 @@ constexpr int fwd_batch = JR_TUNE_FWD_BATCH;
 // slots (11.3 KB) cost no occupancy and save batch turn-arounds: forward 1.444 -> 1.393 ms, backward 1.548 -> 1.529 (round 5 call 17);
 // at K <= 32 (4 per SIMD) 56 / 64 slots measured slower in both kernels
 constexpr int fwd_batch_for(int kcap) { return kcap > 32 ? 64 : JR_TUNE_FWD_BATCH; }
-#ifndef JR_TUNE_BWD_BATCH64      // backward at K > 32: record slots per wavefront (64 x 176 B = 11.3 KB: 13 wavefronts per CU; 52 -> 16)
-#define JR_TUNE_BWD_BATCH64 64
+#ifndef JR_TUNE_BWD_BATCH64      // backward at K > 32: record slots per wavefront.  Round 6: with the hashed union the K = 64 kernels fit 128 VGPRs, so 4 wavefronts
+                                 // per SIMD pay when the LDS allows 16 per CU: 52 slots (9.7 KB) instead of 64 (11.3 KB: 13 per CU) - backward 1.536 -> 1.365 ms on the headline batch at K = 64
+#define JR_TUNE_BWD_BATCH64 52
 #endif
 constexpr int bwd_batch_for(int kcap) { return kcap > 32 ? JR_TUNE_BWD_BATCH64 : JR_TUNE_BWD_BATCH; }
 constexpr int fwd_batch_mixed = JR_TUNE_FWD_BATCH_MIXED;

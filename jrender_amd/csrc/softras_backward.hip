@@ -223,7 +223,7 @@ __device__ inline int backward_pair(const RasterParams& p, const FaceRec& r, con
 // 20 / 32 B at five wavefronts, <1,1,32> with the LDS texel sums 16 B at four - one wavefront fewer for those three.
 constexpr int bwd_waves(int dist, int rgb, int kcap, bool texlds) {
     const int w = texlds ? (kcap <= 32 ? 4 : 3) : (kcap <= 16 ? JR_TUNE_BWD_WAVES : (kcap <= 32 ? 4 : JR_TUNE_BWD_WAVES64));
-    const bool spills = dist == 1 && rgb != 2 && ((kcap <= 16 && !texlds) || (kcap == 32 && texlds));
+    const bool spills = dist == 1 && rgb != 2 && ((kcap <= 16 && !texlds) || (kcap == 32 && texlds) || (kcap > 32 && !texlds));   // (K = 64 'barycentric': 32 - 48 B at four wavefronts)
     return spills && w > 3 ? w - 1 : w;
 }
 

@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fwd_waves(KC
     const int bin = bin_order[brank];                    // ... heaviest first (k_bin_alloc_schedule)
     const int n = bin_count[bin];
     if (tune::fwd_empty_bins && n == 0 && (p.IS & ((1 << bl) - 1)) == 0) {    // empty bin: tile 0's wavefront writes all its tiles
-        if ((k & tmask) == 0) store_empty_bin<RGB, KCAP>(p, bin, threadIdx.x, bl, aggrs, rgba, ids);
+        if ((k & tmask) == 0 && !(JR_TUNE_DIAG & 2048)) store_empty_bin<RGB, KCAP>(p, bin, threadIdx.x, bl, aggrs, rgba, ids);   // (diagnostic bit 11, WRONG images: what do the empty bins' stores cost the launch?)
         return;
     }
     TileGeom t;

@@ -228,6 +228,31 @@ def test_crowded_bin(ctx, port):
         assert ctx.last_stats()["max_faces_in_bin"] > 4096
 
 
+@pytest.mark.parametrize("K,heavy,half", [(16, False, 0.03), (64, False, 0.12), (64, True, 0.12), (33, True, 0.06)])
+def test_backward_union_of_more_than_64_faces_per_tile(ctx, port, K, heavy, half):
+    """Round 6: the backward finds a tile's faces by hashing its pixels' buffered ids into an LDS table that holds 64 distinct faces per
+    pass; a tile that needs more is cut into residue classes of the face id, refined where a class still overflows (softras_backward.hip).
+    14 000 pixel-sized triangles on a 64^2 image put ~5 faces on every pixel and 150 - 300 distinct faces into every 8x8 tile (asserted on
+    the oracle's index buffer), K = 64 up to 1 000; `heavy` also splits the heavy tiles over several wavefronts by id residue (the classes are
+    then taken from the bits above that residue).  Index buffer bit-exact as always; the gradients are the point."""
+    rng = np.random.default_rng(11)
+    n = 14000
+    c = rng.uniform(-0.97, 0.97, (n, 1, 2))
+    xy = c + rng.uniform(-half, half, (n, 3, 2))                     # (half = 0.03: pixel-sized faces, ~5 per pixel; 0.12: ~60 per pixel, the K = 64 buffers fill)
+    z = rng.uniform(2, 4, (n, 3, 1))
+    fv = np.concatenate([xy, z], -1).astype(np.float32)[None]
+    tex = rng.uniform(0, 1, (1, n, 1, 3)).astype(np.float32)
+    if heavy:
+        ctx.set_launch_policy(48, 8)
+    try:
+        ref, fn = run_case(ctx, port, fv, tex, image_size=64, max_faces_per_pixel_for_grad=K, sigma_val=1e-5)
+    finally:
+        ctx.set_launch_policy(-1, 0)
+    ids = ref["faces_id_buffer"][0]                                  # [K, 64, 64]
+    per_tile = [np.unique(ids[:, r:r + 8, c:c + 8][ids[:, r:r + 8, c:c + 8] >= 0]).size for r in range(0, 64, 8) for c in range(0, 64, 8)]
+    assert min(per_tile) > 64 and max(per_tile) > 128, (min(per_tile), max(per_tile))
+
+
 def test_degenerate_faces_do_not_break_parity(ctx, port):
     # zero-area and sliver triangles: the det clamp path (SRK:213) must match bit for bit
     fv, tex = syn.triangle_soup(200, 1, seed=9, scale=2.0)

@@ -63,6 +63,8 @@ VARIANTS = {
     "bwd_k64w4b52": ["JR_TUNE_BWD_WAVES64=4", "JR_TUNE_BWD_BATCH64=52"],   # round 6: K = 64 backward fits 128 VGPRs with the hashed union: 4 wavefronts per SIMD need <= 10 KB of LDS
     "prev": [],                                             # (round 6 call 6: a saved build from before the texel-load wait fix / light sync)
     "heavy_sync": ["JR_TUNE_LIGHT_SYNC=0"],                 # round 6: __syncthreads() (workgroup-scope fence: vmcnt(0)) for the LDS hand-overs of the one-wavefront raster kernels
+    "setup128": ["JR_TUNE_SETUP_WG=128"],                   # round 6: k_face_setup with 128-face workgroups and __syncthreads() (rounds 1 - 5)
+    "diag_noempty": ["JR_TUNE_DIAG=2048"],                  # WRONG images: the headline forward without the empty bins' output stores (what do they cost the launch?)
     "bwd_sorted": ["JR_TUNE_BWD_HASH_UNION=0"],             # round 6: the backward's face union by per-lane sort + min-extraction (rounds 2 - 5) instead of the LDS hash table
     "no_heavy_pipe": ["JR_TUNE_FWD_HEAVY_PIPE=0"],           # round 3: heavy tiles with the passes in sequence (tile_heavy) instead of the pipeline
     "pipe_ct2": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=2"], "pipe_ct0": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=0"],   # round 3: the K-buffer wavefront / both applying wavefronts take no evaluate tasks

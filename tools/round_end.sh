@@ -37,7 +37,7 @@ timeout 400 python tools/time_configs.py > $out/${tag}_time_configs.txt 2>&1
 (timeout 900 python tests/fuzz_parity.py --cases 600 --seed ${FUZZ_SEED:-81} > $out/${tag}_fuzz_softras.log 2>&1; echo "rc=$?" >> $out/${tag}_fuzz_softras.log)
 (timeout 300 python tests/fuzz_n3mr.py --cases 1500 --seed ${FUZZ_SEED:-81} > $out/${tag}_fuzz_n3mr.log 2>&1; echo "rc=$?" >> $out/${tag}_fuzz_n3mr.log)
 timeout 600 python tools/geometry_sweep.py --quick --bins 32 > $out/${tag}_policy_vs_bin32.txt 2>&1
-timeout 120 python bench.py --dry-run-ranks 8 > $out/${tag}_dry_run_8_ranks.json 2>> $out/${tag}_bench.err
+for n in 2 4 8; do timeout 120 python bench.py --dry-run-ranks $n > $out/${tag}_dry_run_${n}_ranks.json 2>> $out/${tag}_bench.err; done
 # kernel trace of the demo2 loop with the chain around the rasteriser on the device
 (cd /tmp; export TMPDIR=/tmp; cd - > /dev/null; timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/demo2_prof -o demo2 --output-format csv -- python examples/demo2_deform.py --iters 100 --quiet > $out/${tag}_demo2_traced.log 2>&1)
 cp $(find gpurun_out/demo2_prof -name "*kernel_stats.csv" | head -1) $out/${tag}_demo2_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/demo2_prof $out/${tag}_demo2_traced.log
