@@ -179,7 +179,8 @@ int jr_flatten_loss(jr_ctx* ctx, const int32_t* v0s, const int32_t* v1s, const i
  *       u = sigmoid(log(|t| / (1 - |t|)) + displace) * sign(t);  c = tanh(center);  v = relu(u)(1 - c) - relu(-u)(c + 1) + c
  * jr_deform_vertices_backward  its VJP for the upstream gradient w0*grad0 + w1*grad1 + w2*grad2 (each [NV,3]; grad1 / grad2
  *     may be NULL: the silhouette term and the two regularisers of demo2-deform.py:85-88 are combined here) ->
- *     grad_displace [NV,3], grad_center [3] (a deterministic two-stage sum over the vertices).
+ *     grad_displace [NV,3], grad_center [3] (a two-stage sum over the vertices: double partial sums per workgroup, added with double
+ *     atomics - independent of the order to the float rounding of the result, not bit-deterministic).
  * jr_adam_step   one step of nn.Adam (demo2-deform.py:72) on n floats, in place on param / m / v (m, v start at zero);
  *     step counts from 1; scalars are doubles like the Python floats of the host mirror (jrender_amd/optim.py), which
  *     this kernel reproduces operation by operation:  p -= (lr / (1 - b0^t)) m / (sqrt(v / (1 - b1^t)) + eps).

@@ -81,6 +81,7 @@ struct jr_ctx {
     double* red_acc = nullptr;
     unsigned* red_ticket = nullptr;
     size_t red_cap = 0;
+    bool red_dirty = false;                 // a launch that uses the scratch was issued and not yet known to have been accepted: its tickets may be left non-zero
     // optional per-phase HIP-event timing (jr_profile_*): pairs of events bracketing each phase
     bool prof_on = false;
     std::vector<hipEvent_t> prof_events;     // pool, reused after every collect
@@ -250,6 +251,24 @@ jr::RasterParams make_params(const jr_ctx* ctx, int B, int NF, int T, int IS, in
 }
 
 // Per-face records, bin counts and launch order for this geometry (all the backward needs).
+// The two-stage sums (loss_kernels.hip, optim_kernels.hip) assume their accumulators and tickets are zero when a launch starts and leave them
+// zero when it ends.  A launch the runtime refused (or whose status was never read because an error returned early) may not have: the next
+// user of the scratch clears it first instead of publishing early / never.
+int begin_reduction(jr_ctx* ctx, size_t n) {
+    if (ensure_reduction_scratch(ctx, n)) return 1;
+    if (ctx->red_dirty) {
+        JR_HIP(hipMemsetAsync(ctx->red_acc, 0, sizeof(double) * ctx->red_cap, ctx->stream));
+        JR_HIP(hipMemsetAsync(ctx->red_ticket, 0, sizeof(unsigned) * ctx->red_cap, ctx->stream));
+    }
+    ctx->red_dirty = true;
+    return 0;
+}
+int end_reduction(jr_ctx* ctx) {
+    JR_HIP(hipGetLastError());
+    ctx->red_dirty = false;
+    return 0;
+}
+
 int setup_faces(jr_ctx* ctx, const jr::RasterParams& p, const float* faces, const float* textures,
                 float* faces_info) {
     const size_t nfaces = (size_t)p.B * p.NF, nbins = (size_t)p.B * p.bins_x * p.bins_y;
@@ -769,24 +788,24 @@ int jr_laplacian_loss(jr_ctx* ctx, const int32_t* rowptr, const int32_t* col, co
     if (!ctx || !rowptr || !col || !val || !vertices || !scratch || !loss) return fail("jr_laplacian_loss: NULL argument");
     if (grad_vertices && (!rowptr_t || !col_t || !val_t)) return fail("jr_laplacian_loss: the gradient needs the transposed matrix");
     if (B < 1 || NV < 1) return fail("jr_laplacian_loss: bad sizes");
+    if (B > 65535) return fail("jr_laplacian_loss: at most 65 535 meshes per call (the batch is the launch grid's second dimension), got %d", B);
     JR_HIP(hipSetDevice(ctx->device));
-    if (ensure_reduction_scratch(ctx, (size_t)B)) return 1;
+    if (begin_reduction(ctx, (size_t)B)) return 1;
     jr::launch_laplacian_loss(ctx->stream, rowptr, col, val, rowptr_t, col_t, val_t, vertices, scratch, loss, grad_vertices,
                               ctx->red_acc + 4, ctx->red_ticket + 4, B, NV, grad_scale);
-    JR_HIP(hipGetLastError());
-    return 0;
+    return end_reduction(ctx);
 }
 int jr_flatten_loss(jr_ctx* ctx, const int32_t* v0s, const int32_t* v1s, const int32_t* v2s, const int32_t* v3s,
                     const float* vertices, float* loss, float* grad_vertices, int B, int NV, int NE, float eps,
                     float grad_scale) {
     if (!ctx || !v0s || !v1s || !v2s || !v3s || !vertices || !loss) return fail("jr_flatten_loss: NULL argument");
     if (B < 1 || NV < 1 || NE < 0) return fail("jr_flatten_loss: bad sizes");
+    if (B > 65535) return fail("jr_flatten_loss: at most 65 535 meshes per call (the batch is the launch grid's second dimension), got %d", B);
     JR_HIP(hipSetDevice(ctx->device));
-    if (ensure_reduction_scratch(ctx, (size_t)B)) return 1;
+    if (begin_reduction(ctx, (size_t)B)) return 1;
     jr::launch_flatten_loss(ctx->stream, v0s, v1s, v2s, v3s, vertices, loss, grad_vertices, ctx->red_acc + 4,
                             ctx->red_ticket + 4, B, NV, NE, eps, grad_scale);
-    JR_HIP(hipGetLastError());
-    return 0;
+    return end_reduction(ctx);
 }
 
 int jr_deform_vertices_forward(jr_ctx* ctx, const float* template_vertices, const float* displace, const float* center,
@@ -805,11 +824,10 @@ int jr_deform_vertices_backward(jr_ctx* ctx, const float* template_vertices, con
         return fail("jr_deform_vertices_backward: NULL argument");
     if (NV < 1 || NV > (1 << 28)) return fail("jr_deform_vertices_backward: bad vertex count %d", NV);
     JR_HIP(hipSetDevice(ctx->device));
-    if (ensure_reduction_scratch(ctx, 0)) return 1;
+    if (begin_reduction(ctx, 0)) return 1;
     jr::launch_deform_backward(ctx->stream, template_vertices, displace, center, grad0, w0, grad1, w1, grad2, w2,
                                grad_displace, grad_center, ctx->red_acc, ctx->red_ticket, NV);
-    JR_HIP(hipGetLastError());
-    return 0;
+    return end_reduction(ctx);
 }
 int jr_adam_step(jr_ctx* ctx, float* param, const float* grad, float* m, float* v, size_t n, double lr, double beta0,
                  double beta1, double eps, double weight_decay, int step) {
