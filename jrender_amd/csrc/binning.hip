@@ -48,8 +48,11 @@ __device__ inline void pixel_range(float vlo, float vhi, int is, int& lo, int& h
 }
 
 // Wave-aggregated counter bump: lanes that target the same bin form a group (ballot match against the
-// first pending lane; after four rounds the stragglers - unrelated faces, e.g. a triangle soup - are groups of
-// one), the group's first lane adds the group size, every member gets base + its rank.  The matching is ALU only
+// first pending lane, up to 16 rounds; when three rounds have found groups of one the rest - unrelated faces, e.g. a
+// triangle soup - are taken as groups of one too), the group's first lane adds the group size, every member gets base + its rank.
+// Round 6: 16 rounds instead of 4.  The counters are device-scope atomics that every XCD reaches, and they - not the 328 B of
+// stores per face - were what k_face_setup and k_bin_fill waited for: 64 consecutive faces of a mesh fall into ~10 - 20 bins, four
+// rounds left 40+ lanes bumping a counter each (headline batch: k_face_setup 52 -> 28 us, k_bin_fill 37 -> 14 us; a round is ~10 ALU instructions).  The matching is ALU only
 // and ALL leaders add in ONE atomic instruction: one memory round trip per call (round 3; it was one per group,
 // and a single view's k_bin_fill - 610 wavefronts, nothing to hide latency behind - was a chain of ~16 of them).
 // -> rank of this lane inside its group, the group's first lane and its size (ALU only)
@@ -58,10 +61,13 @@ __device__ inline void wave_bin_match(int tb, int& leader, int& rank, int& cnt) 
     rank = 0; leader = lane; cnt = 1;
     int key = tb;
     unsigned long long todo = ballot(tb >= 0);
-    for (int round = 0; todo != 0 && round < 4; round++) {
+    int singles = 0;                      // (wave-uniform)
+    for (int round = 0; todo != 0 && round < JR_TUNE_BIN_MATCH_ROUNDS; round++) {
         const int l = __builtin_ctzll(todo);
         const int lb = __builtin_amdgcn_readlane(key, l);
         const unsigned long long same = ballot(key == lb);
+        singles += (same & (same - 1ull)) == 0ull;
+        if (round >= 3 && singles >= 3) break;       // unrelated faces: further rounds would find groups of one as well
         if (key == lb) {
             rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
             leader = l;
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     float info[27];
     face_setup(f, info);
     if (tune::profile_sections) { asm volatile("" :: "v"(info[0]), "v"(info[8]), "v"(info[17])); clk.lap(0); }
-    if (faces_info) {   // nullptr when the backward only rebuilds the lists
+    if (faces_info && !(JR_TUNE_DIAG & 4096)) {   // nullptr when the backward only rebuilds the lists  (diagnostic bits 12 - 15, WRONG results: what do the faces_info stores / the record stores / the bin counts / the pixel ranges cost k_face_setup?)
 #pragma unroll
         for (int k = 0; k < 27; k++) s_out[threadIdx.x * 27 + k] = info[k];
         setup_sync();
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     }
     *reinterpret_cast<FaceGeo*>(&s_out[threadIdx.x * 44]) = g;
     setup_sync();
-    {
+    if (!(JR_TUNE_DIAG & 8192)) {
         float4* out = reinterpret_cast<float4*>(geo + i0);
         for (int q = threadIdx.x; q < nvalid * 11; q += SETUP_WG) out[q] = reinterpret_cast<const float4*>(s_out)[q];
     }
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     pixel_range(g.ylo, g.yhi, p.IS, py0, py1);   // in "yi" space (yi = IS-1-row)
     ushort4 rect = make_ushort4(1, 0, 1, 0);     // empty: x0 > x1
     int bx0 = 0, nbx = 0, by0 = 0, nb = 0;
+    if ((JR_TUNE_DIAG & 32768)) { px0 = 1; px1 = 0; asm volatile("" :: "v"(g.xlo), "v"(g.yhi)); }
     if (valid && px0 <= px1 && py0 <= py1) {
         const int row0 = p.IS - 1 - py1, row1 = p.IS - 1 - py0;
         rect = make_ushort4((unsigned short)px0, (unsigned short)px1, (unsigned short)row0,
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(SETUP_WG) void k_face_setup(RasterParams p, const f
     clk.lap(3);
     const int bb = (ic / p.NF) * p.bins_x * p.bins_y;
     int cx = 0, cy = 0;
+    if (JR_TUNE_DIAG & 16384) nb = 0;
     for (int it = 0; ballot(it < nb) != 0; it++) {
         const int tb = it < nb ? bb + (by0 + cy) * p.bins_x + bx0 + cx : -1;
         wave_bin_add<false>(bin_count, tb);

@@ -129,6 +129,9 @@
                                  // execute in order) instead of __syncthreads(), whose workgroup-scope fence waits for every outstanding store / atomic (vmcnt(0))
 #define JR_TUNE_LIGHT_SYNC 1
 #endif
+#ifndef JR_TUNE_BIN_MATCH_ROUNDS  // wave_bin_match: ballot-matching rounds before the remaining lanes bump their counters one by one (4 = rounds 3 - 5)
+#define JR_TUNE_BIN_MATCH_ROUNDS 16
+#endif
 #ifndef JR_TUNE_SETUP_WG         // k_face_setup: faces per workgroup (64 = one wavefront, LDS hand-overs without __syncthreads(); 128 = rounds 1 - 5)
 #define JR_TUNE_SETUP_WG 64
 #endif

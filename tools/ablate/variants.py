@@ -65,6 +65,8 @@ VARIANTS = {
     "heavy_sync": ["JR_TUNE_LIGHT_SYNC=0"],                 # round 6: __syncthreads() (workgroup-scope fence: vmcnt(0)) for the LDS hand-overs of the one-wavefront raster kernels
     "setup128": ["JR_TUNE_SETUP_WG=128"],                   # round 6: k_face_setup with 128-face workgroups and __syncthreads() (rounds 1 - 5)
     "diag_noempty": ["JR_TUNE_DIAG=2048"],                  # WRONG images: the headline forward without the empty bins' output stores (what do they cost the launch?)
+    "match4": ["JR_TUNE_BIN_MATCH_ROUNDS=4"], "match8": ["JR_TUNE_BIN_MATCH_ROUNDS=8"], "match32": ["JR_TUNE_BIN_MATCH_ROUNDS=32"], "match64": ["JR_TUNE_BIN_MATCH_ROUNDS=64"],   # round 6 calls 16 / 17: ballot-matching rounds of wave_bin_match (product 16; rounds 3 - 5: 4) - fewer device-scope atomics
+    "sd_noinfo": ["JR_TUNE_DIAG=4096"], "sd_nogeo": ["JR_TUNE_DIAG=8192"], "sd_nocount": ["JR_TUNE_DIAG=16384"], "sd_norange": ["JR_TUNE_DIAG=49152"], "sd_compute": ["JR_TUNE_DIAG=61440"],   # WRONG results: cost probes of k_face_setup (round 6 call 15)
     "bwd_sorted": ["JR_TUNE_BWD_HASH_UNION=0"],             # round 6: the backward's face union by per-lane sort + min-extraction (rounds 2 - 5) instead of the LDS hash table
     "no_heavy_pipe": ["JR_TUNE_FWD_HEAVY_PIPE=0"],           # round 3: heavy tiles with the passes in sequence (tile_heavy) instead of the pipeline
     "pipe_ct2": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=2"], "pipe_ct0": ["JR_TUNE_FWD_PIPE_CONSUMER_TASKS=0"],   # round 3: the K-buffer wavefront / both applying wavefronts take no evaluate tasks
