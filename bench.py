@@ -48,18 +48,31 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def csrc_hash():
+def csrc_hash(root=None):
     """Content hash of the kernel sources the running library was built from (jrender_amd/csrc/*.hip|*.h|*.cpp).  The
     PMC figures attached to `roofline` (profiles/traffic_latest.json, valu_latest.json) carry the hash of the sources they
     were collected on (tools/pmc_to_json.py): a mismatch prints `profile_stale: true` instead of passing old counters off
     as the shipped kernels'.  (A hash of file contents, not a git object: the GPU box has no .git.)"""
     import hashlib
-    d = os.path.join(ROOT, "jrender_amd", "csrc")
+    d = os.path.join(root or ROOT, "jrender_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h", ".cpp")):
             h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
     return h.hexdigest()[:16]
+
+
+def profile_staleness(traffic_json, valu_json, isa_json, here):
+    """(profile_stale, profiled_kernels_device_code_unchanged) of the bench line.  The counters' stamp covers ALL kernel sources:
+    any edit makes them stale.  When only another translation unit changed since they were taken, tools/isa_same.py (CPU,
+    reproducible) has compiled every unit of both trees to gfx950 assembly and compared; its record counts only if it is about
+    exactly these two source states.  The second value is None when there is nothing to say (fresh counters, or no such record)."""
+    stale = not (traffic_json.get("csrc_hash") == here and valu_json.get("csrc_hash") == here)
+    same = None
+    if (stale and isa_json and isa_json.get("new_csrc_hash") == here
+            and isa_json.get("old_csrc_hash") == traffic_json.get("csrc_hash") == valu_json.get("csrc_hash")):
+        same = all((isa_json.get("units") or {}).get(u, {}).get("same") is True for u in ("softras_forward.hip", "softras_backward.hip"))
+    return stale, same
 
 
 def algorithmic_bytes(B, NF, T, IS, K):
@@ -503,8 +516,9 @@ def bench_softras(args, ctx, comm, rank, world):
     valu = dict(vj.get(dom) or {}) if profiled and vj.get(dom) else None
     here = csrc_hash()
     profile_stale = None
+    kernels_same = None
     if profiled:
-        profile_stale = not (tj.get("csrc_hash") == here and vj.get("csrc_hash") == here)
+        profile_stale, kernels_same = profile_staleness(tj, vj, load_json("isa_same_latest.json"), here)
     if valu and per_launch[dom] > 0:
         # issue-slot occupancy against THIS run's launch time (the counters are per launch; the duration is measured live):
         # VALU wavefront-instructions x the mean issue cost of the kernel's opcode mix / (SIMDs x cycles), see tools/pmc_to_json.py
@@ -572,7 +586,7 @@ def bench_softras(args, ctx, comm, rank, world):
                                % (args.steps, bracketed_ms),
                      "step_frac": ab["step"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "hbm_read_frac": ab["read"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "valu": valu, "valu_bwd": valu_bwd, "valu_fwd_floor": valu_fwd, "profile_stale": profile_stale, "csrc_hash": here,
+                     "valu": valu, "valu_bwd": valu_bwd, "valu_fwd_floor": valu_fwd, "profile_stale": profile_stale, "profiled_kernels_device_code_unchanged": kernels_same, "csrc_hash": here,
                      "profile_csrc_hash": tj.get("csrc_hash") if profiled else None},
         "phase_ms_per_step": {k: v[0] / args.steps for k, v in phases.items()},
         "exchange": {"kind": exchange, "backend": backend, "ms_per_step": percentiles(ex_ms)["median"] if ex_ms else 0.0},

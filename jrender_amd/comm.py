@@ -403,7 +403,9 @@ def _rccl_with_one_retry(ctx, rank, world):
     HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; with the legacy mode it fails with `hipIpcGetMemHandle: invalid argument`); a node
     whose driver wants the other mode fails the same way with the value this launch exported.  The HSA runtime reads the
     variable once, at start-up, so the retry is a re-exec of this rank (same argv, JRENDER_IPC_RETRY=1, its own rendezvous
-    files).  ncclCommInitRank is collective: when it fails, it fails on every rank, and every rank takes this path."""
+    files).  ncclCommInitRank is collective: when it fails, it fails on every rank, and every rank takes this path.
+    JRENDER_IPC_RETRY_MODE pins the second attempt's mode ("0" / "1") or switches it off ("off"): an operator who knows that one of the
+    two modes takes a node of their pool down keeps the diagnostic and the second attempt without the toggle."""
     import sys
     try:
         if os.environ.get("JRENDER_FAIL_COMM_INIT_ONCE") and not os.environ.get("JRENDER_IPC_RETRY"):     # (tests: the retry path on one GPU)
@@ -421,7 +423,11 @@ def _rccl_with_one_retry(ctx, rank, world):
         if os.environ.get("JRENDER_IPC_RETRY"):
             sys.stderr.write("jrender_amd.comm: this was the second attempt (IPC mode toggled): giving up\n")
             raise
-        env = dict(os.environ, JRENDER_IPC_RETRY="1", HSA_ENABLE_IPC_MODE_LEGACY="1" if mode == "0" else "0")
+        pinned = os.environ.get("JRENDER_IPC_RETRY_MODE")       # "0" / "1": the mode of the second attempt, whatever the first one ran with; "off": no second attempt
+        if pinned == "off":
+            sys.stderr.write("jrender_amd.comm: JRENDER_IPC_RETRY_MODE=off: no second attempt\n")
+            raise
+        env = dict(os.environ, JRENDER_IPC_RETRY="1", HSA_ENABLE_IPC_MODE_LEGACY=pinned if pinned in ("0", "1") else ("1" if mode == "0" else "0"))
         sys.stderr.write("jrender_amd.comm: retrying ONCE with HSA_ENABLE_IPC_MODE_LEGACY=%s (re-exec of this rank)\n" % env["HSA_ENABLE_IPC_MODE_LEGACY"])
         sys.stderr.flush(); sys.stdout.flush()
         os.execve(sys.executable, list(getattr(sys, "orig_argv", [sys.executable] + sys.argv)), env)

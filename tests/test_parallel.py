@@ -164,6 +164,64 @@ def test_rendezvous_path_from_env(monkeypatch):
     assert "1234" in jcomm.rendezvous_path() and str(os.getppid()) in jcomm.rendezvous_path()
 
 
+@pytest.mark.parametrize("first,pinned,second", [("0", None, "1"), ("1", None, "0"), (None, None, "0"), ("0", "0", "0"), ("0", "1", "1"), ("0", "off", None)])
+def test_comm_init_retry_environment(monkeypatch, capsys, first, pinned, second):
+    """VERDICT r5 next #7 on the CPU: what a rank does when ncclCommInitRank fails - the diagnostic, then ONE re-exec of the same
+    command line with JRENDER_IPC_RETRY=1 and HSA_ENABLE_IPC_MODE_LEGACY toggled (or pinned by JRENDER_IPC_RETRY_MODE, or none when
+    that says off); a failure of the second attempt is final.  os.execve and the communicator are stand-ins here; the real re-exec
+    with a real one-rank RCCL communicator is tests/test_gpu_comm.py."""
+    from jrender_amd import comm as jcomm, _ffi
+
+    class Ctx:
+        device = 0
+    calls = []
+
+    def fail(ctx, rank, world):
+        raise RuntimeError("ncclCommInitRank(rank %d of %d) failed: unhandled system error" % (rank, world))
+
+    class Exec(Exception):
+        pass
+
+    def execve(exe, argv, env):
+        calls.append((exe, argv, env))
+        raise Exec()
+    monkeypatch.setattr(jcomm, "RcclCommunicator", fail)
+    monkeypatch.setattr(_ffi, "device_count", lambda: 8)
+    monkeypatch.setattr(os, "execve", execve)
+    for k, v in (("HSA_ENABLE_IPC_MODE_LEGACY", first), ("JRENDER_IPC_RETRY_MODE", pinned), ("JRENDER_IPC_RETRY", None), ("JRENDER_FAIL_COMM_INIT_ONCE", None)):
+        monkeypatch.delenv(k, raising=False) if v is None else monkeypatch.setenv(k, v)
+    if second is None:
+        with pytest.raises(RuntimeError, match="ncclCommInitRank"):
+            jcomm._rccl_with_one_retry(Ctx(), 3, 8)
+        assert not calls and "no second attempt" in capsys.readouterr().err
+        return
+    with pytest.raises(Exec):
+        jcomm._rccl_with_one_retry(Ctx(), 3, 8)
+    err = capsys.readouterr().err
+    assert "rank 3 of 8" in err and "ncclCommInitRank" in err and "HSA_ENABLE_IPC_MODE_LEGACY=%s" % first in err
+    assert "retrying ONCE with HSA_ENABLE_IPC_MODE_LEGACY=%s" % second in err
+    (exe, argv, env), = calls
+    assert exe == sys.executable and env["JRENDER_IPC_RETRY"] == "1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == second
+    assert argv[0] == sys.executable or os.path.basename(argv[0]).startswith("python")
+    # the second attempt: its own rendezvous files, and a failure is final
+    monkeypatch.setenv("JRENDER_IPC_RETRY", "1")
+    monkeypatch.setenv("MASTER_PORT", "4321")
+    assert jcomm.rendezvous_path().endswith(".retry")
+    del calls[:]
+    with pytest.raises(RuntimeError, match="ncclCommInitRank"):
+        jcomm._rccl_with_one_retry(Ctx(), 3, 8)
+    assert not calls and "giving up" in capsys.readouterr().err
+    # any other error is not this path's business
+    monkeypatch.delenv("JRENDER_IPC_RETRY")
+
+    def other(ctx, rank, world):
+        raise RuntimeError("hipMalloc failed")
+    monkeypatch.setattr(jcomm, "RcclCommunicator", other)
+    with pytest.raises(RuntimeError, match="hipMalloc"):
+        jcomm._rccl_with_one_retry(Ctx(), 0, 2)
+    assert not calls
+
+
 def test_bench_launcher_reports_a_dead_rank_instead_of_hanging():
     """VERDICT r2 (weak 8): `bench.py --gpus N` used to block on rank 0's pipe; a rank that died before the
     communicator was up left the launcher (and the driver's 1800 s timeout) waiting.  Now every child is polled: a rank

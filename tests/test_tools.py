@@ -47,6 +47,37 @@ def test_profile_jsons_feed_the_bench_line():
     assert valu["csrc_hash"] == traffic["csrc_hash"] == n3["csrc_hash"]
 
 
+def test_stale_counters_are_accounted_for():
+    """bench.py's `roofline.profile_stale` / `.profiled_kernels_device_code_unchanged`: counters taken on other kernel sources than the
+    shipped ones are flagged, and the flag is only softened by a tools/isa_same.py record about exactly these two source states that
+    found the forward's and the backward's device code identical.  If the committed counters ARE stale, such a record must exist."""
+    import bench
+    valu = json.load(open(os.path.join(ROOT, "profiles", "valu_latest.json")))
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    here = bench.csrc_hash()
+    iso_path = os.path.join(ROOT, "profiles", "isa_same_latest.json")
+    iso = json.load(open(iso_path)) if os.path.exists(iso_path) else None
+    stale, same = bench.profile_staleness(traffic, valu, iso, here)
+    if stale:
+        assert same is True, "profiles/*_latest.json were collected on other kernel sources and no tools/isa_same.py record covers the difference"
+        assert iso["units"]["binning.hip"]["same"] is False or any(not u["same"] for u in iso["units"].values())       # (something did change)
+    else:
+        assert same is None
+    # the rule itself
+    t, v = {"csrc_hash": "aaa"}, {"csrc_hash": "aaa"}
+    rec = {"old_csrc_hash": "aaa", "new_csrc_hash": "bbb", "units": {"softras_forward.hip": {"same": True}, "softras_backward.hip": {"same": True}, "binning.hip": {"same": False}}}
+    assert bench.profile_staleness(t, v, None, "aaa") == (False, None)
+    assert bench.profile_staleness(t, v, rec, "aaa") == (False, None)
+    assert bench.profile_staleness(t, v, None, "bbb") == (True, None)
+    assert bench.profile_staleness(t, v, rec, "bbb") == (True, True)
+    assert bench.profile_staleness(t, v, rec, "ccc") == (True, None)                    # a record about other sources says nothing
+    assert bench.profile_staleness(t, {"csrc_hash": "zzz"}, rec, "bbb") == (True, None)
+    rec["units"]["softras_backward.hip"]["same"] = False
+    assert bench.profile_staleness(t, v, rec, "bbb") == (True, False)
+    del rec["units"]["softras_backward.hip"]
+    assert bench.profile_staleness(t, v, rec, "bbb") == (True, False)
+
+
 def test_pipelined_heavy_tile_step_machine_model():
     """tools/sim/heavy_pipe_model.py: wavefront 3's decisions of tile_heavy_pipe (softras_forward.hip) replayed with owner
     tags on every double / triple buffer: each round evaluated once and applied once, in order, no buffer written
