@@ -74,7 +74,9 @@ def have_ref():
 
 def _scalars(kw):
     p = dict(DEFAULTS)
-    unknown = set(kw) - set(p) - {"background_color"}
+    # bin_size / max_elems_per_bin: arguments of the reference operator (SRW:15) that select ITS coarse-to-fine kernels; the bin_size = 0
+    # kernels these oracles restate ignore them (tests/test_oracle_c2f.py: with ascending lists the binned forward gives the same bits)
+    unknown = set(kw) - set(p) - {"background_color", "bin_size", "max_elems_per_bin"}
     if unknown:
         raise TypeError("unknown parameters: %s" % sorted(unknown))
     p.update(kw)
@@ -273,6 +275,45 @@ class Oracle:
         if rc:
             raise RuntimeError("oracle backward_subset failed rc=%d" % rc)
         return gf.reshape(B, NF, 3, 3), gt
+
+
+class C2fOracle:
+    """The reference's COARSE-TO-FINE forward (soft_rasterize_coarse_to_fine.py) compiled for the host, its coarse kernel launched
+    as ONE thread so that every bin list is ascending by face id (oracle/ref_c2f_driver.cpp says why that launch is legal and why it
+    is the only comparable one).  Only exists where oracle/_ref was built.  forward() takes the reference operator's keyword
+    arguments plus bin_size / max_elems_per_bin (SRW:85-90: 0 -> num_faces / 5 as the reference's wrapper does)."""
+
+    def __init__(self, nthreads=0):
+        import importlib
+        path = importlib.import_module(__name__ + ".build_ref").build_c2f()
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("oracle/_ref/libsoftras_c2f_ref.so not built and /root/reference not mounted")
+        self.lib = C.CDLL(path)
+        self.nthreads = int(nthreads)
+
+    def forward(self, face_vertices, textures, bin_size=16, max_elems_per_bin=0, **kw):
+        p, s = _scalars(kw)
+        fv = np.ascontiguousarray(face_vertices, np.float32)
+        B, NF = fv.shape[:2]
+        fv = fv.reshape(B, NF, 9)
+        tex = np.ascontiguousarray(textures, np.float32).reshape(B, NF, -1, 3)
+        T, IS, K = tex.shape[2], int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+        M = int(max_elems_per_bin) if max_elems_per_bin else int(NF / 5)            # SRW:85-90
+        bins = 1 + (IS - 1) // int(bin_size)
+        info = np.empty((B, NF, 27), np.float32)
+        aggr = np.empty((B, 2, IS, IS), np.float32)
+        rgba = np.empty((B, 4, IS, IS), np.float32)
+        ids = np.empty((B, K, IS, IS), np.int32)
+        per_bin = np.empty((B, bins, bins), np.int32)
+        elems = np.empty((B, bins, bins, max(M, 1)), np.int32)
+        rc = self.lib.ref_softras_forward_c2f(_fp(fv), _fp(tex), _fp(info), _fp(aggr), _fp(rgba), _ip(ids),
+                                              B, NF, T, IS, K, s["near"], s["far"], s["eps"], s["sigma"], s["dist"],
+                                              s["dist_eps"], s["gamma"], s["rgb"], s["alpha"], s["tex"], s["ds"],
+                                              int(bin_size), M, _ip(per_bin), _ip(elems), self.nthreads)
+        if rc:
+            raise ValueError("reference coarse-to-fine forward refused the geometry (more than 27 bins per edge, C2F:16-18) rc=%d" % rc)
+        return dict(face_vertices=fv, textures=tex, soft_colors=rgba, faces_info=info, aggrs_info=aggr, faces_id_buffer=ids,
+                    elems_per_bin=per_bin, bin_elems=elems, max_elems_per_bin=M, params=p)
 
 
 class N3mrOracle:

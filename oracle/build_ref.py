@@ -226,6 +226,66 @@ def build(force=False):
     return LIB
 
 
+C2F = os.path.join(REF_ROOT, "jrender/renderer/dr/softras/cuda/soft_rasterize_coarse_to_fine.py")
+C2F_LIB = os.path.join(OUT_DIR, "libsoftras_c2f_ref.so")
+
+
+def _extract_c2f():
+    """`cuda_header` of the reference's coarse-to-fine forward (C2F:21-763) and the bin margin literal it interpolates
+    into the launch (`blur_radius`, C2F:15 -> the third argument of TriangleBoundingBoxKernel in `cuda_src`, C2F:802-805)."""
+    import re
+    captured = []
+    stub = types.ModuleType("jittor")
+
+    def code(shapes, dtypes, inputs, **kw):
+        captured.append(kw)
+        return [_Var(s, d) for s, d in zip(shapes, dtypes)]
+
+    stub.code = code
+    saved = sys.modules.get("jittor")
+    sys.modules["jittor"] = stub
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_c2f", C2F)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        B, NF, T, IS, K = 1, 1, 1, 32, 16
+        fv, tex = _Var((B, NF, 9)), _Var((B, NF, T, 3))
+        info, aggr = _Var((B, NF, 27)), _Var((B, 2, IS, IS))
+        rgba, ids = _Var((B, 4, IS, IS)), _Var((B, K, IS, IS), "int32")
+        mod.forward_soft_rasterize_coarse_to_fine(fv, tex, info, aggr, rgba, ids, IS, 1, 100, 1e-3, 1e-5, 2, 9.21, 1e-4, 1, 2, 0, 1, 16, 64)
+    finally:
+        if saved is None:
+            del sys.modules["jittor"]
+        else:
+            sys.modules["jittor"] = saved
+    header, src = captured[0]["cuda_header"], captured[0]["cuda_src"]
+    m = re.search(r"TriangleBoundingBoxKernel<<<[^>]*>>>\(\s*faces_p,\s*batch_size \* num_faces,\s*([0-9.eE+-]+),", src)
+    if not m:
+        raise RuntimeError("reference coarse-to-fine launch changed; re-check the blur_radius extraction")
+    return header, m.group(1)
+
+
+def build_c2f(force=False):
+    """Build (or reuse) oracle/_ref/libsoftras_c2f_ref.so: the reference's coarse-to-fine forward for the host, its coarse kernel
+    launched as one thread so that the bin lists are ascending (oracle/ref_c2f_driver.cpp).  None when the reference tree is not mounted."""
+    if not os.path.exists(C2F):
+        return C2F_LIB if os.path.exists(C2F_LIB) else None
+    deps = [C2F, os.path.join(HERE, "ref_c2f_driver.cpp"), os.path.join(HERE, "ref_shim/cuda_runtime.h"), os.path.abspath(__file__)]
+    if not force and os.path.exists(C2F_LIB) and os.path.getmtime(C2F_LIB) >= max(os.path.getmtime(d) for d in deps):
+        return C2F_LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    header, blur = _extract_c2f()
+    with open(os.path.join(OUT_DIR, "c2f_fwd.inc"), "w") as f:
+        f.write(header)
+    with open(os.path.join(OUT_DIR, "c2f_params.h"), "w") as f:
+        f.write("#define C2F_BLUR_RADIUS %sf\n" % blur if "." in blur or "e" in blur.lower() else "#define C2F_BLUR_RADIUS %s.f\n" % blur)
+    tmp = tempfile.mktemp(suffix=".so", dir=OUT_DIR)
+    subprocess.check_call(["g++", *CXXFLAGS, "-I", HERE, "-I", os.path.join(HERE, "ref_shim"),
+                           os.path.join(HERE, "ref_c2f_driver.cpp"), "-o", tmp], cwd=HERE)
+    os.replace(tmp, C2F_LIB)
+    return C2F_LIB
+
+
 FMA_LIB = os.path.join(OUT_DIR, "libsoftras_ref_fma.so")
 
 
@@ -252,3 +312,4 @@ if __name__ == "__main__":
     print(build_fma(force="--force" in sys.argv))
     print(build_n3mr(force="--force" in sys.argv))
     print(build_textures(force="--force" in sys.argv))
+    print(build_c2f(force="--force" in sys.argv))

@@ -81,3 +81,14 @@ static inline double atomicAdd(double* addr, double v) {
     { old = *addr; *addr += v; }
     return old;
 }
+
+/* Names the reference's coarse-to-fine kernels use on top of the above (soft_rasterize_coarse_to_fine.py: BitMask over dynamic
+ * shared memory, RasterizeCoarseCudaKernel).  oracle/ref_c2f_driver.cpp launches that kernel as <<<1, 1>>> - a legal launch of its
+ * block- and grid-stride loops in which __syncthreads() has nothing to wait for and the chunks are taken in ascending order. */
+#include <stdint.h>
+#define __shared__
+static inline void __syncthreads() {}
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline unsigned atomicOr(unsigned* addr, unsigned v)  { unsigned old; { old = *addr; *addr |= v; } return old; }
+static inline unsigned atomicAnd(unsigned* addr, unsigned v) { unsigned old; { old = *addr; *addr &= v; } return old; }
+static inline int atomicAdd(int* addr, int v) { int old; { old = *addr; *addr += v; } return old; }

