@@ -4,6 +4,8 @@ import json
 import os
 import re
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -76,6 +78,33 @@ def test_stale_counters_are_accounted_for():
     assert bench.profile_staleness(t, v, rec, "bbb") == (True, False)
     del rec["units"]["softras_backward.hip"]
     assert bench.profile_staleness(t, v, rec, "bbb") == (True, False)
+
+
+def test_counter_bump_model_of_the_list_building_kernels():
+    """tools/sim/bin_atomics.py replays binning.hip's wave_bin_match (lanes of a wavefront that target the same bin share one atomic,
+    one group per ballot-matching round) on the bench's synthetic scenes.  With unlimited rounds a trip issues one atomic per DISTINCT
+    bin; fewer rounds can only add atomics; a mesh's consecutive faces share bins, a soup's do not - the measured times of
+    profiles/r06_c16_match_rounds.txt follow these counts."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bin_atomics", os.path.join(ROOT, "tools", "sim", "bin_atomics.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    from jrender_amd import synthetic as syn
+    rounds = [1, 4, 8, 16, ("adaptive", 16), 64]
+    mesh = m.count(syn.sphere_views(3300, 2)[0], 256, 16, rounds)
+    soup = m.count(syn.triangle_soup(3300, 2, seed=0)[0], 256, 16, rounds)
+    for r in (mesh, soup):
+        a = r["atomics"]
+        assert a[1] >= a[4] >= a[8] >= a[16] >= a[64] and a[("adaptive", 16)] >= a[16] and a[("adaptive", 16)] <= a[4] + r["trips"]
+        assert abs(a[64] - r["mean_distinct_bins_per_trip"] * r["trips"]) < 1e-6 * a[64] + 1      # unlimited rounds: one atomic per distinct bin
+        assert a[1] <= r["pairs"] and a[64] >= r["trips"]
+    assert mesh["atomics"][("adaptive", 16)] < 0.6 * mesh["atomics"][4]               # what round 6 gained on meshes ...
+    assert soup["atomics"][("adaptive", 16)] > 0.95 * soup["atomics"][4] > 0.9 * soup["pairs"]     # ... and could not gain on a soup
+    # the matching itself, on hand-made trips
+    k = np.array([5, 5, 7, 5, 9, 7, 11, 13, 13], np.int64)
+    assert m.atomics_of_a_trip(k, 64) == 5 and m.atomics_of_a_trip(k, 1) == 1 + 6 and m.atomics_of_a_trip(k, 2) == 2 + 4
+    ones = np.arange(40, dtype=np.int64)
+    assert m.atomics_of_a_trip(ones, 16) == 40 and m.atomics_of_a_trip(ones, ("adaptive", 16)) == 40
 
 
 def test_pipelined_heavy_tile_step_machine_model():
