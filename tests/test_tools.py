@@ -80,6 +80,27 @@ def test_stale_counters_are_accounted_for():
     assert bench.profile_staleness(t, v, rec, "bbb") == (True, False)
 
 
+def test_isa_same_tool_on_an_unchanged_unit():
+    """tools/isa_same.py on the smallest translation unit, HEAD against the working tree: the device assembly of an unchanged source
+    must compare SAME although the two compilations run in different directories (the compilation-unit id hipcc derives from the
+    source path is normalised away)."""
+    import shutil
+    import subprocess
+    import sys
+    if not os.path.isdir(os.path.join(ROOT, ".git")) or shutil.which("git") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        import pytest
+        pytest.skip("needs the git checkout and hipcc")
+    if subprocess.run(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "jrender_amd/csrc/loss_kernels.hip", "jrender_amd/csrc/jr_kernels.h",
+                       "jrender_amd/csrc/jr_tuning.h", "include/jrender_hip.h"]).returncode != 0:
+        import pytest
+        pytest.skip("the unit or its headers differ from HEAD in the working tree")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_same.py"), "HEAD", "loss_kernels.hip"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["units"]["loss_kernels.hip"]["same"] is True and rec["units"]["loss_kernels.hip"]["asm_lines"] > 500
+    assert rec["old_csrc_hash"] and rec["new_csrc_hash"]
+
+
 def test_counter_bump_model_of_the_list_building_kernels():
     """tools/sim/bin_atomics.py replays binning.hip's wave_bin_match (lanes of a wavefront that target the same bin share one atomic,
     one group per ballot-matching round) on the bench's synthetic scenes.  With unlimited rounds a trip issues one atomic per DISTINCT
