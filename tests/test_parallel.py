@@ -222,6 +222,34 @@ def test_comm_init_retry_environment(monkeypatch, capsys, first, pinned, second)
     assert not calls
 
 
+def test_rendezvous_under_the_driver_s_launcher():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port P <script>` - the command
+    line the driver uses for bench.py at N > 1 - around tests/_torchrun_rendezvous_worker.py: the real unique-id rendezvous of
+    RcclCommunicator (stand-ins only for the jr_comm_* calls, there is no GPU here) and the host communicator.  Every rank must read
+    the id rank 0 published, under a prefix all workers of this launch derive alike (agent pid, MASTER_PORT, run id), and the id file must
+    be gone after the collective create."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "JRENDER_RDZV", "JRENDER_IPC_RETRY", "MASTER_PORT", "MASTER_ADDR")}
+    import tempfile
+    short = tempfile.mkdtemp(prefix="jr", dir="/tmp")              # (pytest's tmp_path is too long for the host communicator's AF_UNIX socket: 108 bytes)
+    env["TMPDIR"] = short
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "tests", "_torchrun_rendezvous_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    recs = [json.loads(l[len("WORKER "):]) for l in out.stdout.splitlines() if l.startswith("WORKER ")]
+    assert sorted(r["rank"] for r in recs) == [0, 1, 2] and all(r["world"] == 3 and r["local_rank"] == r["rank"] for r in recs)
+    assert len({r["id_sha256"] for r in recs}) == 1 and len({r["prefix"] for r in recs}) == 1 and len({r["ppid"] for r in recs}) == 1
+    assert str(port) in recs[0]["prefix"] and str(recs[0]["ppid"]) in recs[0]["prefix"] and recs[0]["prefix"].startswith(short)
+    assert all(r["sum"] == [6.0] * 5 and r["max"] == 2.0 and r["gathered"] == [[0.0] * 3, [1.0] * 3, [2.0] * 3] for r in recs)
+    assert not any(r["id_file_left"] for r in recs)
+    import shutil
+    shutil.rmtree(short, ignore_errors=True)
+
+
 def test_bench_launcher_reports_a_dead_rank_instead_of_hanging():
     """VERDICT r2 (weak 8): `bench.py --gpus N` used to block on rank 0's pipe; a rank that died before the
     communicator was up left the launcher (and the driver's 1800 s timeout) waiting.  Now every child is polled: a rank
