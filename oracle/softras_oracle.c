@@ -152,7 +152,7 @@ static void euclid(float* sign, float* dx, float* dy, const float* w, float* t,
 }
 
 #ifdef ORC_EXPERIMENT_FAST_D
-/* EXPERIMENT ONLY (tools/fast_d_probe.py builds a separate library with -DORC_EXPERIMENT_FAST_D -mfma; the oracle proper never
+/* EXPERIMENT ONLY (tests/probe_fast_distance.py builds a separate library with -DORC_EXPERIMENT_FAST_D -mfma; the oracle proper never
  * defines it).  VERDICT r5 "next" #2 asks what a FAST distance for OUTSIDE pairs would cost in parity: the same expression tree as
  * euclid()'s outside branch with floating-point contraction on (FMA) and the quotient taken as a product with a float reciprocal -
  * what a `v_rcp_f32` + `v_fma_f32` path on the GPU would compute.  The cull DECISION stays on the exact distance; only the

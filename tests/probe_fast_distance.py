@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CPU experiment for VERDICT r5 "next" #2 (a guard-band FAST distance in the forward): what would it cost in parity?
 
-    python tools/fast_d_probe.py [--faces 39000] [--image-size 1024] [--sigma 1e-5] [--guard 1e-3]        (~ 5 minutes on 8 cores)
+    python tests/probe_fast_distance.py [--faces 39000] [--image-size 1024] [--sigma 1e-5] [--guard 1e-3]        (~ 5 minutes on 8 cores)
 
 The proposal: for OUTSIDE pairs compute the squared distance on a contracted / reciprocal fast path, take the cull decision from it
 unless it lies in a guard band around the threshold (then fall back to the exact tree), and let the coverage D of the survivors come
