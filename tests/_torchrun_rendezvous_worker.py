@@ -72,7 +72,8 @@ def main():
     rec["id_file_left"] = os.path.exists(prefix + ".id")
     h.barrier()
     h.close()
-    print("WORKER " + json.dumps(rec), flush=True)
+    sys.stdout.flush()
+    os.write(1, ("WORKER " + json.dumps(rec) + "\n").encode())        # ONE write: three workers share the agent's stdout pipe
 
 
 if __name__ == "__main__":

@@ -241,6 +241,7 @@ def test_rendezvous_under_the_driver_s_launcher():
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     recs = [json.loads(l[len("WORKER "):]) for l in out.stdout.splitlines() if l.startswith("WORKER ")]
+    assert len(recs) == 3, out.stdout[-2000:]
     assert sorted(r["rank"] for r in recs) == [0, 1, 2] and all(r["world"] == 3 and r["local_rank"] == r["rank"] for r in recs)
     assert len({r["id_sha256"] for r in recs}) == 1 and len({r["prefix"] for r in recs}) == 1 and len({r["ppid"] for r in recs}) == 1
     assert str(port) in recs[0]["prefix"] and str(recs[0]["ppid"]) in recs[0]["prefix"] and recs[0]["prefix"].startswith(short)
