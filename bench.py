@@ -730,6 +730,11 @@ def main():
     if ndev < local_world and not args.allow_shared_gpus:
         sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible - an N-rank line must mean N GPUs "
                  "(--allow-shared-gpus runs the plumbing over the host communicator instead)" % (local_world, ndev))
+    if world > 1 and rank != 0:
+        # under an external launcher every rank shares ONE stdout: only rank 0 may write there (the JSON line); what the others or
+        # their libraries print (RCCL's start-up banner) goes to stderr
+        sys.stdout.flush()
+        os.dup2(2, 1)
     ctx = _ffi.Context(local_rank % ndev)       # --allow-shared-gpus: plumbing run, ranks share GPUs (host communicator)
     comm = jcomm.init_from_env(ctx)
     try:
