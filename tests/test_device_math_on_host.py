@@ -1,0 +1,134 @@
+"""The HIP kernels' per-pair arithmetic, compiled for the HOST and compared with the oracle pair by pair (CPU only).
+
+jrender_amd/csrc/softras_device.h holds what the raster kernels compute per (pixel, face): face set-up, the packed record, barycentrics,
+the distance tree, clipping, depth, texel choice, coverage.  tests/host_math/ compiles that very header with g++ under a 30-line shim
+(no code of it is restated) and tests/host_math/harness.cpp runs every face against every pixel centre of its widened box, next to the
+oracle's own functions: the bit-critical quantities - everything the face-index buffer depends on - must be THE SAME BITS, in the plain
+IEEE instantiation and in the reciprocal-refinement one the kernels run on well-conditioned faces.  The GPU suite shows this through
+whole kernels; here it holds without a GPU, on millions of pairs per second, and under AddressSanitizer + UBSan (this pool has no GPU
+sanitizer).  Not comparable on the host and not compared: paths built on the device's approximate v_rcp_f32 / v_exp_f32 (the default
+colour path; the inside pairs' second and third projection outside 'hard' alpha)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from jrender_amd import synthetic as syn
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_math")
+NAMES = ["pairs", "ub_skipped", "unsafe_faces", "faces_info", "border", "w", "sign", "dis_ieee", "dis_refined", "bary_dist", "w_clip",
+         "zp_ieee", "zp_refined", "coverage_ref_form", "texel", "split_vs_joint", "bwd_vs_fwd_form", "cull_decision"]
+MISMATCH = NAMES[3:]
+FLAGS = ["-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-w"]            # the device build's floating-point flags (jrender_amd/_build.py)
+DIST_EPS_LOG = float(np.float32(np.log(1.0 / 1e-4 - 1.0)))                    # SRW:25
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+
+
+def build(out_dir, extra=(), exe=False):
+    objs = []
+    for src, cc, std in (("oracle_wrap.c", "gcc", "-std=gnu11"), ("harness.cpp", "g++", "-std=c++17")) + ((("main.cpp", "g++", "-std=c++17"),) if exe else ()):
+        o = os.path.join(out_dir, src + ".o")
+        subprocess.check_call([cc, std, *FLAGS, *extra, "-I", os.path.join(HERE, "shim"), "-c", os.path.join(HERE, src), "-o", o])
+        objs.append(o)
+    out = os.path.join(out_dir, "hm_main" if exe else "libhm.so")
+    subprocess.check_call(["g++", *(() if exe else ("-shared",)), *extra, *objs, "-o", out, "-lm"])
+    return out
+
+
+@pytest.fixture(scope="module")
+def workdir():
+    d = tempfile.mkdtemp(prefix="jr_hm_")
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.fixture(scope="module")
+def lib(workdir):
+    return C.CDLL(build(workdir))
+
+
+def compare(lib, faces, IS, sigma=1e-5, max_px=48):
+    f = np.ascontiguousarray(np.asarray(faces, np.float32).reshape(-1, 9))
+    cnt = (C.c_long * 24)()
+    lib.hm_compare(f.ctypes.data_as(C.POINTER(C.c_float)), C.c_long(f.shape[0]), int(IS), C.c_float(sigma), C.c_float(DIST_EPS_LOG), int(max_px), cnt)
+    return dict(zip(NAMES, list(cnt)[:len(NAMES)]))
+
+
+def hostile_faces(n, seed):
+    """slivers, zero-area faces, repeated vertices, coordinates far outside the screen (records that are not FLAG_SAFE), depths from
+    1e-3 to 1e3, a few NaN / inf coordinates - the inputs the kernels route through their plain IEEE instantiation"""
+    rng = np.random.default_rng(seed)
+    f = np.empty((n, 3, 3), np.float32)
+    c = rng.uniform(-0.9, 0.9, (n, 1, 2))
+    f[:, :, :2] = c + rng.uniform(-0.05, 0.05, (n, 3, 2))
+    f[:, :, 2] = 10.0 ** rng.uniform(-3, 3, (n, 3))
+    k = n // 8
+    f[:k, 2, :2] = 0.5 * (f[:k, 0, :2] + f[:k, 1, :2]) + rng.uniform(-1e-6, 1e-6, (k, 2))      # slivers
+    f[k:2 * k, 2, :2] = f[k:2 * k, 1, :2]                                                       # repeated vertex
+    f[2 * k:3 * k, :, :2] *= 0.0                                                               # a point at the origin
+    f[3 * k:4 * k, :, :2] = rng.uniform(-3e3, 3e3, (k, 3, 2))                                    # beyond the fast-division range of the record
+    f[4 * k:5 * k, 0, :2] += rng.uniform(-2, 2, (k, 2))                                         # long thin faces across the screen
+    f[5 * k, 0, 0] = np.nan; f[5 * k + 1, 1, 1] = np.inf; f[5 * k + 2, 2, 2] = 0.0; f[5 * k + 3, :, 2] = np.nan
+    return f
+
+
+SCENES = {
+    "sphere3300_two_views_256": lambda: (syn.sphere_views(3300, 2)[0], 256, 1e-5),
+    "sphere39000_part_1024": lambda: (syn.sphere_views(39000, 1)[0][:, ::13], 1024, 1e-5),
+    "soup2000_128_sigma1e-4": lambda: (syn.triangle_soup(2000, 1, seed=1, scale=3.0)[0], 128, 1e-4),
+    "soup500_tiny_17": lambda: (syn.triangle_soup(500, 1, seed=2, scale=4.0)[0], 17, 1e-6),
+    "hostile_96": lambda: (hostile_faces(4000, 7), 96, 3e-5),
+}
+
+
+@pytest.mark.parametrize("scene", sorted(SCENES))
+def test_device_header_matches_the_oracle_pair_by_pair(lib, scene):
+    faces, IS, sigma = SCENES[scene]()
+    r = compare(lib, faces, IS, sigma)
+    assert r["pairs"] > 10000, r
+    assert all(r[k] == 0 for k in MISMATCH), {k: v for k, v in r.items() if v}
+    if scene.startswith("hostile"):
+        assert r["unsafe_faces"] > 400                      # the plain-division instantiation was really exercised on records of its own
+
+
+def test_the_refinement_quotients_lean_on_the_hardware_reciprocal(workdir):
+    """recip_exact = v_rcp_f32 + ONE Newton step is the IEEE reciprocal because of what v_rcp_f32 returns on gfx950 (checked for every
+    float on the device: jr_selftest_reciprocal, tests/test_gpu_parity.py::test_fast_division_identity) - it is NOT a property of any
+    reciprocal that is 1 ulp off.  With an adversarial neighbour as the seed a handful of depths per million differ by an ulp; nothing
+    else moves (the distance tree and the decisions never touch the approximate reciprocal)."""
+    d = os.path.join(workdir, "ulp")
+    os.makedirs(d, exist_ok=True)
+    lib1 = C.CDLL(build(d, extra=("-DHM_RCP_ULP_OFF=1",)))
+    faces, IS, sigma = SCENES["sphere3300_two_views_256"]()
+    r = compare(lib1, faces, IS, sigma)
+    assert all(r[k] == 0 for k in MISMATCH if k != "zp_refined"), {k: v for k, v in r.items() if v}
+    assert r["zp_refined"] <= 2e-5 * r["pairs"]
+
+
+def test_under_address_and_undefined_behaviour_sanitizers(workdir):
+    """The same comparison as a stand-alone executable built with -fsanitize=address,undefined -fno-sanitize-recover: out-of-bounds
+    indexing (edge / vertex tables of the record), signed overflow, invalid float -> int conversions and shifts in the per-pair
+    arithmetic would abort it.  (GPU AddressSanitizer is not available on this pool; this covers the arithmetic header, not the kernels'
+    memory traffic.)"""
+    d = os.path.join(workdir, "san")
+    os.makedirs(d, exist_ok=True)
+    try:
+        exe = build(d, extra=("-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"), exe=True)
+    except subprocess.CalledProcessError:
+        pytest.skip("the sanitizer runtimes are not installed")
+    for name in ("hostile_96", "soup500_tiny_17"):
+        faces, IS, sigma = SCENES[name]()
+        if name == "hostile_96":
+            faces = faces[np.isfinite(faces).all((1, 2))]       # (float -> int of NaN in the texel choice is the reference's own undefined corner: SRK:159-166)
+        path = os.path.join(d, name + ".bin")
+        np.ascontiguousarray(np.asarray(faces, np.float32).reshape(-1, 9)).tofile(path)
+        out = subprocess.run([exe, path, str(IS), repr(sigma), repr(DIST_EPS_LOG), "48"], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert out.returncode == 0, out.stderr[-3000:]
+        r = dict(zip(NAMES, [int(x) for x in out.stdout.split()]))
+        assert r["pairs"] > 10000 and all(r[k] == 0 for k in MISMATCH), r
