@@ -132,3 +132,28 @@ def test_under_address_and_undefined_behaviour_sanitizers(workdir):
         assert out.returncode == 0, out.stderr[-3000:]
         r = dict(zip(NAMES, [int(x) for x in out.stdout.split()]))
         assert r["pairs"] > 10000 and all(r[k] == 0 for k in MISMATCH), r
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_pixel_range_of_the_list_building_is_exact(workdir):
+    """jr::pixel_range (binning.hip) on the host - tests/host_math/binning_on_host.hip builds that file with its device functions compiled
+    for the host as well - against its definition: the pixel centres that pass the reference's border test on one axis.  Exactness is what
+    lets the forward skip its own box test and keeps faces that touch no pixel centre out of the lists.  Bounds are pixel centres moved by
+    0 - 3 ulps, uniform values, values far outside the image, infinities and NaN; every image size from 1 to 80 and the usual larger ones."""
+    out = os.path.join(workdir, "libhb.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-w",
+                           "-I", os.path.join(os.path.dirname(HERE), "..", "include"), "-I", os.path.join(os.path.dirname(HERE), "..", "jrender_amd", "csrc"),
+                           "-shared", os.path.join(HERE, "binning_on_host.hip"), "-o", out])
+    try:
+        lib = C.CDLL(out)
+    except OSError as e:                                   # (the HIP runtime library the object links against does not load on this host)
+        pytest.skip(str(e))
+    lib.hm_pixel_range_check.restype = C.c_long
+    bad = (C.c_float * 4)()
+    total = 0
+    for IS in list(range(1, 81)) + [96, 100, 127, 128, 255, 256, 511, 512, 1000, 1024, 2048, 4096]:
+        n = 20000 if IS <= 256 else 4000
+        wrong = lib.hm_pixel_range_check(IS, C.c_long(n), C.c_ulonglong(2024), bad)
+        assert wrong == 0, (IS, wrong, list(bad))
+        total += n
+    assert total > 1.5e6
