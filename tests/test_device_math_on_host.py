@@ -157,3 +157,68 @@ def test_pixel_range_of_the_list_building_is_exact(workdir):
         assert wrong == 0, (IS, wrong, list(bad))
         total += n
     assert total > 1.5e6
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_backward_pair_arithmetic_on_the_host_against_the_reference_s_exact_sums(workdir):
+    """jr::backward_pair (softras_backward.hip: the gradient of one (pixel, face) pair - all the backward kernel computes between fetching
+    a pair and reducing its components) built for the host by tests/host_math/backward_on_host.hip and run over whole images in the order
+    of the saved index buffer, its float terms summed in double.  Held to the exact (double) sum of the REFERENCE's float per-pair terms
+    (oracle/_ref: ref_softras_backward_exactsum) in all 18 distance x colour x alpha modes with one texel, 2 x 2 texels and vertex colours:
+    what remains is per-pair arithmetic only - no atomic order, no kernel organisation.  Measured 7e-7 of the largest component,
+    1.1e-4 element-wise (floor 1e-3): the gradient-only reciprocal multiplies."""
+    import itertools
+    from oracle import Oracle, _scalars, have_ref
+    if not have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    out = os.path.join(workdir, "libhbw.so")
+    root = os.path.join(os.path.dirname(HERE), "..")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-w",
+                           "-I", os.path.join(root, "include"), "-I", os.path.join(root, "jrender_amd", "csrc"),
+                           "-shared", os.path.join(HERE, "backward_on_host.hip"), "-o", out])
+    try:
+        lib = C.CDLL(out)
+    except OSError as e:
+        pytest.skip(str(e))
+    ref = Oracle("reference", nthreads=0)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def host_backward(saved, g):
+        p, s = _scalars(dict(saved["params"]))
+        fv, tex = saved["face_vertices"], saved["textures"]
+        NF, T = fv.shape[1], tex.shape[2]
+        IS, K = int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+        gf, gt, st = np.empty((NF, 9), np.float64), np.empty((NF, T, 3), np.float64), (C.c_long * 4)()
+        rc = lib.hm_backward_image(fp(fv), fp(tex), fp(saved["soft_colors"]), fp(saved["aggrs_info"]),
+                                   saved["faces_id_buffer"].ctypes.data_as(C.POINTER(C.c_int32)), fp(np.ascontiguousarray(g, np.float32)),
+                                   NF, T, IS, K, s["near"], s["far"], s["eps"], s["sigma"], s["dist"], s["dist_eps"], s["gamma"], s["rgb"], s["alpha"],
+                                   s["tex"], s["ds"], dp(gf), dp(gt), st)
+        assert rc == 0 and st[0] > 1000
+        return gf.reshape(1, NF, 3, 3), gt.reshape(1, NF, T, 3)
+
+    def errors(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        assert (np.isfinite(a) == np.isfinite(b)).all()
+        m = np.isfinite(b)
+        if not m.any() or np.abs(b[m]).max() == 0:
+            return 0.0, 0.0
+        top = np.abs(b[m]).max()
+        return float(np.abs(a - b)[m].max() / top), float((np.abs(a - b)[m] / (np.abs(b[m]) + 1e-3 * top)).max())
+
+    soup = syn.triangle_soup(300, 1, seed=3, texels=4, scale=5.0)
+    soup[0][..., :2] *= 0.55
+    scenes = {"surface4": soup, "surface1": syn.sphere_views(280, 1), "vertex": syn.sphere_views(280, 1, texels=3)}
+    worst = [0.0, 0.0]
+    for dist, rgb, alpha, tt in itertools.product(["hard", "barycentric", "euclidean"], ["hard", "softmax"], ["hard", "sum", "prod"], sorted(scenes)):
+        f, t = scenes[tt]
+        kw = dict(image_size=40, dist_func=dist, aggr_func_rgb=rgb, aggr_func_alpha=alpha, texture_type="vertex" if tt == "vertex" else "surface",
+                  sigma_val=1e-4, max_faces_per_pixel_for_grad=6)
+        s = ref.forward(f, t, **kw)
+        g = np.random.default_rng(1).uniform(-1, 1, s["soft_colors"].shape).astype(np.float32)
+        rf, rt = ref.backward_exactsum(s, g)
+        hf, ht = host_backward(s, g)
+        for name, (mx, el) in (("grad_faces", errors(hf, rf)), ("grad_textures", errors(ht, rt))):
+            assert mx <= 5e-6 and el <= 1e-3, (kw, tt, name, mx, el)
+            worst = [max(worst[0], mx), max(worst[1], el)]
+    assert worst[0] > 0                                      # (float terms against their exact sum: not literally the same computation)
