@@ -111,7 +111,12 @@ int hm_backward_image(const float* faces, const float* textures, const float* so
             } else if (T == 1) {                                                  // single texel (:531)
                 gt[0] += (double)(tw * q.g0); gt[1] += (double)(tw * q.g1); gt[2] += (double)(tw * q.g2);
             } else if (tex_on) {                                                  // the sampled texel (:509-514)
-                gt[texel * 3 + 0] += (double)(tgs * q.g0); gt[texel * 3 + 1] += (double)(tgs * q.g1); gt[texel * 3 + 2] += (double)(tgs * q.g2);
+                const float c[3] = {tgs * q.g0, tgs * q.g1, tgs * q.g2};
+                for (int k = 0; k < 3; k++) {
+                    gt[texel * 3 + k] += (double)c[k];
+                    if (!isfinite(c[k]))                                          // (:515-526: the reference's 0 * inf poisons the face's other texels)
+                        for (int jt = 0; jt < T; jt++) if (jt != texel) gt[jt * 3 + k] += (double)NAN;
+                }
             }
         }
     }

@@ -77,12 +77,12 @@ void image(const jr::RasterParams& p, const jr::FaceGeo* rec, const float* textu
 
 extern "C" {
 
-// One image (B = 1), the reference's layouts -> faces_info [NF,27], aggrs [2,IS,IS], rgba [4,IS,IS], ids [K,IS,IS] (K <= 16).
+// One image (B = 1), the reference's layouts -> faces_info [NF,27], aggrs [2,IS,IS], rgba [4,IS,IS], ids [K,IS,IS] (K <= 64).
 int hm_forward_image(const float* faces, const float* textures, int NF, int T, int IS, int K, float near_, float far_, float eps, float sigma,
                      int dist, float dist_eps, float gamma, int rgb, int alpha, int tex, int double_side,
                      float* faces_info, float* aggrs, float* rgba, int32_t* ids) {
     using namespace jr;
-    if (K < 1 || K > 16 || dist < 0 || dist > 2 || rgb < 0 || rgb > 1 || !KBuffer<16>::IDS_GLOBAL) return 1;
+    if (K < 1 || K > 64 || dist < 0 || dist > 2 || rgb < 0 || rgb > 1 || !KBuffer<16>::IDS_GLOBAL) return 1;
     const RasterParams p = host_params(NF, T, IS, K, near_, far_, eps, sigma, dist, dist_eps, gamma, rgb, alpha, tex, double_side);
     FaceGeo* rec = new FaceGeo[NF > 0 ? NF : 1];
     for (int fn = 0; fn < NF; fn++) {
@@ -93,9 +93,12 @@ int hm_forward_image(const float* faces, const float* textures, int NF, int T, i
     for (long i = 0; i < (long)K * IS * IS; i++) ids[i] = -1;            // slots that are never filled (the kernels: store_ids at the end)
     // the kernels' choice of the distance instantiation (softras_forward.hip: launch_softras_forward)
     const int d = (p.dist == 2 && ((p.alpha == 0 && tune::fwd_hard_exact) || p.sigma < tune::fwd_exact_inside_sigma)) ? 3 : p.dist;
-#define HM_RUN(D) (rgb == 0 ? image<D, 0, 16>(p, rec, textures, aggrs, rgba, ids) : image<D, 1, 16>(p, rec, textures, aggrs, rgba, ids))
+    // ... and of the K-buffer capacity: 16, 32 or 64 depth registers (softras_forward.hip:1481-1483)
+#define HM_RUN_K(D, KC) (rgb == 0 ? image<D, 0, KC>(p, rec, textures, aggrs, rgba, ids) : image<D, 1, KC>(p, rec, textures, aggrs, rgba, ids))
+#define HM_RUN(D) (K <= 16 ? HM_RUN_K(D, 16) : (K <= 32 ? HM_RUN_K(D, 32) : HM_RUN_K(D, 64)))
     if (d == 0) HM_RUN(0); else if (d == 1) HM_RUN(1); else if (d == 2) HM_RUN(2); else HM_RUN(3);
 #undef HM_RUN
+#undef HM_RUN_K
     delete[] rec;
     return 0;
 }

@@ -210,7 +210,7 @@ def test_backward_pair_arithmetic_on_the_host_against_the_reference_s_exact_sums
                                    saved["faces_id_buffer"].ctypes.data_as(C.POINTER(C.c_int32)), fp(np.ascontiguousarray(g, np.float32)),
                                    NF, T, IS, K, s["near"], s["far"], s["eps"], s["sigma"], s["dist"], s["dist_eps"], s["gamma"], s["rgb"], s["alpha"],
                                    s["tex"], s["ds"], dp(gf), dp(gt), st)
-        assert rc == 0 and st[0] > 1000
+        assert rc == 0
         return gf.reshape(1, NF, 3, 3), gt.reshape(1, NF, T, 3)
 
     def errors(a, b):
@@ -220,7 +220,8 @@ def test_backward_pair_arithmetic_on_the_host_against_the_reference_s_exact_sums
         if not m.any() or np.abs(b[m]).max() == 0:
             return 0.0, 0.0
         top = np.abs(b[m]).max()
-        return float(np.abs(a - b)[m].max() / top), float((np.abs(a - b)[m] / (np.abs(b[m]) + 1e-3 * top)).max())
+        d = np.abs(a[m] - b[m])
+        return float(d.max() / top), float((d / (np.abs(b[m]) + 1e-3 * top)).max())
 
     soup = syn.triangle_soup(300, 1, seed=3, texels=4, scale=5.0)
     soup[0][..., :2] *= 0.55
@@ -238,6 +239,22 @@ def test_backward_pair_arithmetic_on_the_host_against_the_reference_s_exact_sums
             assert mx <= 5e-6 and el <= 1e-3, (kw, tt, name, mx, el)
             worst = [max(worst[0], mx), max(worst[1], el)]
     assert worst[0] > 0                                      # (float terms against their exact sum: not literally the same computation)
+    # randomised cases of the GPU sweep's generator (tests/fuzz_parity.py), one view each; non-finite gradients (overflowed weights poison
+    # a face's texels in the reference, SRK:1317-1320) must appear in the same places
+    from tests.fuzz_parity import draw_case
+    rng = np.random.default_rng(7)
+    done = 0
+    while done < 80:
+        kind, f, t, kw = draw_case(rng)
+        if f.shape[1] * kw["image_size"] ** 2 > 1e7:
+            continue
+        s = ref.forward(f[:1], t[:1], **kw)
+        g = rng.uniform(-1, 1, s["soft_colors"].shape).astype(np.float32)
+        rf, rt = ref.backward_exactsum(s, g)
+        hf, ht = host_backward(s, g)
+        for name, (mx, el) in (("grad_faces", errors(hf, rf)), ("grad_textures", errors(ht, rt))):
+            assert mx <= 2e-5 and el <= 1e-3, (kind, kw, name, mx, el)
+        done += 1
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
@@ -273,6 +290,24 @@ def test_forward_state_machine_on_the_host_gives_the_oracle_s_index_buffer(workd
     soup = syn.triangle_soup(300, 1, seed=3, texels=4, scale=5.0)
     soup[0][..., :2] *= 0.55
     scenes = {"surface4": soup, "surface1": syn.sphere_views(280, 1), "vertex": syn.sphere_views(280, 1, texels=3)}
+    # randomised cases of the GPU sweep's own generator (tests/fuzz_parity.py: scene kind, modes, K up to 64, sigma down to 1e-6, gamma,
+    # near / far, texture layout), one view each, capped in size for the CPU
+    from tests.fuzz_parity import draw_case
+    rng = np.random.default_rng(20261001)
+    fuzzed = 0
+    while fuzzed < 250:
+        kind, f, t, kw = draw_case(rng)
+        if f.shape[1] * kw["image_size"] ** 2 > 2e7:
+            continue
+        f, t = f[:1], t[:1]
+        a = port.forward(f, t, **kw)
+        if port.ub_events():
+            continue
+        b = host_forward(f, t, **kw)
+        assert bits_equal(a["faces_info"], b["faces_info"]), (kind, kw)
+        assert bits_equal(a["faces_id_buffer"], b["faces_id_buffer"]), (kind, kw, int((a["faces_id_buffer"] != b["faces_id_buffer"]).any(1).sum()))
+        assert rel_err(b["soft_colors"], a["soft_colors"], RGBA_ATOL) <= 1.0 and rel_err(b["aggrs_info"], a["aggrs_info"], RGBA_ATOL) <= 1.0, (kind, kw)
+        fuzzed += 1
     compared, worst = 0, 0.0
     for dist, rgb, alpha, tt, fb in itertools.product(["hard", "barycentric", "euclidean"], ["hard", "softmax"], ["hard", "sum", "prod"], sorted(scenes), [True, False]):
         f, t = scenes[tt]
