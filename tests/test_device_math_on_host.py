@@ -323,6 +323,29 @@ def test_forward_state_machine_on_the_host_gives_the_oracle_s_index_buffer(workd
         assert e <= 1.0, (kw, tt, e)
         compared, worst = compared + 1, max(worst, e)
     assert compared >= 100
+    # the committed vectors: written by the reference's kernels (bin_size = 0 and coarse-to-fine), and the inputs of the pinned last-bit corners
+    import glob
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(gold, "*.npz"))):
+        z = np.load(path)
+        if "params" in z and "face_vertices" in z:
+            kw = {k: v for k, v in json.loads(str(z["params"])).items() if k not in ("bin_size", "max_elems_per_bin")}
+            for v in range(z["face_vertices"].shape[0]):
+                b = host_forward(z["face_vertices"][v:v + 1], z["textures"][v:v + 1], **kw)
+                assert bits_equal(b["faces_id_buffer"], z["faces_id_buffer"][v:v + 1]) and bits_equal(b["faces_info"], z["faces_info"][v:v + 1]), path
+                assert rel_err(b["soft_colors"], z["soft_colors"][v:v + 1], RGBA_ATOL) <= 1.0, path
+            seen += 1
+        elif os.path.basename(path).startswith("regress_") and "kw" in z:
+            import ast
+            kw = ast.literal_eval(str(z["kw"]))             # (written as a Python dict literal by the sweep)
+            for v in range(z["fv"].shape[0]):
+                a = port.forward(z["fv"][v:v + 1], z["tex"][v:v + 1], **kw)
+                b = host_forward(z["fv"][v:v + 1], z["tex"][v:v + 1], **kw)
+                assert bits_equal(a["faces_id_buffer"], b["faces_id_buffer"]) and rel_err(b["soft_colors"], a["soft_colors"], RGBA_ATOL) <= 1.0, path
+            seen += 1
+    assert seen >= 12
     # a crowded scene at the operator's defaults: sigma 1e-5, K = 16 with replacements, two bigger images
     for (f, t), IS in ((syn.sphere_views(3300, 1), 128), (soup, 96)):
         a, b = port.forward(f, t, image_size=IS), host_forward(f, t, image_size=IS)
