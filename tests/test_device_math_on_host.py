@@ -351,3 +351,34 @@ def test_forward_state_machine_on_the_host_gives_the_oracle_s_index_buffer(workd
         a, b = port.forward(f, t, image_size=IS), host_forward(f, t, image_size=IS)
         if not port.ub_events():
             assert bits_equal(a["faces_id_buffer"], b["faces_id_buffer"]) and rel_err(b["soft_colors"], a["soft_colors"], RGBA_ATOL) <= 1.0
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_nmr_forward_face_and_pixel_functions_on_the_host(workdir):
+    """The second renderer path (dr_type='n3mr'): n3_face_inv and n3_pixel of n3mr_kernels.hip - face set-up, coverage test,
+    clamped weights and depth of one (face, pixel) pair (N3K:63-134) - built for the host by tests/host_math/n3mr_on_host.hip and driven by
+    a serial form of k_n3mr_zbuffer (depth test = minimum of the packed (depth bits, face index) key).  Against the reference's own NMR
+    kernels compiled for the host: faces_inv, the face-index map, the depth map and the winner's weights, bit for bit."""
+    from oracle import N3mrOracle
+    from tests.util import bits_equal
+    try:
+        orc = N3mrOracle("reference")
+    except FileNotFoundError:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    lib = build_hip_for_the_host("n3mr_on_host", workdir)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    back = syn.sphere_views(280, 1)[0][:, :, ::-1].copy()                                        # reversed winding: every face of the near side is a back side
+    scenes = {"sphere280_64": (syn.sphere_views(280, 1)[0], 64), "soup800_96": (syn.triangle_soup(800, 1, seed=5, scale=3.0)[0], 96),
+              "sphere3300_128": (syn.sphere_views(3300, 1)[0], 128), "sphere280_reversed_48": (back, 48),
+              "hostile_64": (hostile_faces(1500, 11)[np.isfinite(hostile_faces(1500, 11)).all((1, 2))][None], 64)}
+    for name, (fv, IS) in scenes.items():
+        f = np.ascontiguousarray(np.asarray(fv, np.float32).reshape(1, -1, 9))
+        NF = f.shape[1]
+        a = orc.forward(f.reshape(1, NF, 3, 3), None, image_size=IS, near=0.1, far=100, return_rgb=False, return_alpha=True, return_depth=True)
+        finv, fim = np.empty((1, NF, 9), np.float32), np.empty((1, IS, IS), np.int32)
+        dm, wm = np.empty((1, IS, IS), np.float32), np.empty((1, IS, IS, 3), np.float32)
+        assert lib.hm_n3mr_zbuffer(fp(f), NF, IS, C.c_float(0.1), C.c_float(100.0), fp(finv), fim.ctypes.data_as(C.POINTER(C.c_int32)), fp(dm), fp(wm)) == 0
+        for key, mine in (("faces_inv", finv), ("face_index_map", fim), ("depth_map", dm), ("weight_map", wm)):
+            assert bits_equal(mine, a[key]), (name, key)
+        if "reversed" not in name and "hostile" not in name:
+            assert (fim >= 0).sum() > 1000
