@@ -40,7 +40,7 @@ def build(out_dir, extra=(), exe=False):
     return out
 
 
-def build_hip_for_the_host(name, out_dir):
+def build_hip_for_the_host(name, out_dir, extra=(), load=True):
     """tests/host_math/<name>.hip -> shared object with the HOST side only.  The file includes a kernel source of the product with its
     device functions also built for the host; compiling the device side too would cost minutes (the forward: 2 min 16 s) for code this
     test never launches.  --cuda-host-only leaves ONE undefined symbol, the embedded device binary the object registers when it is
@@ -49,7 +49,7 @@ def build_hip_for_the_host(name, out_dir):
     root = os.path.join(os.path.dirname(HERE), "..")
     obj = os.path.join(out_dir, name + ".o")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "--cuda-host-only", "-cuid=jr_" + name, "-O2", "-std=c++17", "-ffp-contract=off",
-                           "-fno-fast-math", "-fPIC", "-w", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "jrender_amd", "csrc"),
+                           "-fno-fast-math", "-fPIC", "-w", *extra, "-I", os.path.join(root, "include"), "-I", os.path.join(root, "jrender_amd", "csrc"),
                            "-c", os.path.join(HERE, name + ".hip"), "-o", obj])
     syms = [l.split()[-1] for l in subprocess.check_output(["nm", obj], text=True).splitlines() if " U __hip_fatbin_" in l]
     assert len(syms) == 1, syms
@@ -65,6 +65,8 @@ def build_hip_for_the_host(name, out_dir):
     subprocess.check_call(["gcc", "-c", asm, "-o", fbo])
     out = os.path.join(out_dir, "lib" + name + ".so")
     subprocess.check_call([hipcc, "-shared", obj, fbo, "-o", out])
+    if not load:
+        return out
     try:
         return C.CDLL(out)
     except OSError as e:                                   # (the HIP runtime library the object links against does not load on this host)
@@ -382,3 +384,58 @@ def test_nmr_forward_face_and_pixel_functions_on_the_host(workdir):
             assert bits_equal(mine, a[key]), (name, key)
         if "reversed" not in name and "hostile" not in name:
             assert (fim >= 0).sum() > 1000
+
+
+UBSAN_DRIVER = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, sys.argv[3])
+from oracle import Oracle, _scalars
+from tests.fuzz_parity import draw_case
+fwd, bwd = C.CDLL(sys.argv[1]), C.CDLL(sys.argv[2])
+port = Oracle("port", nthreads=0)
+fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+rng = np.random.default_rng(99)
+done = 0
+while done < 60:
+    kind, f, t, kw = draw_case(rng)
+    if f.shape[1] * kw["image_size"] ** 2 > 6e6:
+        continue
+    s = port.forward(f[:1], t[:1], **kw)
+    p, sc = _scalars(kw)
+    fv, tex = s["face_vertices"], s["textures"]
+    NF, T, IS, K = fv.shape[1], tex.shape[2], int(p["image_size"]), int(p["max_faces_per_pixel_for_grad"])
+    common = (sc["near"], sc["far"], sc["eps"], sc["sigma"], sc["dist"], sc["dist_eps"], sc["gamma"], sc["rgb"], sc["alpha"], sc["tex"], sc["ds"])
+    info, aggr = np.empty((1, NF, 27), np.float32), np.empty((1, 2, IS, IS), np.float32)
+    rgba, ids = np.empty((1, 4, IS, IS), np.float32), np.empty((1, K, IS, IS), np.int32)
+    assert fwd.hm_forward_image(fp(fv), fp(tex), NF, T, IS, K, *common, fp(info), fp(aggr), fp(rgba), ids.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    assert (ids == s["faces_id_buffer"]).all()
+    g = rng.uniform(-1, 1, rgba.shape).astype(np.float32)
+    gf, gt, st = np.empty((NF, 9), np.float64), np.empty((NF, T, 3), np.float64), (C.c_long * 4)()
+    assert bwd.hm_backward_image(fp(fv), fp(tex), fp(rgba), fp(aggr), ids.ctypes.data_as(C.POINTER(C.c_int32)), fp(g), NF, T, IS, K, *common, dp(gf), dp(gt), st) == 0
+    done += 1
+print("UBSAN_OK", done)
+"""
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_forward_and_backward_pair_code_under_trapping_ubsan(workdir):
+    """The host builds of the forward state machine and the backward pair function once more with -fsanitize=undefined -fsanitize-trap=all
+    (undefined behaviour executes a trap instruction: no sanitizer runtime to preload into python) over 60 randomised cases in a child
+    process: signed overflow, out-of-range shifts, misaligned or null accesses and out-of-bounds indexing of the K-buffer / record tables
+    in the kernels' per-pair code would kill the child."""
+    import sys
+    d = os.path.join(workdir, "ubsan")
+    os.makedirs(d, exist_ok=True)
+    flags = ("-g", "-fsanitize=undefined", "-fsanitize-trap=all", "-fno-sanitize=float-divide-by-zero")
+    try:
+        fwd = build_hip_for_the_host("forward_on_host", d, extra=flags, load=False)
+        bwd = build_hip_for_the_host("backward_on_host", d, extra=flags, load=False)
+    except subprocess.CalledProcessError:
+        pytest.skip("this hipcc does not build with -fsanitize=undefined")
+    root = os.path.abspath(os.path.join(os.path.dirname(HERE), ".."))
+    out = subprocess.run([sys.executable, "-c", UBSAN_DRIVER, fwd, bwd, root], capture_output=True, text=True, timeout=900)
+    if out.returncode != 0 and "cannot open shared object" in out.stderr:
+        pytest.skip(out.stderr[-300:])
+    assert out.returncode == 0 and "UBSAN_OK 60" in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-2000:])
